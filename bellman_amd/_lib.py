@@ -1,0 +1,92 @@
+"""Loader of the C-ABI shared library (include/bellman_hip.h).
+
+There is NO CPU fallback: if libbellman_hip.so is missing, or no gfx950 device is visible
+when a context is requested, this raises.  The library is built in-tree by
+`make -C bellman_amd/csrc` (or `__graft_entry__.build()`).
+"""
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
+
+# every symbol include/bellman_hip.h declares
+EXPORTS = [
+    "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus",
+    "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_ctx_synchronize",
+    "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
+    "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
+    "bh_bases_register", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
+    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_set_window_bits",
+    "bh_fixed_base_mul_dev",
+    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
+    "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host",
+]
+
+
+def build(jobs=8):
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j%d" % jobs])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libbellman_hip.so not built (run `make -C bellman_amd/csrc`); "
+            "bellman_amd has no CPU fallback"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, sz, u32, i32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_int
+    lib.bh_version.restype = c.c_char_p
+    lib.bh_ctx_create.argtypes = [i32, c.POINTER(vp)]
+    lib.bh_ctx_destroy.argtypes = [vp]
+    lib.bh_ctx_destroy.restype = None
+    lib.bh_ctx_log_num_cus.argtypes = [vp]
+    lib.bh_ctx_log_num_cus.restype = u32
+    lib.bh_dev_alloc.argtypes = [vp, sz, c.POINTER(vp)]
+    lib.bh_dev_free.argtypes = [vp, vp]
+    lib.bh_dev_upload.argtypes = [vp, vp, vp, sz]
+    lib.bh_dev_download.argtypes = [vp, vp, vp, sz]
+    lib.bh_ctx_synchronize.argtypes = [vp]
+    lib.bh_fft_fr.argtypes = [vp, vp, u32, i32]
+    lib.bh_fft_fr_dev.argtypes = [vp, vp, u32, i32, vp]
+    lib.bh_fr_mul_assign_dev.argtypes = [vp, vp, vp, sz, vp]
+    lib.bh_fr_sub_assign_dev.argtypes = [vp, vp, vp, sz, vp]
+    lib.bh_fr_divide_by_z_on_coset_dev.argtypes = [vp, vp, u32, vp]
+    lib.bh_fr_distribute_powers_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.bh_h_poly_fr.argtypes = [vp, vp, vp, vp, sz, vp, c.POINTER(sz)]
+    lib.bh_h_poly_fr_dev.argtypes = [vp, vp, vp, vp, u32, vp]
+    lib.bh_bases_register.argtypes = [vp, i32, vp, sz, sz, c.c_long, c.POINTER(vp)]
+    lib.bh_bases_wrap_dev.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]
+    lib.bh_bases_release.argtypes = [vp, vp]
+    lib.bh_bases_release.restype = None
+    lib.bh_bases_len.argtypes = [vp]
+    lib.bh_bases_len.restype = sz
+    lib.bh_msm_async.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, c.POINTER(vp)]
+    lib.bh_msm_async_dev.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, c.POINTER(vp)]
+    lib.bh_msm_wait.argtypes = [vp, vp]
+    lib.bh_msm_wait_timed.argtypes = [vp, vp, c.POINTER(c.c_float)]
+    lib.bh_msm_set_window_bits.argtypes = [vp, c.c_uint]
+    lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
+    lib.bh_test_fr_mul_dev.argtypes = [vp, vp, vp, vp, sz]
+    lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
+    lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]
+    lib.bh_test_msm_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp, vp]
+    for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host"):
+        getattr(lib, name).argtypes = [vp, vp, vp, sz]
+        getattr(lib, name).restype = None
+    lib.bh_test_point_add_host.argtypes = [i32, vp, vp, vp, sz]
+    lib.bh_test_point_add_host.restype = None
+    lib.bh_test_point_mul_host.argtypes = [i32, vp, vp, vp]
+    lib.bh_test_point_mul_host.restype = None
+    _lib = lib
+    return lib

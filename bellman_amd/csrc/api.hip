@@ -1,0 +1,351 @@
+// extern "C" surface of libbellman_hip (declared and documented in include/bellman_hip.h).
+#include <string.h>
+
+#include <atomic>
+
+#include "common.hpp"
+
+namespace bh {
+// fft.hip
+int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hipStream_t st);
+int fr_mul_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st);
+int fr_sub_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st);
+int fr_divide_by_z(Context &c, fr_t *a, uint32_t log_n, hipStream_t st);
+int fr_distribute_powers(Context &c, fr_t *a, u64 n, const fr_t &g, hipStream_t st);
+int h_poly_dev(Context &c, fr_t *a, fr_t *b, fr_t *cc, fr_t *scratch, uint32_t log_n, hipStream_t st);
+// msm.hip
+struct MsmJobImpl;
+MsmJobImpl *msm_job_new(Context *ctx, int group);
+void msm_job_delete(MsmJobImpl *j);
+int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
+                    int fmt, const u64 *density_dev, unsigned forced_c);
+int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
+hipStream_t msm_job_stream(MsmJobImpl &job);
+void msm_job_own(MsmJobImpl &job, void *dev_ptr);
+int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
+                   hipStream_t st);
+int test_point_add(int group, void *r, const void *a, const void *b, u64 n, hipStream_t st);
+int test_fr_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
+int test_fp_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
+void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
+int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
+                    u32 *start_out, u32 *total_tasks_out);
+void host_point_mul(int group, void *r, const void *a, const void *k);
+
+static std::atomic<unsigned> g_forced_c{0};
+
+// packs strided host records (optionally with an `infinity` flag byte) into dense device records
+__global__ void pack_bases_kernel(const unsigned char *raw, size_t stride, long inf_offset, u32 rec_words,
+                                  u32 *out, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char *src = raw + i * stride;
+  const bool inf = inf_offset >= 0 && src[inf_offset] != 0;
+  for (u32 w = 0; w < rec_words; w++) {
+    u32 v = 0;
+    if (!inf) v = (u32)src[4 * w] | ((u32)src[4 * w + 1] << 8) | ((u32)src[4 * w + 2] << 16) | ((u32)src[4 * w + 3] << 24);
+    out[i * rec_words + w] = v;
+  }
+}
+}  // namespace bh
+
+using namespace bh;
+
+struct bh_bases {
+  int group;
+  void *dev;
+  size_t n;
+  bool owned;
+};
+struct bh_msm_job {
+  MsmJobImpl *impl;
+};
+
+static inline hipStream_t pick_stream(bh_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->c.stream; }
+
+extern "C" {
+
+const char *bh_version(void) { return "bellman_hip 0.1 (gfx950)"; }
+
+int bh_ctx_create(int device, bh_ctx **out) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= device || device < 0) return BH_ERR_NO_DEVICE;
+  BH_HIP_CHECK(hipSetDevice(device));
+  bh_ctx *ctx = new bh_ctx();
+  ctx->c.device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->c.num_cus = prop.multiProcessorCount;
+  BH_HIP_CHECK(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
+  *out = ctx;
+  return BH_OK;
+}
+void bh_ctx_destroy(bh_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->c.device);
+  (void)hipDeviceSynchronize();
+  for (auto &kv : ctx->c.fft_tables) {
+    if (kv.second.tw) (void)hipFree(kv.second.tw);
+    if (kv.second.coset) (void)hipFree(kv.second.coset);
+    if (kv.second.icoset) (void)hipFree(kv.second.icoset);
+  }
+  ctx->c.pool.release_all();
+  if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
+  delete ctx;
+}
+uint32_t bh_ctx_log_num_cus(const bh_ctx *ctx) {
+  uint32_t p = 0;
+  while ((1u << (p + 1)) <= (uint32_t)ctx->c.num_cus) p++;
+  return p;
+}
+int bh_dev_alloc(bh_ctx *ctx, size_t bytes, void **dev_ptr) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  BH_HIP_CHECK(hipMalloc(dev_ptr, bytes ? bytes : 16));
+  return BH_OK;
+}
+int bh_dev_free(bh_ctx *ctx, void *dev_ptr) {
+  (void)ctx;
+  BH_HIP_CHECK(hipFree(dev_ptr));
+  return BH_OK;
+}
+int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+  BH_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+  BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  return BH_OK;
+}
+int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+  BH_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+  BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  return BH_OK;
+}
+int bh_ctx_synchronize(bh_ctx *ctx) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  BH_HIP_CHECK(hipDeviceSynchronize());
+  return BH_OK;
+}
+
+// ---- EvaluationDomain ------------------------------------------------------------------------
+int bh_fft_fr_dev(bh_ctx *ctx, void *data_dev, uint32_t log_n, int mode, void *stream) {
+  if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  if (mode < 0 || mode > 3) return BH_ERR_INVALID_ARG;
+  hipStream_t st = pick_stream(ctx, stream);
+  void *scratch = nullptr;
+  if (log_n > 10) {
+    scratch = ctx->c.pool.acquire(sizeof(fr_t) << log_n);
+    if (!scratch) return BH_ERR_HIP;
+  }
+  int rc = ntt_run(ctx->c, (fr_t *)data_dev, (fr_t *)scratch, log_n, mode, st);
+  if (scratch) {
+    // the scratch buffer may be recycled by another stream: fence before returning it
+    if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+    ctx->c.pool.release(scratch);
+  }
+  return rc;
+}
+int bh_fft_fr(bh_ctx *ctx, void *data_host, uint32_t log_n, int mode) {
+  if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  const size_t bytes = sizeof(fr_t) << log_n;
+  void *d = ctx->c.pool.acquire(bytes);
+  if (!d) return BH_ERR_HIP;
+  int rc = bh_dev_upload(ctx, d, data_host, bytes);
+  if (rc == BH_OK) rc = bh_fft_fr_dev(ctx, d, log_n, mode, nullptr);
+  if (rc == BH_OK) rc = bh_dev_download(ctx, data_host, d, bytes);
+  ctx->c.pool.release(d);
+  return rc;
+}
+int bh_fr_mul_assign_dev(bh_ctx *ctx, void *a, const void *b, size_t n, void *stream) {
+  return fr_mul_assign(ctx->c, (fr_t *)a, (const fr_t *)b, n, pick_stream(ctx, stream));
+}
+int bh_fr_sub_assign_dev(bh_ctx *ctx, void *a, const void *b, size_t n, void *stream) {
+  return fr_sub_assign(ctx->c, (fr_t *)a, (const fr_t *)b, n, pick_stream(ctx, stream));
+}
+int bh_fr_divide_by_z_on_coset_dev(bh_ctx *ctx, void *a, uint32_t log_n, void *stream) {
+  if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  return fr_divide_by_z(ctx->c, (fr_t *)a, log_n, pick_stream(ctx, stream));
+}
+int bh_fr_distribute_powers_dev(bh_ctx *ctx, void *a, size_t n, const void *g_host, void *stream) {
+  fr_t g;
+  memcpy(&g, g_host, sizeof g);
+  return fr_distribute_powers(ctx->c, (fr_t *)a, n, g, pick_stream(ctx, stream));
+}
+int bh_h_poly_fr_dev(bh_ctx *ctx, void *a, void *b, void *c, uint32_t log_n, void *stream) {
+  if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  hipStream_t st = pick_stream(ctx, stream);
+  void *scratch = ctx->c.pool.acquire(sizeof(fr_t) << log_n);
+  if (!scratch) return BH_ERR_HIP;
+  int rc = h_poly_dev(ctx->c, (fr_t *)a, (fr_t *)b, (fr_t *)c, (fr_t *)scratch, log_n, st);
+  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  ctx->c.pool.release(scratch);
+  return rc;
+}
+int bh_h_poly_fr(bh_ctx *ctx, const void *a_host, const void *b_host, const void *c_host, size_t n_evals,
+                 void *h_out_host, size_t *h_len) {
+  // EvaluationDomain::from_coeffs (domain.rs:47-79): m = next power of two >= len, zero padded
+  uint32_t log_n = 0;
+  size_t m = 1;
+  while (m < n_evals) {
+    m *= 2;
+    log_n++;
+    if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  }
+  const size_t bytes = sizeof(fr_t) * m, in_bytes = sizeof(fr_t) * n_evals;
+  void *d[3] = {ctx->c.pool.acquire(bytes), ctx->c.pool.acquire(bytes), ctx->c.pool.acquire(bytes)};
+  const void *h[3] = {a_host, b_host, c_host};
+  int rc = (d[0] && d[1] && d[2]) ? BH_OK : BH_ERR_HIP;
+  for (int i = 0; i < 3 && rc == BH_OK; i++) {
+    if (hipMemsetAsync(d[i], 0, bytes, ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
+    if (rc == BH_OK && in_bytes &&
+        hipMemcpyAsync(d[i], h[i], in_bytes, hipMemcpyHostToDevice, ctx->c.stream) != hipSuccess)
+      rc = BH_ERR_HIP;
+  }
+  if (rc == BH_OK) rc = bh_h_poly_fr_dev(ctx, d[0], d[1], d[2], log_n, nullptr);
+  if (rc == BH_OK) rc = bh_dev_download(ctx, h_out_host, d[0], sizeof(fr_t) * (m - 1));   // prover.rs:238-239
+  if (h_len) *h_len = m - 1;
+  for (int i = 0; i < 3; i++) ctx->c.pool.release(d[i]);
+  return rc;
+}
+
+// ---- bases -------------------------------------------------------------------------------------
+int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n, size_t stride, long inf_offset,
+                      bh_bases **out) {
+  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  if (stride < rec) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *dev = nullptr;
+  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  if (n) {
+    if (stride == rec && inf_offset < 0) {
+      BH_HIP_CHECK(hipMemcpyAsync(dev, host_points, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
+    } else {
+      void *raw = nullptr;
+      BH_HIP_CHECK(hipMalloc(&raw, n * stride));
+      BH_HIP_CHECK(hipMemcpyAsync(raw, host_points, n * stride, hipMemcpyHostToDevice, ctx->c.stream));
+      hipLaunchKernelGGL(pack_bases_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->c.stream,
+                         (const unsigned char *)raw, stride, inf_offset, (u32)(rec / 4), (u32 *)dev, (u64)n);
+      BH_HIP_CHECK(hipGetLastError());
+      BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+      BH_HIP_CHECK(hipFree(raw));
+    }
+    BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  }
+  *out = new bh_bases{group, dev, n, true};
+  return BH_OK;
+}
+int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {
+  (void)ctx;
+  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
+  *out = new bh_bases{group, const_cast<void *>(dev_points), n, false};
+  return BH_OK;
+}
+void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
+  (void)ctx;
+  if (!b) return;
+  if (b->owned && b->dev) (void)hipFree(b->dev);
+  delete b;
+}
+size_t bh_bases_len(const bh_bases *b) { return b->n; }
+
+// ---- multiexp -----------------------------------------------------------------------------------
+int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c) {
+  (void)ctx;
+  g_forced_c.store(c);
+  return BH_OK;
+}
+static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
+                      size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
+                      bh_msm_job **out) {
+  if (!bases || !out) return BH_ERR_INVALID_ARG;
+  if (fmt != BH_SCALARS_CANONICAL && fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
+  if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);
+  if (!impl) return BH_ERR_HIP;
+  hipStream_t st = msm_job_stream(*impl);
+  const void *sc_dev = scalars;
+  const u64 *dn_dev = density;
+  int rc = BH_OK;
+  if (n && scalars_on_host) {
+    void *p = ctx->c.pool.acquire(n * 32);
+    if (!p) rc = BH_ERR_HIP;
+    else {
+      msm_job_own(*impl, p);
+      if (hipMemcpyAsync(p, scalars, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
+      sc_dev = p;
+    }
+  }
+  if (rc == BH_OK && n && density && density_on_host) {
+    const size_t nw = (n + 63) / 64;
+    void *p = ctx->c.pool.acquire(nw * 8);
+    if (!p) rc = BH_ERR_HIP;
+    else {
+      msm_job_own(*impl, p);
+      if (hipMemcpyAsync(p, density, nw * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
+      dn_dev = (const u64 *)p;
+    }
+  }
+  if (rc == BH_OK)
+    rc = msm_job_enqueue(*impl, bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev, g_forced_c.load());
+  if (rc != BH_OK) {
+    float ms;
+    unsigned char dummy[192];
+    (void)msm_job_finish(*impl, dummy, &ms);
+    msm_job_delete(impl);
+    return rc;
+  }
+  *out = new bh_msm_job{impl};
+  return BH_OK;
+}
+int bh_msm_async(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host, size_t n, int fmt,
+                 const uint64_t *density_words, size_t density_len, bh_msm_job **job) {
+  return msm_common(ctx, bases, skip, scalars_host, true, n, fmt, density_words, true, density_len, job);
+}
+int bh_msm_async_dev(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev, size_t n, int fmt,
+                     const uint64_t *density_words_dev, size_t density_len, bh_msm_job **job) {
+  return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, job);
+}
+int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms) {
+  if (!job) return BH_ERR_INVALID_ARG;
+  int rc = msm_job_finish(*job->impl, out_affine, device_ms);
+  msm_job_delete(job->impl);
+  delete job;
+  return rc;
+}
+int bh_msm_wait(bh_msm_job *job, void *out_affine) { return bh_msm_wait_timed(job, out_affine, nullptr); }
+
+int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host, const void *scalars_dev, size_t n,
+                          int fmt, void *out_dev, void *stream) {
+  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
+  return fixed_base_mul(group, base_affine_host, scalars_dev, n, fmt, out_dev, pick_stream(ctx, stream));
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------
+int bh_test_fr_mul_dev(bh_ctx *ctx, void *r, const void *a, const void *b, size_t n) {
+  int rc = test_fr_mul(r, a, b, n, ctx->c.stream);
+  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  return rc;
+}
+int bh_test_fp_mul_dev(bh_ctx *ctx, void *r, const void *a, const void *b, size_t n) {
+  int rc = test_fp_mul(r, a, b, n, ctx->c.stream);
+  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  return rc;
+}
+int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r, const void *a, const void *b, size_t n) {
+  int rc = test_point_add(group, r, a, b, n, ctx->c.stream);
+  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  return rc;
+}
+int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
+                       uint64_t *pairs_out_host, uint32_t *start_out_host, uint32_t *total_tasks_out) {
+  return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, start_out_host,
+                         total_tasks_out);
+}
+void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
+  for (size_t i = 0; i < n; i++) fe_mul(((fr_t *)r)[i], ((const fr_t *)a)[i], ((const fr_t *)b)[i]);
+}
+void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
+  for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
+}
+void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { host_point_add(group, r, a, b, n); }
+void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { host_point_mul(group, r, a, k); }
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Shared host-side plumbing for libbellman_hip: error codes, context, workspace cache.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/bellman_hip.h"
+#include "ec.cuh"
+#include "ff.cuh"
+
+namespace bh {
+
+#define BH_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      fprintf(stderr, "[bellman_hip] %s failed: %s (%s:%d)\n", #expr,                   \
+              hipGetErrorString(_e), __FILE__, __LINE__);                               \
+      return BH_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+// Size-bucketed cache of device allocations: hipMalloc/hipFree synchronise the device, so
+// the per-call workspaces of the (asynchronous, concurrent) MSM entry points are recycled.
+class DevicePool {
+ public:
+  ~DevicePool() { release_all(); }
+  void *acquire(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    size_t cap = 256;
+    while (cap < bytes) cap <<= 1;
+    if (cap > (size_t(1) << 30)) cap = (bytes + ((size_t(1) << 28) - 1)) & ~((size_t(1) << 28) - 1);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = free_.find(cap);
+      if (it != free_.end() && !it->second.empty()) {
+        void *p = it->second.back();
+        it->second.pop_back();
+        live_[p] = cap;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu_);
+    live_[p] = cap;
+    return p;
+  }
+  void release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_[it->second].push_back(p);
+    live_.erase(it);
+  }
+  void release_all() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto &kv : free_)
+      for (void *p : kv.second) (void)hipFree(p);
+    free_.clear();
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<size_t, std::vector<void *>> free_;
+  std::map<void *, size_t> live_;
+};
+
+struct FftTables {
+  fr_t *tw = nullptr;      // omega_n^i, i < n
+  fr_t *coset = nullptr;   // 7^i
+  fr_t *icoset = nullptr;  // 7^-i * n^-1
+  fr_t minv;               // n^-1 (Montgomery)
+};
+
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;  // context stream for synchronous entry points
+  DevicePool pool;
+  std::mutex fft_mu;
+  std::map<uint32_t, FftTables> fft_tables;  // keyed by log_n
+  int num_cus = 256;
+};
+
+}  // namespace bh
+
+struct bh_ctx {
+  bh::Context c;
+};

@@ -1,0 +1,207 @@
+// BLS12-381 G1 / G2 group law for the bucket MSM, written once over a field-ops bundle
+// (FpOps -> G1, Fp2Ops -> G2).
+//
+// Replaces (through `group` traits) what bellman's multiexp calls per base:
+//   src/multiexp.rs:39       bucket += affine base      -> xyzz_madd
+//   src/multiexp.rs:273-274  running_sum += bucket ...  -> xyzz_add
+//   src/multiexp.rs:299      acc.double()               -> xyzz_dbl
+// The reference (bls12_381 0.8.0) uses homogeneous projective coordinates; bellman only ever
+// consumes the result as a GROUP ELEMENT (multiexp.rs:377, prover.rs:356-360), so the
+// representation is free.  XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) has the cheapest mixed
+// addition for short-Weierstrass a = 0 curves: 8M + 2S vs 11M for the complete formulas.
+// Identity: ZZ == 0 (an all-zero record is the identity, so hipMemset(0) clears buckets).
+#pragma once
+#include "ff.cuh"
+
+namespace bh {
+
+template <class F>
+struct alignas(16) Affine {  // identity encoded as (0, 0): not on the curve, unambiguous
+  typename F::T x, y;
+};
+template <class F>
+struct alignas(16) XYZZ {
+  typename F::T x, y, zz, zzz;
+};
+
+template <class F>
+BH_HD bool aff_is_identity(const Affine<F> &p) {
+  return F::is_zero(p.x) && F::is_zero(p.y);
+}
+template <class F>
+BH_HD void xyzz_set_identity(XYZZ<F> &p) {
+  F::zero(p.x);
+  F::zero(p.y);
+  F::zero(p.zz);
+  F::zero(p.zzz);
+}
+template <class F>
+BH_HD bool xyzz_is_identity(const XYZZ<F> &p) {
+  return F::is_zero(p.zz);
+}
+template <class F>
+BH_HD void xyzz_from_affine(XYZZ<F> &r, const Affine<F> &p) {
+  if (aff_is_identity(p)) {
+    xyzz_set_identity(r);
+    return;
+  }
+  r.x = p.x;
+  r.y = p.y;
+  F::one(r.zz);
+  F::one(r.zzz);
+}
+
+// dbl-2008-s-1 (a = 0): 2 [X:Y:ZZ:ZZZ]
+template <class F>
+BH_HD void xyzz_dbl(XYZZ<F> &r, const XYZZ<F> &p) {
+  typedef typename F::T T;
+  if (xyzz_is_identity(p) || F::is_zero(p.y)) {  // (y == 0 cannot occur in a prime-order subgroup)
+    xyzz_set_identity(r);
+    return;
+  }
+  T u, v, w, s, m, t, x3, y3;
+  F::dbl(u, p.y);        // U = 2*Y1
+  F::sqr(v, u);          // V = U^2
+  F::mul(w, u, v);       // W = U*V
+  F::mul(s, p.x, v);     // S = X1*V
+  F::sqr(t, p.x);
+  F::dbl(m, t);
+  F::add(m, m, t);       // M = 3*X1^2
+  F::sqr(x3, m);
+  F::sub(x3, x3, s);
+  F::sub(x3, x3, s);     // X3 = M^2 - 2S
+  F::sub(t, s, x3);
+  F::mul(y3, m, t);
+  F::mul(t, w, p.y);
+  F::sub(y3, y3, t);     // Y3 = M*(S-X3) - W*Y1
+  F::mul(r.zz, v, p.zz);
+  F::mul(r.zzz, w, p.zzz);
+  r.x = x3;
+  r.y = y3;
+}
+
+// affine doubling straight into XYZZ (mdbl-2008-s-1): used when acc == base in xyzz_madd
+template <class F>
+BH_HD void xyzz_dbl_affine(XYZZ<F> &r, const Affine<F> &p) {
+  typedef typename F::T T;
+  T u, s, m, t;
+  F::dbl(u, p.y);          // U = 2*Y1
+  F::sqr(r.zz, u);         // V = ZZ3
+  F::mul(r.zzz, u, r.zz);  // W = ZZZ3
+  F::mul(s, p.x, r.zz);    // S
+  F::sqr(t, p.x);
+  F::dbl(m, t);
+  F::add(m, m, t);         // M = 3 X1^2
+  F::sqr(r.x, m);
+  F::sub(r.x, r.x, s);
+  F::sub(r.x, r.x, s);
+  F::sub(t, s, r.x);
+  F::mul(t, m, t);
+  F::mul(u, r.zzz, p.y);
+  F::sub(r.y, t, u);
+}
+
+// madd-2008-s: acc += affine q  (q must not be the identity; callers check)
+template <class F>
+BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
+  typedef typename F::T T;
+  if (xyzz_is_identity(acc)) {
+    acc.x = q.x;
+    acc.y = q.y;
+    F::one(acc.zz);
+    F::one(acc.zzz);
+    return;
+  }
+  T p, r, pp, ppp, qq, t;
+  F::mul(p, q.x, acc.zz);
+  F::sub(p, p, acc.x);     // P = U2 - X1
+  F::mul(r, q.y, acc.zzz);
+  F::sub(r, r, acc.y);     // R = S2 - Y1
+  if (F::is_zero(p)) {
+    if (F::is_zero(r)) {
+      xyzz_dbl_affine(acc, q);  // same point
+    } else {
+      xyzz_set_identity(acc);   // opposite points
+    }
+    return;
+  }
+  F::sqr(pp, p);
+  F::mul(ppp, p, pp);
+  F::mul(qq, acc.x, pp);   // Q = X1*PP
+  F::sqr(t, r);
+  F::sub(t, t, ppp);
+  F::sub(t, t, qq);
+  F::sub(t, t, qq);        // X3 = R^2 - PPP - 2Q
+  F::sub(qq, qq, t);
+  F::mul(qq, r, qq);       // R*(Q - X3)
+  F::mul(acc.y, acc.y, ppp);
+  F::sub(acc.y, qq, acc.y);
+  acc.x = t;
+  F::mul(acc.zz, acc.zz, pp);
+  F::mul(acc.zzz, acc.zzz, ppp);
+}
+
+// add-2008-s: r = a + b (general)
+template <class F>
+BH_HD void xyzz_add(XYZZ<F> &r, const XYZZ<F> &a, const XYZZ<F> &b) {
+  typedef typename F::T T;
+  if (xyzz_is_identity(a)) {
+    r = b;
+    return;
+  }
+  if (xyzz_is_identity(b)) {
+    r = a;
+    return;
+  }
+  T u1, u2, s1, s2, p, rr, pp, ppp, q, t;
+  F::mul(u1, a.x, b.zz);
+  F::mul(u2, b.x, a.zz);
+  F::mul(s1, a.y, b.zzz);
+  F::mul(s2, b.y, a.zzz);
+  F::sub(p, u2, u1);
+  F::sub(rr, s2, s1);
+  if (F::is_zero(p)) {
+    if (F::is_zero(rr)) {
+      xyzz_dbl(r, a);
+    } else {
+      xyzz_set_identity(r);
+    }
+    return;
+  }
+  F::sqr(pp, p);
+  F::mul(ppp, p, pp);
+  F::mul(q, u1, pp);
+  F::sqr(t, rr);
+  F::sub(t, t, ppp);
+  F::sub(t, t, q);
+  F::sub(t, t, q);         // X3
+  F::sub(q, q, t);
+  F::mul(q, rr, q);
+  F::mul(s1, s1, ppp);
+  F::sub(r.y, q, s1);
+  r.x = t;
+  F::mul(t, a.zz, b.zz);
+  F::mul(r.zz, t, pp);
+  F::mul(t, a.zzz, b.zzz);
+  F::mul(r.zzz, t, ppp);
+}
+
+// XYZZ -> affine (one field inversion): x = X/ZZ, y = Y/ZZZ
+template <class F>
+BH_HD void xyzz_to_affine(Affine<F> &r, const XYZZ<F> &p) {
+  typedef typename F::T T;
+  if (xyzz_is_identity(p)) {
+    F::zero(r.x);
+    F::zero(r.y);
+    return;
+  }
+  T zi, zi2, zi3;                // 1/ZZZ, then 1/ZZ = ZZ^2/ZZZ^2 * ... use: ZZ^3 = ZZZ^2
+  F::inv(zi, p.zzz);             // 1/ZZZ
+  F::mul(r.y, p.y, zi);
+  F::mul(zi2, zi, p.zz);         // ZZ/ZZZ = 1/Z
+  F::sqr(zi3, zi2);              // 1/Z^2 = 1/ZZ
+  F::mul(r.x, p.x, zi3);
+  (void)zi3;
+}
+
+}  // namespace bh

@@ -1,0 +1,333 @@
+// BLS12-381 prime-field arithmetic for gfx950 (and the host, for unit tests and the
+// short serial tails that run on the CPU): Fr (255-bit, 8x32-bit limbs), Fp (381-bit,
+// 12x32-bit limbs), Fp2 = Fp[u]/(u^2+1).  Montgomery form throughout; every value is kept
+// FULLY REDUCED (< modulus) so results are bit-identical to the reference's in-memory
+// representation (bls12_381 0.8.0 `Scalar`/`Fp`: 4x64 / 6x64 little-endian Montgomery limbs,
+// which is the same byte string as 8x32 / 12x32 little-endian limbs).
+//
+// Replaces the trait calls bellman makes into `ff`/`bls12_381`:
+//   src/domain.rs:250-258 (Fr mul/add/sub in the FFT butterflies),
+//   src/multiexp.rs:39,273-274 (point additions -> Fp/Fp2 mul/add/sub).
+//
+// 32-bit limbs because the widest integer multiplier on CDNA4 is v_mad_u64_u32
+// (32x32+64 -> 64); no MFMA: this is modular big-integer arithmetic, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BH_HD __host__ __device__ __forceinline__
+// Out-of-line, by-value (operands and result travel in VGPRs): a 12-limb Montgomery product is
+// ~700 instructions; inlining 10-40 of them per point operation blows the 64 KiB instruction
+// cache and makes hipcc take tens of minutes.
+#define BH_NOINLINE_HD __host__ __device__ __attribute__((noinline))
+
+namespace bh {
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------
+// Field parameter packs.  mod(i)/one(i)/r2(i) are constexpr so that, after full unrolling,
+// every limb is an immediate / SGPR constant.
+// ---------------------------------------------------------------------------------------
+struct FrParams {
+  static constexpr int N = 8;
+  static constexpr u32 INV = 0xffffffffu;  // -q^-1 mod 2^32
+  BH_HD static constexpr u32 mod(int i) {
+    constexpr u32 m[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                          0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    return m[i];
+  }
+  BH_HD static constexpr u32 one(int i) {  // R = 2^256 mod q
+    constexpr u32 m[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                          0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+    return m[i];
+  }
+  BH_HD static constexpr u32 r2(int i) {  // R^2 mod q
+    constexpr u32 m[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                          0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+    return m[i];
+  }
+};
+
+struct FpParams {
+  static constexpr int N = 12;
+  static constexpr u32 INV = 0xfffcfffdu;  // -p^-1 mod 2^32
+  BH_HD static constexpr u32 mod(int i) {
+    constexpr u32 m[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu,
+                           0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u,
+                           0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    return m[i];
+  }
+  BH_HD static constexpr u32 one(int i) {  // R = 2^384 mod p
+    constexpr u32 m[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu,
+                           0x53c758bau, 0x5f489857u, 0x70525745u, 0x77ce5853u,
+                           0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+    return m[i];
+  }
+  BH_HD static constexpr u32 r2(int i) {  // R^2 mod p
+    constexpr u32 m[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u,
+                           0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u,
+                           0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+    return m[i];
+  }
+};
+
+template <class P>
+struct alignas(16) Fe {
+  u32 l[P::N];
+};
+typedef Fe<FrParams> fr_t;
+typedef Fe<FpParams> fp_t;
+
+// ---------------------------------------------------------------------------------------
+// carry helpers (single definition so the lowering can be tuned in one place)
+// ---------------------------------------------------------------------------------------
+BH_HD u32 addc(u32 a, u32 b, u32 cin, u32 &cout) {
+  u64 s = (u64)a + b + cin;
+  cout = (u32)(s >> 32);
+  return (u32)s;
+}
+BH_HD u32 subb(u32 a, u32 b, u32 bin, u32 &bout) {
+  u64 d = (u64)a - b - bin;
+  bout = (u32)(d >> 63);
+  return (u32)d;
+}
+
+template <class P>
+BH_HD void fe_zero(Fe<P> &r) {
+#pragma unroll
+  for (int i = 0; i < P::N; i++) r.l[i] = 0;
+}
+template <class P>
+BH_HD void fe_one(Fe<P> &r) {
+#pragma unroll
+  for (int i = 0; i < P::N; i++) r.l[i] = P::one(i);
+}
+template <class P>
+BH_HD bool fe_is_zero(const Fe<P> &a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) o |= a.l[i];
+  return o == 0;
+}
+template <class P>
+BH_HD bool fe_eq(const Fe<P> &a, const Fe<P> &b) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) o |= a.l[i] ^ b.l[i];
+  return o == 0;
+}
+
+// r = t - mod if t >= mod else t   (t < 2*mod, no overflow word)
+template <class P>
+BH_HD void fe_reduce_once(Fe<P> &r, const u32 *t) {
+  u32 d[P::N];
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) d[i] = subb(t[i], P::mod(i), br, br);
+#pragma unroll
+  for (int i = 0; i < P::N; i++) r.l[i] = br ? t[i] : d[i];
+}
+
+template <class P>
+BH_HD void fe_add(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
+  // a + b < 2*mod < 2^(32N): both moduli leave >= 1 spare top bit, so no carry out.
+  u32 t[P::N];
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) t[i] = addc(a.l[i], b.l[i], c, c);
+  fe_reduce_once<P>(r, t);
+}
+
+template <class P>
+BH_HD void fe_sub(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
+  u32 t[P::N];
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) t[i] = subb(a.l[i], b.l[i], br, br);
+  u32 mask = 0u - br;  // all ones when a < b: add the modulus back
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) r.l[i] = addc(t[i], P::mod(i) & mask, c, c);
+}
+
+template <class P>
+BH_HD void fe_neg(Fe<P> &r, const Fe<P> &a) {
+  bool z = fe_is_zero(a);
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) {
+    u32 d = subb(P::mod(i), a.l[i], br, br);
+    r.l[i] = z ? 0u : d;
+  }
+}
+
+template <class P>
+BH_HD void fe_dbl(Fe<P> &r, const Fe<P> &a) {
+  fe_add(r, a, a);
+}
+
+// Montgomery product, CIOS over 32-bit limbs: r = a*b*R^-1 mod m.
+// Bound: with a,b < m < 2^(32N-1) the running value stays < m*2^33 < 2^(32(N+1)),
+// so N+1 words suffice and the result is < 2m (one conditional subtraction).
+template <class P>
+BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
+  constexpr int N = P::N;
+  u32 t[N + 1];
+#pragma unroll
+  for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u32 bi = b.l[i];
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      c += (u64)a.l[j] * bi + t[j];
+      t[j] = (u32)c;
+      c >>= 32;
+    }
+    u32 tn = t[N] + (u32)c;  // cannot overflow (bound above)
+    const u32 m = t[0] * P::INV;
+    c = ((u64)m * P::mod(0) + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      c += (u64)m * P::mod(j) + t[j];
+      t[j - 1] = (u32)c;
+      c >>= 32;
+    }
+    c += tn;
+    t[N - 1] = (u32)c;
+    t[N] = (u32)(c >> 32);
+  }
+  fe_reduce_once<P>(r, t);
+}
+
+template <class P>
+BH_HD void fe_sqr(Fe<P> &r, const Fe<P> &a) {
+  fe_mul(r, a, a);
+}
+
+// canonical <-> Montgomery
+template <class P>
+BH_HD void fe_to_mont(Fe<P> &r, const Fe<P> &a) {
+  Fe<P> r2;
+#pragma unroll
+  for (int i = 0; i < P::N; i++) r2.l[i] = P::r2(i);
+  fe_mul(r, a, r2);
+}
+template <class P>
+BH_HD void fe_from_mont(Fe<P> &r, const Fe<P> &a) {
+  Fe<P> one;
+  fe_zero(one);
+  one.l[0] = 1;
+  fe_mul(r, a, one);
+}
+
+// a^e for a little-endian 32-bit-limb exponent (host tails / setup; not a hot path)
+template <class P>
+BH_HD void fe_pow(Fe<P> &r, const Fe<P> &a, const u32 *e, int nlimbs) {
+  Fe<P> acc;
+  fe_one(acc);
+  for (int i = nlimbs * 32 - 1; i >= 0; i--) {
+    fe_sqr(acc, acc);
+    if ((e[i / 32] >> (i % 32)) & 1) fe_mul(acc, acc, a);
+  }
+  r = acc;
+}
+template <class P>
+BH_HD void fe_inv(Fe<P> &r, const Fe<P> &a) {  // a^(m-2); a != 0
+  u32 e[P::N];
+#pragma unroll
+  for (int i = 0; i < P::N; i++) e[i] = P::mod(i);
+  e[0] -= 2;  // both moduli have low limb >= 2
+  fe_pow(r, a, e, P::N);
+}
+
+// out-of-line Fp product used by all curve code (the FFT keeps its 8-limb Fr product inline)
+BH_NOINLINE_HD static fp_t fp_mul_call(fp_t a, fp_t b) {
+  fp_t r;
+  fe_mul(r, a, b);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fp2
+// ---------------------------------------------------------------------------------------
+struct alignas(16) fp2_t {
+  fp_t c0, c1;
+};
+
+// "Field ops" bundles so curve code is written once for G1 (Fp) and G2 (Fp2).
+struct FpOps {
+  typedef fp_t T;
+  static constexpr int WORDS = 12;
+  BH_HD static void zero(T &r) { fe_zero(r); }
+  BH_HD static void one(T &r) { fe_one(r); }
+  BH_HD static bool is_zero(const T &a) { return fe_is_zero(a); }
+  BH_HD static bool eq(const T &a, const T &b) { return fe_eq(a, b); }
+  BH_HD static void add(T &r, const T &a, const T &b) { fe_add(r, a, b); }
+  BH_HD static void sub(T &r, const T &a, const T &b) { fe_sub(r, a, b); }
+  BH_HD static void neg(T &r, const T &a) { fe_neg(r, a); }
+  BH_HD static void dbl(T &r, const T &a) { fe_add(r, a, a); }
+  BH_HD static void mul(T &r, const T &a, const T &b) { r = fp_mul_call(a, b); }
+  BH_HD static void sqr(T &r, const T &a) { r = fp_mul_call(a, a); }
+  BH_HD static void inv(T &r, const T &a) {  // a^(p-2)
+    u32 e[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) e[i] = FpParams::mod(i);
+    e[0] -= 2;
+    T acc;
+    fe_one(acc);
+    for (int i = 383; i >= 0; i--) {
+      acc = fp_mul_call(acc, acc);
+      if ((e[i / 32] >> (i % 32)) & 1) acc = fp_mul_call(acc, a);
+    }
+    r = acc;
+  }
+};
+
+struct Fp2Ops {
+  typedef fp2_t T;
+  static constexpr int WORDS = 24;
+  BH_HD static void zero(T &r) { fe_zero(r.c0); fe_zero(r.c1); }
+  BH_HD static void one(T &r) { fe_one(r.c0); fe_zero(r.c1); }
+  BH_HD static bool is_zero(const T &a) { return fe_is_zero(a.c0) && fe_is_zero(a.c1); }
+  BH_HD static bool eq(const T &a, const T &b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
+  BH_HD static void add(T &r, const T &a, const T &b) { fe_add(r.c0, a.c0, b.c0); fe_add(r.c1, a.c1, b.c1); }
+  BH_HD static void sub(T &r, const T &a, const T &b) { fe_sub(r.c0, a.c0, b.c0); fe_sub(r.c1, a.c1, b.c1); }
+  BH_HD static void neg(T &r, const T &a) { fe_neg(r.c0, a.c0); fe_neg(r.c1, a.c1); }
+  BH_HD static void dbl(T &r, const T &a) { add(r, a, a); }
+  BH_HD static void mul(T &r, const T &a, const T &b) {
+    // Karatsuba: 3 Fp products
+    fp_t t0, t1, t2, t3;
+    t0 = fp_mul_call(a.c0, b.c0);
+    t1 = fp_mul_call(a.c1, b.c1);
+    fe_add(t2, a.c0, a.c1);
+    fe_add(t3, b.c0, b.c1);
+    t2 = fp_mul_call(t2, t3);
+    fe_sub(t2, t2, t0);
+    fe_sub(r.c1, t2, t1);
+    fe_sub(r.c0, t0, t1);
+  }
+  BH_HD static void sqr(T &r, const T &a) {
+    // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp products
+    fp_t s, d, p;
+    fe_add(s, a.c0, a.c1);
+    fe_sub(d, a.c0, a.c1);
+    p = fp_mul_call(a.c0, a.c1);
+    r.c0 = fp_mul_call(s, d);
+    fe_add(r.c1, p, p);
+  }
+  BH_HD static void inv(T &r, const T &a) {
+    fp_t n, t;
+    n = fp_mul_call(a.c0, a.c0);
+    t = fp_mul_call(a.c1, a.c1);
+    fe_add(n, n, t);
+    FpOps::inv(n, n);
+    r.c0 = fp_mul_call(a.c0, n);
+    t = fp_mul_call(a.c1, n);
+    fe_neg(r.c1, t);
+  }
+};
+
+}  // namespace bh

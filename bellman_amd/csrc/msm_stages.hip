@@ -1,0 +1,358 @@
+// Pippenger bucket multi-scalar multiplication over BLS12-381 G1 / G2 for gfx950.
+//
+// Replaces bellman's `multiexp` / `multiexp_inner` (src/multiexp.rs:210-332).  What is kept
+// is the CONTRACT (Appendix A items 1-9 of SURVEY.md): the sum over dense entries of
+// s_i * B[skip + rank_i], the Source/QueryDensity error semantics, asynchronous issue with a
+// waiter.  What is not kept is the CPU schedule (one rayon task per window, serial bucket
+// fill): the result is a group element, so the order of additions is unobservable.
+//
+// Device pipeline (all on the job's stream, no host round trip until the very end):
+//   1. digits      one thread per scalar: density rank -> base index, c-bit digits for all
+//                  W = ceil(255/c) windows, written as (digit,base) pairs, window-major.
+//   2. sort        stable LSD radix sort of every window's pairs by digit, 8 bits per pass;
+//                  ranking inside a tile uses wavefront ballots (match-any) + popcounts.
+//   3. bounds      bucket start offsets from the sorted digits; task list (buckets larger than
+//                  CHUNK entries are split so a skewed scalar distribution cannot serialise).
+//   4. accumulate  one lane per task: gather affine bases (L2 / Infinity-Cache resident: the
+//                  96 MiB base table fits the 256 MiB MALL) and XYZZ mixed-add them.
+//   5. reduce      sum_d d*B_d without a serial running sum: split d = hi*2^l + lo, take row
+//                  sums over lo and column sums over hi (wave tree-reductions), then per-bit
+//                  sums of those 2^l-entry vectors -> W*c partial points U_p with
+//                  result = sum_p 2^p U_p.
+//   6. tail        the 255-step double-and-add over U_p is inherently serial -> host.
+#include <algorithm>
+#include <cmath>
+
+#include "msm_scalar.cuh"
+#include "msm_types.hpp"
+
+namespace bh {
+
+// ============================================================================================
+// exclusive scan (u32), in place
+// ============================================================================================
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(u32 *data, u32 *block_sums, u64 n) {
+  __shared__ u32 wsum[SCAN_THREADS / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)tid * SCAN_PER;
+  u32 v[SCAN_PER];
+  u32 run = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    u32 t = (base + k < n) ? data[base + k] : 0;
+    v[k] = run;
+    run += t;
+  }
+  u32 x = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    u32 y = __shfl_up(x, off);
+    if (lane >= (u32)off) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  u32 woff = 0;
+  for (u32 w = 0; w < wave; w++) woff += wsum[w];
+  const u32 toff = woff + x - run;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++)
+    if (base + k < n) data[base + k] = v[k] + toff;
+  if (tid == SCAN_THREADS - 1) block_sums[blockIdx.x] = toff + run;
+}
+__global__ void scan_add_kernel(u32 *data, const u32 *block_off, u64 n) {
+  const u64 i = (u64)blockIdx.x * SCAN_TILE + threadIdx.x;
+  const u32 off = block_off[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    u64 j = i + (u64)k * SCAN_THREADS;
+    if (j < n) data[j] += off;
+  }
+}
+size_t scan_tmp_elems(u64 n) {
+  size_t tot = 0;
+  while (n > 1) {
+    n = (n + SCAN_TILE - 1) / SCAN_TILE;
+    tot += (n + 63) & ~(size_t)63;
+    if (n == 1) break;
+  }
+  return tot + 64;
+}
+static int exclusive_scan_u32(u32 *data, u64 n, u32 *tmp, hipStream_t st) {
+  if (n == 0) return BH_OK;
+  u64 blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_tile_kernel, dim3((u32)blocks), dim3(SCAN_THREADS), 0, st, data, tmp, n);
+  BH_HIP_CHECK(hipGetLastError());
+  if (blocks > 1) {
+    int rc = exclusive_scan_u32(tmp, blocks, tmp + ((blocks + 63) & ~(u64)63), st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_add_kernel, dim3((u32)blocks), dim3(SCAN_THREADS), 0, st, data, tmp, n);
+    BH_HIP_CHECK(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+// ============================================================================================
+// 1. digits
+// ============================================================================================
+__global__ void density_popc_kernel(const u64 *words, u32 *out, u64 nwords) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) out[i] = (u32)__popcll(words[i]);
+}
+
+__global__ void msm_digits_kernel(const void *scalars, int fmt, u32 n, const u64 *density,
+                                  const u32 *word_prefix, u64 skip, u64 n_bases, u32 c, u32 W,
+                                  u64 *pairs, ErrFlags *err) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool dense = true;
+  u64 k = skip + i;
+  if (density) {
+    const u64 word = density[i >> 6];
+    dense = (word >> (i & 63)) & 1;
+    k = skip + word_prefix[i >> 6] + __popcll(word & (((u64)1 << (i & 63)) - 1));
+  }
+  bool live = dense;
+  if (dense && k >= n_bases) {   // every dense entry checks EOF first, whatever its scalar
+    atomicOr(&err->eof, 1u);
+    live = false;
+  }
+  fr_t s;
+  if (live) load_scalar(scalars, i, fmt, s);
+  for (u32 w = 0; w < W; w++) {
+    u32 d = live ? extract_bits(s, w * c, c) : 0;
+    pairs[(u64)w * n + i] = ((u64)d << 32) | (u32)k;
+  }
+}
+
+// ============================================================================================
+// 2. radix sort (per window region of n pairs, keyed on 8 bits of the digit per pass)
+// ============================================================================================
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ROUNDS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u64 *pairs, u32 *counts, u32 n,
+                                                                u32 shift, u32 num_tiles) {
+  __shared__ u32 hist[256];
+  const u32 tid = threadIdx.x, tile = blockIdx.x, w = blockIdx.y;
+  hist[tid] = 0;
+  __syncthreads();
+  const u64 *src = pairs + (u64)w * n;
+#pragma unroll 4
+  for (int r = 0; r < SORT_ROUNDS; r++) {
+    u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
+    if (idx < n) atomicAdd(&hist[(u32)(src[idx] >> shift) & 0xff], 1u);
+  }
+  __syncthreads();
+  counts[((u64)w * 256 + tid) * num_tiles + tile] = hist[tid];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *pairs_in, u64 *pairs_out,
+                                                                   const u32 *offsets, u32 n, u32 shift,
+                                                                   u32 num_tiles) {
+  __shared__ u32 base[256];
+  __shared__ u32 wcnt[SORT_THREADS / 64][256];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x, w = blockIdx.y;
+  base[tid] = offsets[((u64)w * 256 + tid) * num_tiles + tile];   // global position (all windows)
+#pragma unroll
+  for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][tid] = 0;
+  __syncthreads();
+  const u64 *src = pairs_in + (u64)w * n;
+  const u64 lt_mask = ((u64)1 << lane) - 1;
+  for (int r = 0; r < SORT_ROUNDS; r++) {
+    const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
+    const bool valid = idx < n;
+    u64 key = valid ? src[idx] : 0;
+    const u32 bin = (u32)(key >> shift) & 0xff;
+    // wavefront match-any over the 8-bit bin: lanes with equal bins
+    u64 mask = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const u64 bal = __ballot((bin >> b) & 1);
+      mask &= ((bin >> b) & 1) ? bal : ~bal;
+    }
+    const u32 rank = (u32)__popcll(mask & lt_mask);
+    if (valid && rank == 0) wcnt[wave][bin] = (u32)__popcll(mask);
+    __syncthreads();
+    if (valid) {
+      u32 off = base[bin] + rank;
+      for (u32 v = 0; v < wave; v++) off += wcnt[v][bin];
+      pairs_out[off] = key;
+    }
+    __syncthreads();
+    u32 tot = 0;
+#pragma unroll
+    for (int v = 0; v < SORT_THREADS / 64; v++) { tot += wcnt[v][tid]; wcnt[v][tid] = 0; }
+    base[tid] += tot;
+    __syncthreads();
+  }
+}
+
+// ============================================================================================
+// 3. bucket bounds + tasks
+// ============================================================================================
+// start[w*(nb+1) + d] = first sorted position (within window w) whose digit is >= d; d in [0, nb]
+__global__ void bucket_bounds_kernel(const u64 *pairs, u32 *start, u32 n, u32 nb) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 w = blockIdx.y;
+  if (i > n) return;
+  const u64 *src = pairs + (u64)w * n;
+  const int dprev = (i == 0) ? -1 : (int)(u32)(src[i - 1] >> 32);
+  const int dcur = (i == n) ? (int)nb : (int)(u32)(src[i] >> 32);
+  u32 *st = start + (u64)w * (nb + 1);
+  for (int d = dprev + 1; d <= dcur; d++) st[d] = i;
+}
+
+__global__ void count_tasks_kernel(const u32 *start, u32 *ntasks, u32 nb, u32 W, u32 chunk) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;   // global bucket index w*nb + d
+  const u32 NB = W * nb;
+  if (b > NB) return;
+  if (b == NB) { ntasks[b] = 0; return; }
+  const u32 w = b / nb, d = b % nb;
+  const u32 *st = start + (u64)w * (nb + 1);
+  const u32 cnt = (d == 0) ? 0 : st[d + 1] - st[d];
+  ntasks[b] = (cnt + chunk - 1) / chunk;
+}
+
+__global__ void make_tasks_kernel(const u32 *start, const u32 *task_off, Task *tasks, BigBucket *big,
+                                  ErrFlags *err, u32 n, u32 nb, u32 W, u32 chunk, u32 max_big) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 NB = W * nb;
+  if (b == NB) err->total_tasks = task_off[NB];
+  if (b >= NB) return;
+  const u32 w = b / nb, d = b % nb;
+  if (d == 0) return;
+  const u32 *st = start + (u64)w * (nb + 1);
+  const u32 lo = st[d], hi = st[d + 1];
+  if (hi == lo) return;
+  const u32 t0 = task_off[b], nt = task_off[b + 1] - t0;
+  for (u32 j = 0; j < nt; j++) {
+    Task t;
+    t.begin = w * n + lo + j * chunk;
+    t.end = min(t.begin + chunk, w * n + hi);
+    t.dest = (nt == 1) ? b : NB + t0 + j;
+    tasks[t0 + j] = t;
+  }
+  if (nt > 1) {
+    const u32 slot = atomicAdd(&err->nbig, 1u);
+    if (slot < max_big) { BigBucket bb = {b, t0, nt}; big[slot] = bb; }
+  }
+}
+
+static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
+
+MsmPlan make_plan(u64 n, unsigned forced_c) {
+  MsmPlan p;
+  p.n = (u32)n;
+  int c = (int)ilog2(n ? n : 1) - 6;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
+  p.c = (u32)c;
+  p.W = (255 + p.c - 1) / p.c;          // (0..NUM_BITS).step_by(c), multiexp.rs:288-290
+  p.nb = 1u << p.c;
+  p.NB = p.W * p.nb;
+  p.lo_bits = p.c / 2;
+  p.hi_bits = p.c - p.lo_bits;
+  p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
+  u64 avg = n >> p.c;
+  p.chunk = (u32)std::max<u64>(256, 4 * avg);
+  p.max_tasks = (u64)p.NB + ((u64)p.W * n) / p.chunk + 1;
+  p.max_big = (u32)std::min<u64>(((u64)p.W * n) / p.chunk + 1, 1u << 20);
+  p.sort_passes = (p.c + 7) / 8;
+  return p;
+}
+
+
+int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
+                   u64 skip, u64 n_bases, hipStream_t st, const u64 **sorted_out) {
+  const u64 n = p.n;
+  const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
+  const u64 nwords = (n + 63) / 64;
+  if (density_dev) {
+    hipLaunchKernelGGL(density_popc_kernel, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, st, density_dev,
+                       b.word_prefix, nwords);
+    BH_HIP_CHECK(hipGetLastError());
+    int rc = exclusive_scan_u32(b.word_prefix, nwords, b.scan_tmp, st);
+    if (rc) return rc;
+  }
+  // 1. digits
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.n,
+                     density_dev, b.word_prefix, skip, n_bases, p.c, p.W, b.pairs_a, b.err);
+  BH_HIP_CHECK(hipGetLastError());
+  // 2. sort by digit, 8 bits per pass
+  u64 *src = b.pairs_a, *dst = b.pairs_b;
+  for (u32 pass = 0; pass < p.sort_passes; pass++) {
+    const u32 shift = 32 + 8 * pass;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, b.counts, p.n,
+                       shift, p.num_tiles);
+    BH_HIP_CHECK(hipGetLastError());
+    int rc = exclusive_scan_u32(b.counts, ncounts, b.scan_tmp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
+                       p.n, shift, p.num_tiles);
+    BH_HIP_CHECK(hipGetLastError());
+    std::swap(src, dst);
+  }
+  *sorted_out = src;
+  // 3. bounds + tasks
+  hipLaunchKernelGGL(bucket_bounds_kernel, dim3((p.n + 1 + 255) / 256, p.W), dim3(256), 0, st, src, b.start, p.n,
+                     p.nb);
+  BH_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(count_tasks_kernel, dim3((p.NB + 1 + 255) / 256), dim3(256), 0, st, b.start, b.task_off, p.nb,
+                     p.W, p.chunk);
+  BH_HIP_CHECK(hipGetLastError());
+  {
+    int rc = exclusive_scan_u32(b.task_off, (u64)p.NB + 1, b.scan_tmp, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(make_tasks_kernel, dim3((p.NB + 1 + 255) / 256), dim3(256), 0, st, b.start, b.task_off, b.tasks,
+                     b.big, b.err, p.n, p.nb, p.W, p.chunk, p.max_big);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
+
+
+// bring-up aid: stages 1-3 only, results copied to the host (tests/test_gpu_parity.py)
+int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
+                    u32 *start_out, u32 *total_tasks_out) {
+  const MsmPlan p = make_plan(n, cbits);
+  hipStream_t st = c.stream;
+  const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
+  MsmBuffers b;
+  void *sc = nullptr;
+  std::vector<void *> owned;
+  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); if (q) owned.push_back(q); return q; };
+  sc = alloc(n * 32);
+  b.pairs_a = (u64 *)alloc(npairs * 8);
+  b.pairs_b = (u64 *)alloc(npairs * 8);
+  b.counts = (u32 *)alloc(ncounts * 4);
+  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(std::max<u64>(ncounts, p.NB + 1)) * 4);
+  b.start = (u32 *)alloc((u64)p.W * (p.nb + 1) * 4);
+  b.task_off = (u32 *)alloc(((u64)p.NB + 1) * 4);
+  b.tasks = (Task *)alloc(p.max_tasks * sizeof(Task));
+  b.big = (BigBucket *)alloc((u64)p.max_big * sizeof(BigBucket));
+  b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
+  b.word_prefix = nullptr;
+  int rc = BH_OK;
+  for (void *q : owned) if (!q) rc = BH_ERR_HIP;
+  if (owned.size() != 10) rc = BH_ERR_HIP;
+  const u64 *sorted = nullptr;
+  ErrFlags ef;
+  if (rc == BH_OK && hipMemcpyAsync(sc, scalars_host, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemsetAsync(b.err, 0, sizeof(ErrFlags), st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK) rc = msm_run_stages(p, b, sc, fmt, nullptr, 0, n, st, &sorted);
+  if (rc == BH_OK && hipMemcpyAsync(pairs_out, sorted, npairs * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemcpyAsync(start_out, b.start, (u64)p.W * (p.nb + 1) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemcpyAsync(&ef, b.err, sizeof ef, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  if (rc == BH_OK && total_tasks_out) *total_tasks_out = ef.total_tasks;
+  for (void *q : owned) c.pool.release(q);
+  return rc;
+}
+
+}  // namespace bh

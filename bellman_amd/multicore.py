@@ -1,0 +1,74 @@
+"""`Worker` / `Waiter` mirror (reference: src/multicore.rs:21-118).
+
+On the MI355X a Worker is a device context (one per GPU per process): `compute` becomes
+"enqueue on a HIP stream", the Waiter's `wait()` blocks on that stream.
+"""
+
+import ctypes
+
+from . import _lib
+from .errors import check
+
+
+class Worker:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        ctx = ctypes.c_void_p()
+        check(self._lib.bh_ctx_create(device, ctypes.byref(ctx)), "Worker::new")
+        self._ctx = ctx
+        self.device = device
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def log_num_threads(self):
+        """multicore.rs:29-31 analogue: floor(log2(#CUs))."""
+        return self._lib.bh_ctx_log_num_cus(self._ctx)
+
+    def synchronize(self):
+        check(self._lib.bh_ctx_synchronize(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self._lib.bh_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- raw device buffers (inputs resident in HBM) ----
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(self._lib.bh_dev_alloc(self._ctx, nbytes, ctypes.byref(p)))
+        return p
+
+    def free(self, p):
+        check(self._lib.bh_dev_free(self._ctx, p))
+
+    def upload(self, dev, arr):
+        check(self._lib.bh_dev_upload(self._ctx, dev, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def download(self, arr, dev):
+        check(self._lib.bh_dev_download(self._ctx, arr.ctypes.data_as(ctypes.c_void_p), dev, arr.nbytes))
+
+
+class Waiter:
+    """multicore.rs:94-118.  `wait()` consumes the waiter."""
+
+    def __init__(self, fn=None, value=None):
+        self._fn = fn
+        self._value = value
+
+    def wait(self):
+        if self._fn is not None:
+            fn, self._fn = self._fn, None
+            self._value = fn()
+        return self._value
+
+    @staticmethod
+    def done(val):
+        return Waiter(value=val)

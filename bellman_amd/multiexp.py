@@ -1,0 +1,133 @@
+"""`multiexp` mirror (reference: src/multiexp.rs:305-332) over bh_msm_async / bh_msm_wait.
+
+Points are numpy uint64 records in the library's format (96 B G1 / 192 B G2 affine, Montgomery,
+all-zero = identity); scalars are [n,4] uint64 little-endian, canonical unless `mont=True`.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .errors import check
+from .multicore import Waiter
+
+G1, G2 = 1, 2
+_WORDS = {G1: 12, G2: 24}
+
+
+class FullDensity:
+    """src/multiexp.rs:95-115"""
+
+    def get_query_size(self):
+        return None
+
+
+class DensityTracker:
+    """src/multiexp.rs:117-157 (bit i set <=> scalar i has a base in the compacted vector)."""
+
+    def __init__(self, bits=None):
+        self.bv = [] if bits is None else [bool(b) for b in bits]
+
+    def add_element(self):
+        self.bv.append(False)
+
+    def inc(self, idx):
+        self.bv[idx] = True
+
+    def get_total_density(self):
+        return sum(self.bv)
+
+    def get_query_size(self):
+        return len(self.bv)
+
+    def words(self):
+        n = len(self.bv)
+        nwords = (n + 63) // 64
+        padded = np.zeros(nwords * 64, dtype=np.uint8)
+        padded[:n] = np.asarray(self.bv, dtype=np.uint8)
+        return np.packbits(padded, bitorder="little").view(np.uint64).copy()
+
+
+class Bases:
+    """Device-resident `Arc<Vec<G::Affine>>` (src/multiexp.rs:45-52, groth16/src/lib.rs:443-473).
+    `with_skip(k)` is the `(bases, k)` SourceBuilder."""
+
+    def __init__(self, worker, group, points, stride=None, inf_offset=-1):
+        self.worker = worker
+        self.group = group
+        lib = _lib.load()
+        pts = np.ascontiguousarray(points)
+        rec = _WORDS[group] * 8
+        if stride is None:
+            pts = pts.view(np.uint64).reshape(-1, _WORDS[group])
+            n, stride = pts.shape[0], rec
+        else:
+            n = pts.nbytes // stride
+        h = ctypes.c_void_p()
+        check(
+            lib.bh_bases_register(worker.ctx, group, pts.ctypes.data_as(ctypes.c_void_p), n, stride, inf_offset,
+                                  ctypes.byref(h)),
+            "bases_register",
+        )
+        self._h = h
+        self.n = n
+
+    @classmethod
+    def wrap_device(cls, worker, group, dev_ptr, n):
+        self = cls.__new__(cls)
+        self.worker, self.group, self.n = worker, group, n
+        h = ctypes.c_void_p()
+        check(_lib.load().bh_bases_wrap_dev(worker.ctx, group, dev_ptr, n, ctypes.byref(h)))
+        self._h = h
+        return self
+
+    def __len__(self):
+        return self.n
+
+    def release(self):
+        if self._h:
+            _lib.load().bh_bases_release(self.worker.ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,
+             density_dev=None):
+    """multiexp(pool, (bases, skip), density_map, exponents) -> Waiter (src/multiexp.rs:305-332).
+
+    exponents: [n,4] uint64 scalars on the host; or pass scalars_dev (device pointer) + n.
+    The Waiter's wait() returns the affine result record (numpy uint64[12|24]) or raises the
+    SynthesisError the reference would return.  With timed=True it returns (record, device_ms)."""
+    lib = _lib.load()
+    words = None
+    dlen = 0
+    if isinstance(density_map, DensityTracker):
+        dlen = density_map.get_query_size()
+        words = density_map.words()
+    job = ctypes.c_void_p()
+    fmt = 1 if mont else 0
+    if scalars_dev is None:
+        sc = np.ascontiguousarray(exponents, dtype=np.uint64).reshape(-1, 4)
+        n = sc.shape[0]
+        rc = lib.bh_msm_async(pool.ctx, bases._h, skip, sc.ctypes.data_as(ctypes.c_void_p), n, fmt,
+                              None if words is None else words.ctypes.data_as(ctypes.c_void_p), dlen,
+                              ctypes.byref(job))
+    else:
+        rc = lib.bh_msm_async_dev(pool.ctx, bases._h, skip, scalars_dev, n, fmt, density_dev,
+                                  dlen if density_dev is not None else 0, ctypes.byref(job))
+    check(rc, "multiexp")
+    w = _WORDS[bases.group]
+
+    def finish():
+        out = np.zeros(w, dtype=np.uint64)
+        ms = ctypes.c_float(0)
+        check(lib.bh_msm_wait_timed(job, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), "multiexp.wait")
+        return (out, ms.value) if timed else out
+
+    return Waiter(fn=finish)

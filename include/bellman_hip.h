@@ -1,0 +1,152 @@
+/* libbellman_hip - C ABI of the MI355X (gfx950) implementation of bellman's Groth16
+ * proving hot path.  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * The reference (zkcrypto/bellman @ 2024-08-07) has no FFI of its own: the boundary it
+ * exposes is a set of generic Rust signatures.  Each entry point below names the reference
+ * interface it replaces (file:line under /root/reference); INTEGRATION.md shows the Rust
+ * `extern "C"` block + shim a maintainer would add behind those signatures.
+ *
+ * DATA FORMATS (identical to `bls12_381 0.8.0` in-memory values on a little-endian host)
+ *   Fr element   32 B  4 x u64 little-endian limbs.  FFT/polynomial data is in MONTGOMERY
+ *                      form (R = 2^256), exactly the bytes of a Rust `bls12_381::Scalar`.
+ *   MSM scalar   32 B  either canonical little-endian (BH_SCALARS_CANONICAL - the bits of
+ *                      `Exponent::Bits`, src/multiexp.rs:179) or Montgomery (BH_SCALARS_MONT -
+ *                      a Rust `Scalar` as is; converted on the device).
+ *   G1 affine    96 B  x | y, each 6 x u64 LE limbs, Montgomery form (R = 2^384).
+ *   G2 affine   192 B  x.c0 | x.c1 | y.c0 | y.c1 (Fp2 = c0 + c1*u).
+ *                      The point at infinity is the ALL-ZERO record ((0,0) is not on either
+ *                      curve).  bh_bases_register_* can translate `infinity` flag bytes.
+ *
+ * ERROR CODES map 1:1 onto bellman::SynthesisError (src/lib.rs:303-319):
+ */
+#ifndef BELLMAN_HIP_H
+#define BELLMAN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_OK 0
+#define BH_ERR_UNEXPECTED_IDENTITY 1 /* SynthesisError::UnexpectedIdentity   src/multiexp.rs:63-65   */
+#define BH_ERR_UNEXPECTED_EOF 2      /* SynthesisError::IoError(UnexpectedEof) src/multiexp.rs:55-61,74-80 */
+#define BH_ERR_DEGREE_TOO_LARGE 3    /* SynthesisError::PolynomialDegreeTooLarge src/domain.rs:57-59 */
+#define BH_ERR_HIP (-1)              /* HIP runtime failure (message on stderr) */
+#define BH_ERR_INVALID_ARG (-2)      /* the reference would panic (e.g. density length mismatch,
+                                        src/multiexp.rs:324-329; length mismatch src/domain.rs:155,174) */
+#define BH_ERR_NO_DEVICE (-3)        /* no gfx950 device / kernels unavailable: there is NO CPU fallback */
+
+#define BH_SCALARS_CANONICAL 0
+#define BH_SCALARS_MONT 1
+
+#define BH_G1 1
+#define BH_G2 2
+
+typedef struct bh_ctx bh_ctx;         /* one per (process, GPU); thread-safe */
+typedef struct bh_bases bh_bases;     /* device-resident, immutable base vector (the CRS queries) */
+typedef struct bh_msm_job bh_msm_job; /* an MSM in flight == bellman's Waiter<Result<G,_>> */
+
+/* ---- context: replaces multicore::Worker::new() (src/multicore.rs:24-27) ------------- */
+int bh_ctx_create(int device, bh_ctx **out);
+void bh_ctx_destroy(bh_ctx *ctx);
+/* Worker::log_num_threads analogue (src/multicore.rs:29-31): log2 of the CU count. */
+uint32_t bh_ctx_log_num_cus(const bh_ctx *ctx);
+const char *bh_version(void);
+
+/* ---- raw device memory helpers (so callers can keep vectors resident in HBM) -------- */
+int bh_dev_alloc(bh_ctx *ctx, size_t bytes, void **dev_ptr);
+int bh_dev_free(bh_ctx *ctx, void *dev_ptr);
+int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int bh_ctx_synchronize(bh_ctx *ctx);
+
+/* ---- EvaluationDomain (src/domain.rs) ------------------------------------------------
+ * mode: 0 fft (:81-83)  1 ifft (:85-99)  2 coset_fft (:115-118)  3 icoset_fft (:120-125).
+ * `data` holds 2^log_n Montgomery Fr (the padded `coeffs` of from_coeffs, :47-79), natural
+ * order in and out, transformed in place.  log_n >= 32 -> BH_ERR_DEGREE_TOO_LARGE (:57-59). */
+#define BH_FFT 0
+#define BH_IFFT 1
+#define BH_COSET_FFT 2
+#define BH_ICOSET_FFT 3
+int bh_fft_fr(bh_ctx *ctx, void *data_host, uint32_t log_n, int mode);
+/* same on a device pointer, asynchronous on `stream` (a hipStream_t; NULL = context stream) */
+int bh_fft_fr_dev(bh_ctx *ctx, void *data_dev, uint32_t log_n, int mode, void *stream);
+/* pointwise domain ops on device vectors of n Montgomery Fr:
+ *   mul_assign (:154-170)  sub_assign (:173-189)  divide_by_z_on_coset (:139-151, n = 2^log_n)
+ *   distribute_powers(g) (:101-113; g = 32-byte Montgomery Fr on the HOST) */
+int bh_fr_mul_assign_dev(bh_ctx *ctx, void *a_dev, const void *b_dev, size_t n, void *stream);
+int bh_fr_sub_assign_dev(bh_ctx *ctx, void *a_dev, const void *b_dev, size_t n, void *stream);
+int bh_fr_divide_by_z_on_coset_dev(bh_ctx *ctx, void *a_dev, uint32_t log_n, void *stream);
+int bh_fr_distribute_powers_dev(bh_ctx *ctx, void *a_dev, size_t n, const void *g_host, void *stream);
+/* The whole h-polynomial block of create_proof (groth16/src/prover.rs:221-240), fused:
+ * a,b,c = n_evals constraint evaluations each (Montgomery Fr, HOST); writes the m-1 quotient
+ * coefficients (m = next pow2 >= n_evals, :238-239) to h_out_host (Montgomery) and returns
+ * m-1 in *h_len.  Runs ifft/coset_fft x3, (a*b-c)/Z in one pass, icoset_fft. */
+int bh_h_poly_fr(bh_ctx *ctx, const void *a_host, const void *b_host, const void *c_host,
+                 size_t n_evals, void *h_out_host, size_t *h_len);
+/* device-resident variant: a,b,c are 2^log_n-element device vectors (clobbered); result in a */
+int bh_h_poly_fr_dev(bh_ctx *ctx, void *a_dev, void *b_dev, void *c_dev, uint32_t log_n, void *stream);
+
+/* ---- bases: the `(Arc<Vec<G::Affine>>, usize)` SourceBuilder (src/multiexp.rs:45-86) --
+ * Uploads `n` affine points once (the CRS is immutable and shared by every proof,
+ * groth16/src/lib.rs:443-473).  `stride` bytes between records; coordinates (Montgomery) at
+ * byte offset 0; if inf_offset >= 0 the byte at that offset != 0 marks the identity
+ * (the `infinity: Choice` of bls12_381's G1Affine/G2Affine), else identity == all-zero. */
+int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n, size_t stride,
+                      long inf_offset, bh_bases **out);
+/* wrap an existing device array of packed 96/192-byte records (not owned) */
+int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
+void bh_bases_release(bh_ctx *ctx, bh_bases *b);
+size_t bh_bases_len(const bh_bases *b);
+
+/* ---- multiexp (src/multiexp.rs:305-332) ---------------------------------------------
+ * Computes  sum_i [density_i] s_i * B[skip + rank_i]   (rank_i = #dense entries before i),
+ * i.e. multiexp(pool, (bases, skip), density_map, exponents):
+ *   scalars        n_scalars x 32 B (HOST unless *_dev), format per scalar_fmt
+ *   density_words  NULL = FullDensity (:95-115); else LSB0 bitmap, ceil(n/64) u64 words
+ *                  (DensityTracker's BitVec<usize,Lsb0>, :117-131); density_len must equal
+ *                  n_scalars or BH_ERR_INVALID_ARG is returned (the reference panics, :324-329)
+ * Returns immediately with a job (the Waiter); bh_msm_wait blocks (Waiter::wait,
+ * src/multicore.rs:100-109), writes the AFFINE result record (96/192 B, Montgomery; all-zero =
+ * identity) and returns BH_OK / BH_ERR_UNEXPECTED_IDENTITY / BH_ERR_UNEXPECTED_EOF with the
+ * reference's precedence (highest failing window wins, :295-300).  Many jobs may be in
+ * flight per context (create_proof issues 8, groth16/src/prover.rs:244-318). */
+int bh_msm_async(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
+                 size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
+                 size_t density_len, bh_msm_job **job);
+int bh_msm_async_dev(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev,
+                     size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
+                     size_t density_len, bh_msm_job **job);
+int bh_msm_wait(bh_msm_job *job, void *out_affine);
+/* device time of the job's kernels in milliseconds (hipEvents on the job's stream); valid
+ * after bh_msm_wait's return value has been observed via bh_msm_wait_timed */
+int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms);
+/* tuning knob for experiments: window bits c (0 = automatic) */
+int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c);
+
+/* ---- fixed-base scalar multiplication (fixture / CRS generation; SURVEY §8 f4,
+ * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device */
+int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host,
+                          const void *scalars_dev, size_t n, int scalar_fmt, void *out_dev,
+                          void *stream);
+
+/* ---- self-test hooks used by tests/ (element-wise field / group ops on the device) ---- */
+int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+/* r[i] = a[i] + b[i] on the curve (affine in, affine out) */
+int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+/* runs MSM stages 1-3 (digits, radix sort, bucket bounds) for window size c and copies the
+ * sorted (digit<<32|base) pairs [W*n] and bucket starts [W*(2^c+1)] back (bring-up aid) */
+int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
+                       uint64_t *pairs_out_host, uint32_t *start_out_host, uint32_t *total_tasks_out);
+/* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
+void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
+void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
+void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
+void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

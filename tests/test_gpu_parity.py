@@ -1,0 +1,418 @@
+"""GPU parity tests (run with `pytest -m gpu` on a MI355X): every call goes through the C ABI
+(libbellman_hip.so) and is compared BIT-EXACTLY with the CPU oracle (oracle/c, itself validated
+against the KAT-pinned oracle/pyref).  Integer work => exact equality, no tolerances.
+
+Covers SURVEY.md Appendix A: MSM items 1-9, FFT/domain items 10-15."""
+
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cref  # noqa: E402
+from oracle.pyref import bls12_381 as bls  # noqa: E402
+
+Q = bls.Q
+
+
+@pytest.fixture(scope="module")
+def worker():
+    import bellman_amd
+
+    w = bellman_amd.Worker(0)
+    yield w
+    w.close()
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dev(worker, arr):
+    d = worker.alloc(max(arr.nbytes, 16))
+    if arr.nbytes:
+        worker.upload(d, arr)
+    return d
+
+
+# ------------------------------------------------------------------------------ field / group
+def test_field_mul_on_device(worker):
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 20000
+    a, b = cref.random_fr(n, 11), cref.random_fr(n, 12)
+    a[0], b[0] = 0, 0
+    a[1] = cref.ints_to_arr([Q - 1], 4)[0]
+    b[1] = a[1]
+    da, db, dr = _dev(worker, a), _dev(worker, b), worker.alloc(a.nbytes)
+    assert lib.bh_test_fr_mul_dev(worker.ctx, dr, da, db, n) == 0
+    r = np.empty_like(a)
+    worker.download(r, dr)
+    assert np.array_equal(r, cref.mul_assign(a, b))
+    # Fp: random values below p
+    rnd = random.Random(5)
+    xs = [rnd.randrange(bls.P) for _ in range(2000)] + [0, 1, bls.P - 1]
+    ys = [rnd.randrange(bls.P) for _ in range(2000)] + [bls.P - 1] * 3
+    xa, ya = cref.ints_to_arr(xs, 6), cref.ints_to_arr(ys, 6)
+    dx, dy, dz = _dev(worker, xa), _dev(worker, ya), worker.alloc(xa.nbytes)
+    assert lib.bh_test_fp_mul_dev(worker.ctx, dz, dx, dy, len(xs)) == 0
+    z = np.empty_like(xa)
+    worker.download(z, dz)
+    rinv = pow(pow(2, 384, bls.P), -1, bls.P)
+    assert cref.arr_to_ints(z) == [x * y * rinv % bls.P for x, y in zip(xs, ys)]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_point_add_on_device(worker, group):
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 300
+    w = 12 if group == 1 else 24
+    A = cref.gen_bases(group, n, a=5, b=3)
+    B = cref.gen_bases(group, n, a=7, b=11)
+    B[0] = A[0]
+    B[1] = 0
+    A[2] = 0
+    B[3] = cref.point_mul(group, A[3], Q - 1)
+    A[4] = 0
+    B[4] = 0
+    dA, dB, dR = _dev(worker, A), _dev(worker, B), worker.alloc(A.nbytes)
+    assert lib.bh_test_point_add_dev(worker.ctx, group, dR, dA, dB, n) == 0
+    out = np.empty_like(A)
+    worker.download(out, dR)
+    want = np.stack([cref.point_add(group, A[i], B[i]) for i in range(n)])
+    assert np.array_equal(out, want)
+    assert out.shape[1] == w and not out[3].any() and not out[4].any()
+
+
+# ------------------------------------------------------------------------------ FFT
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 15, 16, 17, 18, 20])
+def test_fft_all_modes_bit_exact(worker, log_n):
+    """Appendix A 11,12,14: fft/ifft/coset_fft/icoset_fft == restated best_fft, every limb."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 1 << log_n
+    data = cref.random_fr(n, 100 + log_n)
+    for mode in (0, 1, 2, 3):
+        got = data.copy()
+        assert lib.bh_fft_fr(worker.ctx, _p(got), log_n, mode) == 0
+        want = cref.fft(data, mode, threads=8)
+        assert np.array_equal(got, want), (log_n, mode)
+
+
+def test_fft_2_22_config_c3(worker):
+    """BASELINE config C3: 2^22-point FFT/iFFT: exact vs the oracle + round-trip identities
+    (domain.rs:427-463 fft_composition)."""
+    import bellman_amd
+
+    log_n = 22
+    data = cref.random_fr(1 << log_n, 7)
+    d = bellman_amd.EvaluationDomain.from_coeffs(worker, data)
+    d.fft()
+    got = d.as_ref()
+    assert np.array_equal(got, cref.fft(data, 0, threads=cref.lib().orc_max_threads()))
+    d.ifft()
+    assert np.array_equal(d.as_ref(), data)
+    d.coset_fft()
+    d.icoset_fft()
+    assert np.array_equal(d.as_ref(), data)
+    d.icoset_fft()
+    d.coset_fft()
+    assert np.array_equal(d.into_coeffs(), data)
+
+
+def test_fft_degree_too_large(worker):
+    from bellman_amd import _lib
+
+    buf = np.zeros((1, 4), dtype=np.uint64)
+    assert _lib.load().bh_fft_fr(worker.ctx, _p(buf), 32, 0) == 3  # domain.rs:57-59
+
+
+def test_domain_pointwise_ops(worker):
+    """Appendix A 13: mul_assign, sub_assign, divide_by_z_on_coset, distribute_powers."""
+    import bellman_amd
+
+    n = 1 << 12
+    a, b = cref.random_fr(n, 21), cref.random_fr(n, 22)
+    da = bellman_amd.EvaluationDomain.from_coeffs(worker, a)
+    db = bellman_amd.EvaluationDomain.from_coeffs(worker, b)
+    da.mul_assign(worker, db)
+    want = cref.mul_assign(a, b)
+    assert np.array_equal(da.as_ref(), want)
+    da.sub_assign(worker, db)
+    want = cref.sub_assign(want, b)
+    assert np.array_equal(da.as_ref(), want)
+    da.divide_by_z_on_coset(worker)
+    want = cref.divide_by_z_on_coset(want)
+    assert np.array_equal(da.as_ref(), want)
+    g = cref.fr_to_mont(cref.ints_to_arr([123456789], 4))
+    da.distribute_powers(worker, g[0])
+    w2 = want.copy()
+    cref.lib().orc_distribute_powers(_p(w2), ctypes.c_size_t(n), _p(g), ctypes.c_int(8))
+    assert np.array_equal(da.into_coeffs(), w2)
+    db.into_coeffs()
+
+
+@pytest.mark.parametrize("n_evals", [1, 5, 13, 646, 5000])
+def test_h_poly_pipeline(worker, n_evals):
+    """Appendix A 15: the fused h block of create_proof (prover.rs:221-240)."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    a, b = cref.random_fr(n_evals, 31), cref.random_fr(n_evals, 32)
+    c = cref.mul_assign(a, b)  # satisfied constraints: a*b = c on the domain
+    m = 1
+    while m < n_evals:
+        m *= 2
+    out = np.zeros((max(m - 1, 1), 4), dtype=np.uint64)
+    hlen = ctypes.c_size_t(0)
+    assert lib.bh_h_poly_fr(worker.ctx, _p(a), _p(b), _p(c), n_evals, _p(out), ctypes.byref(hlen)) == 0
+    assert hlen.value == m - 1
+    pad = lambda v: np.concatenate([v, np.zeros((m - n_evals, 4), dtype=np.uint64)])  # noqa: E731
+    want = cref.h_coeffs(pad(a), pad(b), pad(c))
+    assert np.array_equal(out[: m - 1], want)
+
+
+# ------------------------------------------------------------------------------ MSM stages
+@pytest.mark.parametrize("n,c", [(1, 4), (100, 4), (5000, 7), (70000, 11), (1 << 17, 16)])
+def test_msm_sort_stages(worker, n, c):
+    """digits + stable radix sort + bucket bounds against numpy."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    sc = cref.random_fr(n, 40 + c)
+    if n > 10:
+        sc[3] = 0
+        sc[4] = sc[5]
+    W = (255 + c - 1) // c
+    nb = 1 << c
+    pairs = np.zeros(W * n, dtype=np.uint64)
+    start = np.zeros(W * (nb + 1), dtype=np.uint32)
+    tot = ctypes.c_uint32(0)
+    assert lib.bh_test_msm_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(start), ctypes.byref(tot)) == 0
+    ints = np.array(cref.arr_to_ints(sc), dtype=object)
+    nonempty = 0
+    for w in range(W):
+        digits = np.array([(int(v) >> (c * w)) & (nb - 1) for v in ints], dtype=np.uint64)
+        order = np.argsort(digits, kind="stable")
+        want = (digits[order] << np.uint64(32)) | order.astype(np.uint64)
+        got = pairs[w * n : (w + 1) * n]
+        assert np.array_equal(got, want), (w,)
+        st = start[w * (nb + 1) : (w + 1) * (nb + 1)]
+        assert np.array_equal(st, np.searchsorted(digits[order], np.arange(nb + 1), side="left").astype(np.uint32))
+        nonempty += len(set(digits[digits != 0].tolist()))
+    assert tot.value >= nonempty
+
+
+# ------------------------------------------------------------------------------ MSM
+def _scalars(n, seed, special=True):
+    sc = cref.random_fr(n, seed)
+    if special and n >= 12:
+        sc[1] = 0
+        sc[2] = cref.ints_to_arr([1], 4)[0]
+        sc[3] = cref.ints_to_arr([Q - 1], 4)[0]
+        sc[4] = cref.ints_to_arr([1 << 200], 4)[0]
+        sc[5] = sc[6]
+        sc[7] = cref.ints_to_arr([2], 4)[0]
+    return sc
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 100, 1000, 4113, 1 << 14])
+def test_msm_full_density_matches_oracle(worker, group, n):
+    """Appendix A 1,2,3,4,5,7,9 (n < 32 / >= 32 window rule boundary included)."""
+    import bellman_amd
+
+    if group == 2 and n > 5000:
+        pytest.skip("G2 large case covered by test_msm_g2_2_14")
+    bases = cref.gen_bases(group, n, a=3, b=5)
+    if n >= 12:
+        bases[9] = bases[8]  # duplicate base
+    sc = _scalars(n, 50 + n)
+    hb = bellman_amd.Bases(worker, group, bases)
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    rc, want = cref.multiexp(group, bases, 0, None, sc)
+    assert rc == 0
+    assert np.array_equal(got, want)
+
+
+def test_msm_g2_2_14(worker):
+    import bellman_amd
+
+    n = 1 << 14
+    bases = cref.gen_bases(2, n, a=9, b=2)
+    sc = _scalars(n, 77)
+    hb = bellman_amd.Bases(worker, 2, bases)
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    rc, want = cref.multiexp(2, bases, 0, None, sc)
+    assert rc == 0 and np.array_equal(got, want)
+
+
+def test_msm_empty_is_identity(worker):
+    import bellman_amd
+
+    hb = bellman_amd.Bases(worker, 1, cref.gen_bases(1, 4))
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), np.zeros((0, 4), dtype=np.uint64)).wait()
+    assert not got.any()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_density_skip_and_montgomery_scalars(worker, group):
+    """Appendix A 1: dense entries only, base index = skip + rank; scalars given as Rust `Scalar`s."""
+    import bellman_amd
+
+    n = 3000
+    rnd = np.random.default_rng(3)
+    bits = rnd.random(n) < 0.55
+    nb = int(bits.sum()) + 7
+    bases = cref.gen_bases(group, nb, a=2, b=7)
+    sc = _scalars(n, 91)
+    hb = bellman_amd.Bases(worker, group, bases)
+    dt = bellman_amd.DensityTracker(bits)
+    got = bellman_amd.multiexp(worker, hb, dt, sc, skip=7).wait()
+    rc, want = cref.multiexp(group, bases, 7, cref.density_bitmap(bits), sc)
+    assert rc == 0 and np.array_equal(got, want)
+    got2 = bellman_amd.multiexp(worker, hb, dt, cref.fr_to_mont(sc), skip=7, mont=True).wait()
+    assert np.array_equal(got2, want)
+
+
+def test_msm_skewed_scalars_split_buckets(worker):
+    """All scalars equal / boolean-heavy witnesses: exercises the split-bucket path."""
+    import bellman_amd
+
+    n = 20000
+    bases = cref.gen_bases(1, n, a=11, b=13)
+    hb = bellman_amd.Bases(worker, 1, bases)
+    sc = np.tile(cref.ints_to_arr([0x1234567 + (5 << 100) + (7 << 250)], 4), (n, 1))
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    rc, want = cref.multiexp(1, bases, 0, None, sc)
+    assert rc == 0 and np.array_equal(got, want)
+    rnd = np.random.default_rng(4)
+    sc2 = cref.random_fr(n, 5)
+    kind = rnd.integers(0, 4, size=n)
+    sc2[kind == 0] = 0
+    sc2[kind == 1] = cref.ints_to_arr([1], 4)[0]
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc2).wait()
+    rc, want = cref.multiexp(1, bases, 0, None, sc2)
+    assert rc == 0 and np.array_equal(got, want)
+
+
+def test_msm_error_semantics(worker):
+    """Appendix A 6: EOF / UnexpectedIdentity, incl. which one wins when both occur."""
+    import bellman_amd
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+
+    n = 200
+    bases = cref.gen_bases(1, n, a=4, b=9)
+    sc = cref.random_fr(n, 8)
+    sc[:, 3] |= np.uint64(1 << 60)  # top-window digit non-zero for every scalar
+
+    def run(bs, skip, density, scalars):
+        hb = bellman_amd.Bases(worker, 1, bs)
+        dm = bellman_amd.FullDensity() if density is None else bellman_amd.DensityTracker(density)
+        try:
+            bellman_amd.multiexp(worker, hb, dm, scalars, skip=skip).wait()
+            got = 0
+        except UnexpectedIdentity:
+            got = 1
+        except UnexpectedEof:
+            got = 2
+        want, _ = cref.multiexp(1, bs, skip, None if density is None else cref.density_bitmap(density), scalars)
+        assert got == want
+        return got
+
+    assert run(bases[:-1], 0, None, sc) == 2
+    assert run(bases, 1, None, sc) == 2
+    b2 = bases.copy()
+    b2[17] = 0
+    assert run(b2, 0, None, sc) == 1
+    s2 = sc.copy()
+    s2[17] = 0
+    assert run(b2, 0, None, s2) == 0
+    s3 = sc.copy()
+    s3[17] = cref.ints_to_arr([5], 4)[0]  # identity only met in window 0; EOF reported by the top window
+    assert run(b2[:-1], 0, None, s3) == 2
+    assert run(b2[:-1], 0, None, sc) == 1  # identity met first in the top window
+    assert run(bases[:0], 0, [False] * n, sc) == 0  # nothing dense: nothing consumed
+    with pytest.raises(AssertionError):  # density length mismatch panics in the reference
+        hb = bellman_amd.Bases(worker, 1, bases)
+        bellman_amd.multiexp(worker, hb, bellman_amd.DensityTracker([True] * (n - 1)), sc).wait()
+
+
+def test_msm_concurrent_jobs(worker):
+    """Appendix A 8: create_proof keeps 8 multiexps in flight before waiting on any."""
+    import bellman_amd
+
+    n = 5000
+    jobs, wants = [], []
+    for i in range(8):
+        g = 1 if i < 6 else 2
+        bases = cref.gen_bases(g, n, a=i + 1, b=3)
+        sc = cref.random_fr(n, 60 + i)
+        hb = bellman_amd.Bases(worker, g, bases)
+        jobs.append((hb, bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc)))
+        wants.append(cref.multiexp(g, bases, 0, None, sc)[1])
+    for (hb, j), want in zip(jobs, wants):
+        assert np.array_equal(j.wait(), want)
+
+
+def test_msm_window_bits_do_not_change_result(worker):
+    """Appendix A 7: c is unobservable."""
+    import bellman_amd
+    from bellman_amd import _lib
+
+    n = 3000
+    bases = cref.gen_bases(1, n, a=6, b=1)
+    sc = cref.random_fr(n, 9)
+    hb = bellman_amd.Bases(worker, 1, bases)
+    rc, want = cref.multiexp(1, bases, 0, None, sc)
+    try:
+        for c in (2, 3, 5, 8, 9, 13, 16):
+            _lib.load().bh_msm_set_window_bits(worker.ctx, c)
+            assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want), c
+    finally:
+        _lib.load().bh_msm_set_window_bits(worker.ctx, 0)
+
+
+def test_msm_2_20_config_c2(worker):
+    """BASELINE config C2: 2^20-base G1 MSM, bit-exact vs the restated multiexp, plus linearity."""
+    import bellman_amd
+
+    n = 1 << 20
+    bases = cref.gen_bases(1, n, a=1, b=1)
+    sc = cref.random_fr(n, 2020)
+    hb = bellman_amd.Bases(worker, 1, bases)
+    got, ms = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, timed=True).wait()
+    rc, want = cref.multiexp(1, bases, 0, None, sc, threads=cref.lib().orc_max_threads())
+    assert rc == 0 and np.array_equal(got, want)
+    print("G1 MSM 2^20 device ms:", ms)
+    # linearity: MSM(s, B[:h]) + MSM(s, B[h:]) == MSM(s, B)
+    h = n // 2
+    lo = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc[:h]).wait()
+    hi = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc[h:], skip=h).wait()
+    assert np.array_equal(cref.point_add(1, lo, hi), want)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_mul(worker, group):
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 500
+    w = 12 if group == 1 else 24
+    sc = _scalars(n, 13)
+    gen = cref.g1_generator() if group == 1 else cref.g2_generator()
+    dsc, dout = _dev(worker, sc), worker.alloc(n * w * 8)
+    assert lib.bh_fixed_base_mul_dev(worker.ctx, group, _p(np.ascontiguousarray(gen)), dsc, n, 0, dout, None) == 0
+    worker.synchronize()
+    out = np.zeros((n, w), dtype=np.uint64)
+    worker.download(out, dout)
+    ints = cref.arr_to_ints(sc)
+    for i in list(range(12)) + [100, 499]:
+        assert np.array_equal(out[i], cref.point_mul(group, gen, ints[i])), i
