@@ -14,5 +14,5 @@ from .errors import (  # noqa: F401
     UnexpectedIdentity,
 )
 from .multicore import Waiter, Worker  # noqa: F401
-from .multiexp import Bases, DensityTracker, FullDensity, multiexp  # noqa: F401
+from .multiexp import Bases, DensityTracker, FullDensity, multiexp, point_add  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401

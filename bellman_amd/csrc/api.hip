@@ -286,9 +286,9 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (rc == BH_OK)
     rc = msm_job_enqueue(*impl, bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev, g_forced_c.load());
   if (rc != BH_OK) {
-    float ms;
+    float ms[4];
     unsigned char dummy[192];
-    (void)msm_job_finish(*impl, dummy, &ms);
+    (void)msm_job_finish(*impl, dummy, ms);
     msm_job_delete(impl);
     return rc;
   }
@@ -303,13 +303,22 @@ int bh_msm_async_dev(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void
                      const uint64_t *density_words_dev, size_t density_len, bh_msm_job **job) {
   return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, job);
 }
-int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms) {
+int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;
-  int rc = msm_job_finish(*job->impl, out_affine, device_ms);
+  float ms[4] = {0, 0, 0, 0};
+  int rc = msm_job_finish(*job->impl, out_affine, ms);
+  if (stage_ms4) memcpy(stage_ms4, ms, sizeof ms);
   msm_job_delete(job->impl);
   delete job;
   return rc;
 }
+int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms) {
+  float ms[4];
+  int rc = bh_msm_wait_profile(job, out_affine, ms);
+  if (device_ms) *device_ms = ms[0];
+  return rc;
+}
+void bh_point_add(int group, void *r, const void *a, const void *b, size_t n) { host_point_add(group, r, a, b, n); }
 int bh_msm_wait(bh_msm_job *job, void *out_affine) { return bh_msm_wait_timed(job, out_affine, nullptr); }
 
 int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host, const void *scalars_dev, size_t n,
@@ -344,6 +353,9 @@ void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
 }
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
+}
+void bh_test_fr_inv_host(void *r, const void *a, size_t n) {
+  for (size_t i = 0; i < n; i++) fe_inv(((fr_t *)r)[i], ((const fr_t *)a)[i]);
 }
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { host_point_add(group, r, a, b, n); }
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { host_point_mul(group, r, a, k); }

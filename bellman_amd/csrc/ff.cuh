@@ -237,9 +237,9 @@ BH_HD void fe_pow(Fe<P> &r, const Fe<P> &a, const u32 *e, int nlimbs) {
 template <class P>
 BH_HD void fe_inv(Fe<P> &r, const Fe<P> &a) {  // a^(m-2); a != 0
   u32 e[P::N];
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < P::N; i++) e[i] = P::mod(i);
-  e[0] -= 2;  // both moduli have low limb >= 2
+  for (int i = 0; i < P::N; i++) e[i] = subb(P::mod(i), i == 0 ? 2u : 0u, br, br);  // m - 2 (Fr's low limb is 1)
   fe_pow(r, a, e, P::N);
 }
 

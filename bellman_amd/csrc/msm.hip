@@ -41,7 +41,8 @@ MsmJobImpl *msm_job_new(Context *ctx, int group) {
   j->ctx = ctx;
   j->group = group;
   if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&j->ev_begin) != hipSuccess || hipEventCreate(&j->ev_end) != hipSuccess) {
+      hipEventCreate(&j->ev_begin) != hipSuccess || hipEventCreate(&j->ev_end) != hipSuccess ||
+      hipEventCreate(&j->ev_sorted) != hipSuccess || hipEventCreate(&j->ev_accum) != hipSuccess) {
     delete j;
     return nullptr;
   }
@@ -53,6 +54,8 @@ void msm_job_delete(MsmJobImpl *j) {
   if (j->host_result) (void)hipHostFree(j->host_result);
   if (j->ev_begin) (void)hipEventDestroy(j->ev_begin);
   if (j->ev_end) (void)hipEventDestroy(j->ev_end);
+  if (j->ev_sorted) (void)hipEventDestroy(j->ev_sorted);
+  if (j->ev_accum) (void)hipEventDestroy(j->ev_accum);
   if (j->stream) (void)hipStreamDestroy(j->stream);
   delete j;
 }
@@ -68,7 +71,7 @@ int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 ski
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   if (job.trivial) {
     memset(out_affine, 0, job.group == BH_G1 ? 96 : 192);
-    if (ms) *ms = 0.f;
+    if (ms) ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
     return job.early_rc;
   }
   return job.group == BH_G1 ? msm_finish_g1(job, out_affine, ms) : msm_finish_g2(job, out_affine, ms);

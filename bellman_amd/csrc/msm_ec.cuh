@@ -223,10 +223,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   }
   Task *tasks = b.tasks;
   BigBucket *big = b.big;
+  BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
   // 4. accumulate
   hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((u32)((p.max_tasks + 127) / 128)), dim3(128), 0, st, sorted,
                      tasks, (const Affine<F> *)bases_dev, pts, err);
   BH_HIP_CHECK(hipGetLastError());
+  BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
   hipLaunchKernelGGL(msm_merge_big_kernel<F>, dim3(256), dim3(64), 0, st, pts, big, err, p.NB, p.max_big);
   BH_HIP_CHECK(hipGetLastError());
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits
@@ -285,7 +287,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   int rc = BH_OK;
   if (job.trivial) {
     memset(out_affine, 0, sizeof(Affine<F>));
-    if (ms) *ms = 0.f;
+    if (ms) ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
     return job.early_rc;
   }
   if (hipStreamSynchronize(job.stream) != hipSuccess) rc = BH_ERR_HIP;
@@ -294,7 +296,12 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     const size_t bits_bytes = (size_t)p.W * p.c * sizeof(XYZZ<F>);
     ErrFlags ef;
     memcpy(&ef, (char *)job.host_result + bits_bytes, sizeof ef);
-    if (ms) (void)hipEventElapsedTime(ms, job.ev_begin, job.ev_end);
+    if (ms) {  // [0] whole device pipeline, [1] digits+sort+tasks, [2] bucket accumulation, [3] reductions
+      (void)hipEventElapsedTime(&ms[0], job.ev_begin, job.ev_end);
+      (void)hipEventElapsedTime(&ms[1], job.ev_begin, job.ev_sorted);
+      (void)hipEventElapsedTime(&ms[2], job.ev_sorted, job.ev_accum);
+      (void)hipEventElapsedTime(&ms[3], job.ev_accum, job.ev_end);
+    }
     if (ef.eof && ef.ident) {
       // both kinds of failure exist: the reference reports the top window's first failure
       const double cref = (p.n < 32) ? 3.0 : std::ceil(std::log((double)p.n));   // multiexp.rs:318-322

@@ -42,6 +42,7 @@ struct MsmJobImpl {
   int group = BH_G1;
   hipStream_t stream = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_sorted = nullptr, ev_accum = nullptr;   // stage boundaries (profiling)
   MsmPlan plan;
   std::vector<void *> dev_allocs;     // returned to the pool on wait
   void *host_result = nullptr;        // pinned: W*c XYZZ + ErrFlags
@@ -78,7 +79,7 @@ int msm_enqueue_g1(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
                    int fmt, const u64 *density_dev, unsigned forced_c);
 int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
                    int fmt, const u64 *density_dev, unsigned forced_c);
-int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);
+int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);   // ms: float[4] or null
 int msm_finish_g2(MsmJobImpl &job, void *out_affine, float *ms);
 int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
 int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);

@@ -103,7 +103,7 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
 
     exponents: [n,4] uint64 scalars on the host; or pass scalars_dev (device pointer) + n.
     The Waiter's wait() returns the affine result record (numpy uint64[12|24]) or raises the
-    SynthesisError the reference would return.  With timed=True it returns (record, device_ms)."""
+    SynthesisError the reference would return.  With timed=True it returns (record, [total, sort, accumulate, reduce] device ms)."""
     lib = _lib.load()
     words = None
     dlen = 0
@@ -126,8 +126,18 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
 
     def finish():
         out = np.zeros(w, dtype=np.uint64)
-        ms = ctypes.c_float(0)
-        check(lib.bh_msm_wait_timed(job, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)), "multiexp.wait")
-        return (out, ms.value) if timed else out
+        ms = (ctypes.c_float * 4)()
+        check(lib.bh_msm_wait_profile(job, out.ctypes.data_as(ctypes.c_void_p), ms), "multiexp.wait")
+        return (out, list(ms)) if timed else out
 
     return Waiter(fn=finish)
+
+
+def point_add(group, a, b):
+    """Host-side affine addition of result records (folding per-GPU partial sums)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    _lib.load().bh_point_add(group, out.ctypes.data_as(ctypes.c_void_p), a.ctypes.data_as(ctypes.c_void_p),
+                             b.ctypes.data_as(ctypes.c_void_p), 1)
+    return out

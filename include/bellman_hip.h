@@ -122,6 +122,12 @@ int bh_msm_wait(bh_msm_job *job, void *out_affine);
 /* device time of the job's kernels in milliseconds (hipEvents on the job's stream); valid
  * after bh_msm_wait's return value has been observed via bh_msm_wait_timed */
 int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms);
+/* as above with per-stage device times (hipEvents on the job's stream), milliseconds:
+ * [0] whole pipeline  [1] digits + radix sort + task list  [2] bucket accumulation  [3] reductions */
+int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4);
+/* r[i] = a[i] + b[i] for affine records on the HOST - used to fold the per-GPU partial results of
+ * a base-sharded MSM after the all-gather, and g_a/g_b/g_c in create_proof. */
+void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);
 /* tuning knob for experiments: window bits c (0 = automatic) */
 int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c);
 
@@ -145,6 +151,7 @@ void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
+void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
 
 #ifdef __cplusplus
 }

@@ -98,3 +98,16 @@ def test_host_group_law_matches_oracle(lib, group):
         o = np.zeros(w, dtype=np.uint64)
         lib.bh_test_point_mul_host(group, _p(o), _p(A[4]), _p(ka))
         assert np.array_equal(o, cref.point_mul(group, A[4], k))
+
+
+def test_host_fr_inverse_matches_oracle(lib):
+    """Host-side domain constants (minv, zinv, geninv: domain.rs:75-78,139-140) come from fe_inv.
+    Regression for the first GPU run: q-2 must borrow across 32-bit limbs (q's low limb is 1)."""
+    a = cref.random_fr(20, 9)
+    a[0] = cref.fr_to_mont(cref.ints_to_arr([2], 4))[0]
+    r = np.zeros_like(a)
+    lib.bh_test_fr_inv_host(_p(r), _p(a), 20)
+    want = np.zeros_like(a)
+    for i in range(20):
+        cref.lib().orc_fr_inv(_p(want[i : i + 1]), _p(np.ascontiguousarray(a[i : i + 1])))
+    assert np.array_equal(r, want)
