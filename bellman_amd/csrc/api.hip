@@ -29,7 +29,7 @@ int test_fr_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 int test_fp_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
 int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
-                    u32 *start_out, u32 *total_tasks_out);
+                    u32 *zstart_out);
 void host_point_mul(int group, void *r, const void *a, const void *k);
 
 static std::atomic<unsigned> g_forced_c{0};
@@ -248,7 +248,12 @@ size_t bh_bases_len(const bh_bases *b) { return b->n; }
 // ---- multiexp -----------------------------------------------------------------------------------
 int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c) {
   (void)ctx;
-  g_forced_c.store(c);
+  g_forced_c.store((g_forced_c.load() & ~0xffu) | (c & 0xffu));
+  return BH_OK;
+}
+int bh_msm_set_chunk(bh_ctx *ctx, unsigned k) {
+  (void)ctx;
+  g_forced_c.store((g_forced_c.load() & 0xffu) | (k << 8));
   return BH_OK;
 }
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
@@ -344,9 +349,8 @@ int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r, const void *a, const 
   return rc;
 }
 int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *start_out_host, uint32_t *total_tasks_out) {
-  return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, start_out_host,
-                         total_tasks_out);
+                       uint64_t *pairs_out_host, uint32_t *zstart_out_host) {
+  return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, zstart_out_host);
 }
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fr_t *)r)[i], ((const fr_t *)a)[i], ((const fr_t *)b)[i]);

@@ -167,39 +167,103 @@ BH_HD void fe_dbl(Fe<P> &r, const Fe<P> &a) {
   fe_add(r, a, a);
 }
 
-// Montgomery product, CIOS over 32-bit limbs: r = a*b*R^-1 mod m.
-// Bound: with a,b < m < 2^(32N-1) the running value stays < m*2^33 < 2^(32(N+1)),
-// so N+1 words suffice and the result is < 2m (one conditional subtraction).
+// ---------------------------------------------------------------------------------------
+// Montgomery product  r = a*b*2^(-32N) mod m.
+//
+// gfx950's only wide integer multiplier is v_mad_u64_u32 (32x32 + 64 -> 64, ~26 T/s measured,
+// profiles/r1_microbench_int.txt) and it has no carry-in, so a 32-bit-limb CIOS spends more
+// time on carry adds and register moves than on multiplying (1200 instructions, 288 of them
+// mads).  Instead the operands are re-sliced into L limbs of 30 bits: a column of the
+// schoolbook product is then a sum of <= L products < 2^60, which a 64-bit accumulator holds
+// without overflow, i.e. a pure chain of mads with no carry handling at all.  The reduction is
+// done column-wise in the same radix with R' = 2^(30L); feeding b*2^(30L-32N) instead of b
+// makes the result a*b*2^(-32N), the Montgomery form used in memory.  Inputs and output are the
+// fully reduced 32-bit-limb representation.
+// ---------------------------------------------------------------------------------------
+template <class P>
+struct Radix30 {
+  static constexpr int N = P::N;
+  static constexpr int L = (32 * N + 29) / 30;        // 13 for Fp, 9 for Fr
+  static constexpr int SHIFT = 30 * L - 32 * N;       // 6 for Fp, 14 for Fr
+  static constexpr u32 MASK = 0x3fffffffu;
+  static constexpr u32 INV = P::INV & MASK;           // -m^-1 mod 2^30
+  // bits [30*i, 30*i+30) of the modulus
+  BH_HD static constexpr u32 mod(int i) {
+    const int bp = 30 * i, w = bp / 32, sh = bp % 32;
+    u64 v = (w < N) ? P::mod(w) : 0u;
+    if (w + 1 < N) v |= (u64)P::mod(w + 1) << 32;
+    return (u32)(v >> sh) & MASK;
+  }
+};
+
+// limb i (30 bits) of (x << SH), x given as N 32-bit words
+template <class P, int SH>
+BH_HD u32 fe_limb30(const Fe<P> &x, int i) {
+  const int bp = 30 * i - SH;
+  if (bp < 0) return (x.l[0] << (-bp)) & 0x3fffffffu;   // only limb 0, since SH < 30
+  const int w = bp / 32, sh = bp % 32;
+  u32 v = (w < P::N) ? (x.l[w] >> sh) : 0u;
+  if (sh > 2 && w + 1 < P::N) v |= x.l[w + 1] << (32 - sh);
+  return v & 0x3fffffffu;
+}
+
 template <class P>
 BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
-  constexpr int N = P::N;
-  u32 t[N + 1];
+  typedef Radix30<P> R;
+  constexpr int N = P::N, L = R::L;
+  u32 A[L], B[L];
 #pragma unroll
-  for (int i = 0; i <= N; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const u32 bi = b.l[i];
-    u64 c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      c += (u64)a.l[j] * bi + t[j];
-      t[j] = (u32)c;
-      c >>= 32;
-    }
-    u32 tn = t[N] + (u32)c;  // cannot overflow (bound above)
-    const u32 m = t[0] * P::INV;
-    c = ((u64)m * P::mod(0) + t[0]) >> 32;
-#pragma unroll
-    for (int j = 1; j < N; j++) {
-      c += (u64)m * P::mod(j) + t[j];
-      t[j - 1] = (u32)c;
-      c >>= 32;
-    }
-    c += tn;
-    t[N - 1] = (u32)c;
-    t[N] = (u32)(c >> 32);
+  for (int i = 0; i < L; i++) {
+    A[i] = fe_limb30<P, 0>(a, i);
+    B[i] = fe_limb30<P, R::SHIFT>(b, i);
   }
-  fe_reduce_once<P>(r, t);
+  // product columns: c[k] = sum_{i+j=k} A[i]*B[j]  (< L * 2^60 < 2^64)
+  u64 c[2 * L];
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+#pragma unroll
+    for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
+  }
+  // column-wise Montgomery reduction.  Column k holds c[k] + carry + sum m[i]*mod[k-i]; the high
+  // part of c[k] goes straight into the next carry so the running sum t stays below 2^64
+  // (t < 2^30 + carry + L*2^60 with carry < 2^35).
+  u32 m[L], out[L];
+  u64 carry = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+    u64 t = (c[k] & R::MASK) + carry;
+#pragma unroll
+    for (int i = 0; i < k; i++) t += (u64)m[i] * R::mod(k - i);
+    m[k] = ((u32)t * R::INV) & R::MASK;
+    t += (u64)m[k] * R::mod(0);      // low 30 bits of t are now zero
+    carry = (t >> 30) + (c[k] >> 30);
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+    u64 t = (c[k] & R::MASK) + carry;
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) t += (u64)m[i] * R::mod(k - i);
+    out[k - L] = (u32)t & R::MASK;
+    carry = (t >> 30) + (c[k] >> 30);
+  }
+  // repack 30-bit limbs into 32-bit words (value < 2m < 2^(32N))
+  u32 w[N];
+  u64 acc = 0;
+  int bits = 0, wi = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    acc |= (u64)out[i] << bits;
+    bits += 30;
+    if (bits >= 32 && wi < N) {
+      w[wi++] = (u32)acc;
+      acc >>= 32;
+      bits -= 32;
+    }
+  }
+  if (wi < N) w[wi] = (u32)acc;
+  fe_reduce_once<P>(r, w);
 }
 
 template <class P>

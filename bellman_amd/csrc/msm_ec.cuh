@@ -37,104 +37,205 @@ __global__ void msm_err_resolve_kernel(const void *scalars, int fmt, u32 n, cons
 }
 
 // ============================================================================================
-// 4. bucket accumulation
+// 4. bucket accumulation over equal chunks of the sorted stream
 // ============================================================================================
+// Lane l of window w owns sorted entries [z_w + l*K, z_w + (l+1)*K).  Buckets that lie completely
+// inside the chunk are written straight to pts[bucket]; the (at most two) buckets shared with
+// the neighbouring chunks go to head[l] / tail[l] and are folded by msm_merge_chunks_kernel.
+struct ChunkView {
+  u32 begin, end;       // entry range inside the window
+  u32 d_first, d_last;  // digits of the first / last entry
+  bool head_partial;    // first bucket started in an earlier chunk
+  bool tail_partial;    // last bucket continues in the next chunk
+};
+__device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lane, u32 K, ChunkView &v) {
+  const u64 b = (u64)z + (u64)lane * K;
+  if (b >= n) return false;
+  v.begin = (u32)b;
+  v.end = (u32)min((u64)n, b + K);
+  v.d_first = (u32)(src[v.begin] >> 32);
+  v.d_last = (u32)(src[v.end - 1] >> 32);
+  v.head_partial = v.begin > 0 && (u32)(src[v.begin - 1] >> 32) == v.d_first;
+  v.tail_partial = v.end < n && (u32)(src[v.end] >> 32) == v.d_last;
+  return true;
+}
+
 template <class F>
-__global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const Task *tasks,
+__global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const u32 *zstart,
                                                              const Affine<F> *bases, XYZZ<F> *pts,
-                                                             ErrFlags *err) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= err->total_tasks) return;
-  const Task task = tasks[t];
+                                                             XYZZ<F> *head, XYZZ<F> *tail, u32 n, u32 c,
+                                                             u32 K, u32 chunks_per_window, ErrFlags *err) {
+  const u32 w = blockIdx.y;
+  const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 *src = pairs + (u64)w * n;
+  ChunkView v;
+  if (lane >= chunks_per_window || !chunk_view(src, n, zstart[w], lane, K, v)) return;
+  XYZZ<F> *bucket = pts + ((u64)w << c);
+  const u64 slot = (u64)w * chunks_per_window + lane;
   XYZZ<F> acc;
   xyzz_set_identity(acc);
+  u32 cur = v.d_first;
   bool saw_identity = false;
-  for (u32 p = task.begin; p < task.end; p++) {
-    const u32 idx = (u32)pairs[p];
-    const Affine<F> q = bases[idx];
+  for (u32 p = v.begin; p < v.end; p++) {
+    const u64 e = src[p];
+    const u32 d = (u32)(e >> 32);
+    if (d != cur) {   // bucket `cur` ends inside this chunk
+      if (cur == v.d_first && v.head_partial) head[slot] = acc; else bucket[cur] = acc;
+      xyzz_set_identity(acc);
+      cur = d;
+    }
+    const Affine<F> q = bases[(u32)e];
     if (aff_is_identity(q)) { saw_identity = true; continue; }
     xyzz_madd(acc, q);
   }
+  if (cur == v.d_first && v.head_partial) head[slot] = acc;
+  else if (v.tail_partial) tail[slot] = acc;
+  else bucket[cur] = acc;
   if (saw_identity) atomicOr(&err->ident, 1u);
-  pts[task.dest] = acc;
 }
 
-// ============================================================================================
-// 5. reductions: one wavefront per output point
-// ============================================================================================
-// tree-reduce the 64 per-lane accumulators of a one-wave workgroup through LDS
+// Folds the partial sums of buckets that straddle chunk boundaries.  The lane whose chunk holds
+// the bucket's first entry owns the merge: tail[l] + head[l+1] + ... until the bucket ends.  Runs
+// longer than MERGE_WALK chunks (narrow top window, skewed scalars) are queued for
+// msm_merge_long_kernel so that no lane ever executes a long serial chain of point additions.
+// `walk` = chunks an owner folds serially (a few times the average run length).
 template <class F>
-__device__ __forceinline__ void wave_reduce_points(XYZZ<F> &acc, XYZZ<F> *slots) {
-  const u32 lane = threadIdx.x;
-  for (u32 off = 32; off >= 1; off >>= 1) {
-    if (lane >= off && lane < 2 * off) slots[lane] = acc;
-    __syncthreads();
-    if (lane < off) {
-      XYZZ<F> o = slots[lane + off];
+__global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart, XYZZ<F> *pts,
+                                                               const XYZZ<F> *head, const XYZZ<F> *tail, u32 n,
+                                                               u32 c, u32 K, u32 chunks_per_window, u32 walk,
+                                                               LongRun *long_runs, u32 max_long, ErrFlags *err) {
+  const u32 w = blockIdx.y;
+  const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 *src = pairs + (u64)w * n;
+  const u32 z = zstart[w];
+  ChunkView v;
+  if (lane >= chunks_per_window || !chunk_view(src, n, z, lane, K, v)) return;
+  if (!v.tail_partial) return;
+  if (v.head_partial && v.d_first == v.d_last) return;   // a middle piece of a long bucket
+  const u32 d = v.d_last;
+  const u64 slot0 = (u64)w * chunks_per_window;
+  XYZZ<F> acc = tail[slot0 + lane];
+  bool ended = false;
+  for (u32 j = lane + 1; j < chunks_per_window && j <= lane + walk; j++) {
+    ChunkView u;
+    if (!chunk_view(src, n, z, j, K, u) || u.d_first != d) { ended = true; break; }
+    XYZZ<F> o = head[slot0 + j], r;
+    xyzz_add(r, acc, o);
+    acc = r;
+    if (u.d_last != d || !u.tail_partial) { ended = true; break; }   // the bucket ended in chunk j
+  }
+  if (!ended && lane + walk + 1 < chunks_per_window) {
+    // still running after `walk` chunks: hand the whole run to the workgroup-parallel merge
+    ChunkView u;
+    if (chunk_view(src, n, z, lane + walk + 1, K, u) && u.d_first == d) {
+      const u32 slot = atomicAdd(&err->nlong, 1u);
+      if (slot < max_long) { LongRun lr = {w, lane, d}; long_runs[slot] = lr; }
+      return;
+    }
+  }
+  pts[((u64)w << c) + d] = acc;
+}
+
+// shuffle-based tree reduction of per-lane points over groups of G consecutive lanes
+template <class F>
+__device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G) {
+  constexpr int NW = sizeof(XYZZ<F>) / 4;
+  for (u32 off = G >> 1; off >= 1; off >>= 1) {
+    XYZZ<F> o;
+    u32 *dst = reinterpret_cast<u32 *>(&o);
+    const u32 *srcw = reinterpret_cast<const u32 *>(&acc);
+#pragma unroll
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(srcw[i], off);
+    if ((threadIdx.x & (G - 1)) < off) {
       XYZZ<F> r;
       xyzz_add(r, acc, o);
       acc = r;
+    }
+  }
+}
+
+// One 512-thread workgroup per long run: tail[l0] + sum of head[l0+1 .. l1].
+constexpr u32 LONG_THREADS = 512;
+template <class F>
+__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 *pairs, const u32 *zstart,
+                                                                      XYZZ<F> *pts, const XYZZ<F> *head,
+                                                                      const XYZZ<F> *tail, u32 n, u32 c, u32 K,
+                                                                      u32 chunks_per_window, const LongRun *long_runs,
+                                                                      u32 max_long, const ErrFlags *err) {
+  __shared__ XYZZ<F> wave_part[LONG_THREADS / 64];
+  __shared__ u32 s_last;
+  u32 nlong = err->nlong;
+  if (nlong > max_long) nlong = max_long;
+  const u32 tid = threadIdx.x;
+  for (u32 e = blockIdx.x; e < nlong; e += gridDim.x) {
+    const LongRun lr = long_runs[e];
+    const u64 *src = pairs + (u64)lr.w * n;
+    const u32 z = zstart[lr.w];
+    if (tid == 0) {   // last sorted position holding digit d -> last chunk of the run
+      u32 lo = z + lr.lane * K, hi = n;   // first index with digit > d
+      while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if ((u32)(src[mid] >> 32) <= lr.d) lo = mid + 1; else hi = mid;
+      }
+      s_last = (lo - 1 - z) / K;
+    }
+    __syncthreads();
+    const u32 l1 = s_last;
+    const u64 slot0 = (u64)lr.w * chunks_per_window;
+    XYZZ<F> acc;
+    xyzz_set_identity(acc);
+    if (tid == 0) acc = tail[slot0 + lr.lane];
+    for (u32 j = lr.lane + 1 + tid; j <= l1; j += LONG_THREADS) {
+      XYZZ<F> o = head[slot0 + j], r;
+      xyzz_add(r, acc, o);
+      acc = r;
+    }
+    group_reduce_points<F>(acc, 64);
+    if ((tid & 63) == 0) wave_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid < 64) {
+      if (tid < LONG_THREADS / 64) acc = wave_part[tid]; else xyzz_set_identity(acc);
+      group_reduce_points<F>(acc, LONG_THREADS / 64);
+      if (tid == 0) pts[((u64)lr.w << c) + lr.d] = acc;
     }
     __syncthreads();
   }
 }
 
-
+// ============================================================================================
+// 5. reductions: G lanes per output point (serial partial sums, then a shuffle tree)
+// ============================================================================================
 // out[g] = sum of a set of in[] points chosen by the mode:
-//   SUM_STRIDED: g = (outer, innerIdx): elements in[(outer << group_shift) + innerIdx*istride + t*stride]
-//   SUM_BITS   : g = (outer, k): elements in[(outer << group_shift) + i], i < count, bit k of i set
+//   SUM_STRIDED: g = (outer, inner): elements in[(outer << group_shift) + inner*istride + t*stride], t < count
+//   SUM_BITS   : g = (outer, k):     elements in[(outer << group_shift) + i], i < count, bit k of i set
 template <class F>
-__global__ __launch_bounds__(64) void msm_sum_kernel(const XYZZ<F> *in, XYZZ<F> *out, SumDesc d, u32 istride) {
-  __shared__ XYZZ<F> slots[64];
-  const u32 lane = threadIdx.x;
-  const u32 g = blockIdx.x;
+__global__ __launch_bounds__(64) void msm_sum_kernel(const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) {
+  const u32 G = d.lanes;
+  const u32 g = (blockIdx.x * 64 + threadIdx.x) / G;
+  const u32 sub = threadIdx.x & (G - 1);
   XYZZ<F> acc;
   xyzz_set_identity(acc);
-  const u32 outer = g / d.inner, in_idx = g % d.inner;
-  const XYZZ<F> *base = in + ((u64)outer << d.group_shift);
-  if (d.mode == SUM_STRIDED) {
-    for (u32 t = lane; t < d.count; t += 64) {
-      XYZZ<F> o = base[(u64)in_idx * istride + (u64)t * d.stride];
-      XYZZ<F> r;
-      xyzz_add(r, acc, o);
-      acc = r;
-    }
-  } else {  // SUM_BITS: in_idx = bit position k
-    for (u32 i = lane; i < d.count; i += 64) {
-      if ((i >> in_idx) & 1) {
-        XYZZ<F> o = base[i];
-        XYZZ<F> r;
+  if (g < d.groups) {
+    const u32 outer = g / d.inner, in_idx = g % d.inner;
+    const XYZZ<F> *base = in + ((u64)outer << d.group_shift);
+    if (d.mode == SUM_STRIDED) {
+      for (u32 t = sub; t < d.count; t += G) {
+        XYZZ<F> o = base[(u64)in_idx * d.istride + (u64)t * d.stride], r;
         xyzz_add(r, acc, o);
         acc = r;
       }
+    } else {  // SUM_BITS: in_idx = bit position k
+      for (u32 i = sub; i < d.count; i += G) {
+        if ((i >> in_idx) & 1) {
+          XYZZ<F> o = base[i], r;
+          xyzz_add(r, acc, o);
+          acc = r;
+        }
+      }
     }
   }
-  wave_reduce_points<F>(acc, slots);
-  if (lane == 0) out[g] = acc;
-}
-
-// merge the partial sums of split buckets back into their bucket slot
-template <class F>
-__global__ __launch_bounds__(64) void msm_merge_big_kernel(XYZZ<F> *pts, const BigBucket *big, const ErrFlags *err,
-                                                          u32 NB, u32 max_big) {
-  __shared__ XYZZ<F> slots[64];
-  const u32 lane = threadIdx.x;
-  u32 nbig = err->nbig;
-  if (nbig > max_big) nbig = max_big;
-  for (u32 e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const BigBucket bb = big[e];
-    XYZZ<F> acc;
-    xyzz_set_identity(acc);
-    for (u32 t = lane; t < bb.ntasks; t += 64) {
-      XYZZ<F> o = pts[(u64)NB + bb.first_task + t];
-      XYZZ<F> r;
-      xyzz_add(r, acc, o);
-      acc = r;
-    }
-    wave_reduce_points<F>(acc, slots);
-    if (lane == 0) pts[bb.bucket] = acc;
-    __syncthreads();
-  }
+  group_reduce_points<F>(acc, G);
+  if (sub == 0 && g < d.groups) out[g] = acc;
 }
 
 // ============================================================================================
@@ -178,7 +279,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                        u64 n, int fmt, const u64 *density_dev, unsigned forced_c) {
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
-  const MsmPlan p = make_plan(n, forced_c);
+  const MsmPlan p = make_plan(n, forced_c & 0xffu, forced_c >> 8);
   job.plan = p;
   if ((u64)p.W * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
   auto alloc = [&](size_t bytes) -> void * {
@@ -192,12 +293,16 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   b.pairs_a = (u64 *)alloc(npairs * 8);
   b.pairs_b = (u64 *)alloc(npairs * 8);
   b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(std::max<u64>(ncounts, p.NB + 1)) * 4);
-  b.start = (u32 *)alloc((u64)p.W * (p.nb + 1) * 4);
-  b.task_off = (u32 *)alloc(((u64)p.NB + 1) * 4);
-  b.tasks = (Task *)alloc(p.max_tasks * sizeof(Task));
-  b.big = (BigBucket *)alloc((u64)p.max_big * sizeof(BigBucket));
-  XYZZ<F> *pts = (XYZZ<F> *)alloc(((u64)p.NB + p.max_tasks) * sizeof(XYZZ<F>));
+  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
+  b.zstart = (u32 *)alloc((u64)p.W * 4);
+  const u64 nslots = (u64)p.W * p.chunks_per_window;
+  XYZZ<F> *pts = (XYZZ<F> *)alloc((u64)p.NB * sizeof(XYZZ<F>));
+  XYZZ<F> *head = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
+  XYZZ<F> *tail = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
+  // serial walk bound: 4x the average number of chunks per bucket, at least 8
+  const u32 walk = std::max<u32>(8, 4 * ((p.n >> p.c) / p.chunk + 1));
+  const u32 max_long = (u32)(nslots / (walk + 1) + 1);
+  LongRun *long_runs = (LongRun *)alloc((u64)max_long * sizeof(LongRun));
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
   XYZZ<F> *rowcol = (XYZZ<F> *)alloc((u64)p.W * (H + Lw) * sizeof(XYZZ<F>));
   XYZZ<F> *bits = (XYZZ<F> *)alloc((u64)p.W * p.c * sizeof(XYZZ<F>));
@@ -205,8 +310,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   b.word_prefix = nullptr;
   const u64 nwords = (n + 63) / 64;
   if (density_dev) b.word_prefix = (u32 *)alloc((nwords + 1) * 4);
-  if (!b.pairs_a || !b.pairs_b || !b.counts || !b.scan_tmp || !b.start || !b.task_off || !b.tasks || !b.big ||
-      !pts || !rowcol || !bits || !b.err || (density_dev && !b.word_prefix))
+  if (!b.pairs_a || !b.pairs_b || !b.counts || !b.scan_tmp || !b.zstart || !pts || !head || !tail || !long_runs || !rowcol ||
+      !bits || !b.err || (density_dev && !b.word_prefix))
     return BH_ERR_HIP;
   ErrFlags *err = b.err;
   job.err_dev = err;
@@ -221,36 +326,51 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     int rc = msm_run_stages(p, b, scalars_dev, fmt, density_dev, skip, n_bases, st, &sorted);
     if (rc) return rc;
   }
-  Task *tasks = b.tasks;
-  BigBucket *big = b.big;
   BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
-  // 4. accumulate
-  hipLaunchKernelGGL(msm_accumulate_kernel<F>, dim3((u32)((p.max_tasks + 127) / 128)), dim3(128), 0, st, sorted,
-                     tasks, (const Affine<F> *)bases_dev, pts, err);
-  BH_HIP_CHECK(hipGetLastError());
-  BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
-  hipLaunchKernelGGL(msm_merge_big_kernel<F>, dim3(256), dim3(64), 0, st, pts, big, err, p.NB, p.max_big);
-  BH_HIP_CHECK(hipGetLastError());
-  // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits
+  // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
+  {
+    const dim3 grid((p.chunks_per_window + 127) / 128, p.W);
+    hipLaunchKernelGGL(msm_accumulate_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart,
+                       (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    BH_HIP_CHECK(hipGetLastError());
+    BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
+    hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
+                       p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
+    BH_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_merge_long_kernel<F>, dim3(256), dim3(LONG_THREADS), 0, st, sorted, b.zstart, pts, head,
+                       tail, p.n, p.c, p.chunk, p.chunks_per_window, long_runs, max_long, err);
+    BH_HIP_CHECK(hipGetLastError());
+  }
+  // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
+  // G lanes per output chosen so that each launch is about one wavefront per SIMD.
   XYZZ<F> *rows = rowcol, *cols = rowcol + (u64)p.W * H;
+  auto pick_lanes = [&](u32 groups, u32 count) {
+    u32 g = 64;
+    const u64 target = (u64)c.num_cus * 4 * 64 * 2;   // about two waves per SIMD
+    while (g > 4 && (u64)groups * g > target) g >>= 1;
+    while (g > 1 && g > count) g >>= 1;
+    return g;
+  };
+  auto launch_sum = [&](const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) -> int {
+    d.lanes = pick_lanes(d.groups, d.mode == SUM_BITS ? d.count / 2 : d.count);
+    const u64 lanes = (u64)d.groups * d.lanes;
+    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3((u32)((lanes + 63) / 64)), dim3(64), 0, st, in, out, d);
+    BH_HIP_CHECK(hipGetLastError());
+    return BH_OK;
+  };
   {
     SumDesc d;
-    d.mode = SUM_STRIDED; d.groups = p.W * H; d.count = Lw; d.inner = H; d.stride = 1; d.group_shift = p.c;
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(d.groups), dim3(64), 0, st, pts, rows, d, Lw);
-    BH_HIP_CHECK(hipGetLastError());
-    d.groups = p.W * Lw; d.count = H; d.inner = Lw; d.stride = Lw;
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(d.groups), dim3(64), 0, st, pts, cols, d, 1u);
-    BH_HIP_CHECK(hipGetLastError());
+    int rc;
+    d.mode = SUM_STRIDED; d.groups = p.W * H; d.count = Lw; d.inner = H; d.stride = 1; d.istride = Lw; d.group_shift = p.c;
+    if ((rc = launch_sum(pts, rows, d))) return rc;
+    d.groups = p.W * Lw; d.count = H; d.inner = Lw; d.stride = Lw; d.istride = 1;
+    if ((rc = launch_sum(pts, cols, d))) return rc;
     // U[w][p]: p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi)
-    d.mode = SUM_BITS; d.stride = 1;
+    d.mode = SUM_BITS; d.stride = 1; d.istride = 0;
     d.groups = p.W * p.lo_bits; d.count = Lw; d.inner = p.lo_bits; d.group_shift = p.lo_bits;
-    if (d.groups) {
-      hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(d.groups), dim3(64), 0, st, cols, bits, d, 0u);
-      BH_HIP_CHECK(hipGetLastError());
-    }
+    if (d.groups && (rc = launch_sum(cols, bits, d))) return rc;
     d.groups = p.W * p.hi_bits; d.count = H; d.inner = p.hi_bits; d.group_shift = p.hi_bits;
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(d.groups), dim3(64), 0, st, rows, bits + (u64)p.W * p.lo_bits, d, 0u);
-    BH_HIP_CHECK(hipGetLastError());
+    if ((rc = launch_sum(rows, bits + (u64)p.W * p.lo_bits, d))) return rc;
   }
   BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
   // results to pinned host memory

@@ -11,9 +11,9 @@
 //                  W = ceil(255/c) windows, written as (digit,base) pairs, window-major.
 //   2. sort        stable LSD radix sort of every window's pairs by digit, 8 bits per pass;
 //                  ranking inside a tile uses wavefront ballots (match-any) + popcounts.
-//   3. bounds      bucket start offsets from the sorted digits; task list (buckets larger than
-//                  CHUNK entries are split so a skewed scalar distribution cannot serialise).
-//   4. accumulate  one lane per task: gather affine bases (L2 / Infinity-Cache resident: the
+//   3. chunks      the sorted stream of every window is cut into equal chunks of K entries: every
+//                  lane performs exactly K mixed additions whatever the bucket-size distribution.
+//   4. accumulate  one lane per chunk: gather affine bases (L2 / Infinity-Cache resident: the
 //                  96 MiB base table fits the 256 MiB MALL) and XYZZ mixed-add them.
 //   5. reduce      sum_d d*B_d without a serial running sum: split d = hi*2^l + lo, take row
 //                  sums over lo and column sums over hi (wave tree-reductions), then per-bit
@@ -193,62 +193,26 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
 }
 
 // ============================================================================================
-// 3. bucket bounds + tasks
+// 3. first non-zero digit position per window (zero digits sort to the front and are skipped)
 // ============================================================================================
-// start[w*(nb+1) + d] = first sorted position (within window w) whose digit is >= d; d in [0, nb]
-__global__ void bucket_bounds_kernel(const u64 *pairs, u32 *start, u32 n, u32 nb) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 w = blockIdx.y;
-  if (i > n) return;
+__global__ void window_zero_count_kernel(const u64 *pairs, u32 *zstart, u32 n, u32 W) {
+  const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
   const u64 *src = pairs + (u64)w * n;
-  const int dprev = (i == 0) ? -1 : (int)(u32)(src[i - 1] >> 32);
-  const int dcur = (i == n) ? (int)nb : (int)(u32)(src[i] >> 32);
-  u32 *st = start + (u64)w * (nb + 1);
-  for (int d = dprev + 1; d <= dcur; d++) st[d] = i;
-}
-
-__global__ void count_tasks_kernel(const u32 *start, u32 *ntasks, u32 nb, u32 W, u32 chunk) {
-  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;   // global bucket index w*nb + d
-  const u32 NB = W * nb;
-  if (b > NB) return;
-  if (b == NB) { ntasks[b] = 0; return; }
-  const u32 w = b / nb, d = b % nb;
-  const u32 *st = start + (u64)w * (nb + 1);
-  const u32 cnt = (d == 0) ? 0 : st[d + 1] - st[d];
-  ntasks[b] = (cnt + chunk - 1) / chunk;
-}
-
-__global__ void make_tasks_kernel(const u32 *start, const u32 *task_off, Task *tasks, BigBucket *big,
-                                  ErrFlags *err, u32 n, u32 nb, u32 W, u32 chunk, u32 max_big) {
-  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 NB = W * nb;
-  if (b == NB) err->total_tasks = task_off[NB];
-  if (b >= NB) return;
-  const u32 w = b / nb, d = b % nb;
-  if (d == 0) return;
-  const u32 *st = start + (u64)w * (nb + 1);
-  const u32 lo = st[d], hi = st[d + 1];
-  if (hi == lo) return;
-  const u32 t0 = task_off[b], nt = task_off[b + 1] - t0;
-  for (u32 j = 0; j < nt; j++) {
-    Task t;
-    t.begin = w * n + lo + j * chunk;
-    t.end = min(t.begin + chunk, w * n + hi);
-    t.dest = (nt == 1) ? b : NB + t0 + j;
-    tasks[t0 + j] = t;
+  u32 lo = 0, hi = n;   // first index whose digit != 0
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if ((u32)(src[mid] >> 32) == 0) lo = mid + 1; else hi = mid;
   }
-  if (nt > 1) {
-    const u32 slot = atomicAdd(&err->nbig, 1u);
-    if (slot < max_big) { BigBucket bb = {b, t0, nt}; big[slot] = bb; }
-  }
+  zstart[w] = lo;
 }
 
 static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
 
-MsmPlan make_plan(u64 n, unsigned forced_c) {
+MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   MsmPlan p;
   p.n = (u32)n;
-  int c = (int)ilog2(n ? n : 1) - 6;
+  int c = (int)ilog2(n ? n : 1) - 4;   // average bucket ~16 entries; tuned on MI355X (tools/tune_msm.py)
   if (c < 4) c = 4;
   if (c > 16) c = 16;
   if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
@@ -259,10 +223,8 @@ MsmPlan make_plan(u64 n, unsigned forced_c) {
   p.lo_bits = p.c / 2;
   p.hi_bits = p.c - p.lo_bits;
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
-  u64 avg = n >> p.c;
-  p.chunk = (u32)std::max<u64>(256, 4 * avg);
-  p.max_tasks = (u64)p.NB + ((u64)p.W * n) / p.chunk + 1;
-  p.max_big = (u32)std::min<u64>(((u64)p.W * n) / p.chunk + 1, 1u << 20);
+  p.chunk = forced_chunk ? forced_chunk : 32;
+  p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
   return p;
 }
@@ -299,19 +261,8 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
     std::swap(src, dst);
   }
   *sorted_out = src;
-  // 3. bounds + tasks
-  hipLaunchKernelGGL(bucket_bounds_kernel, dim3((p.n + 1 + 255) / 256, p.W), dim3(256), 0, st, src, b.start, p.n,
-                     p.nb);
-  BH_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(count_tasks_kernel, dim3((p.NB + 1 + 255) / 256), dim3(256), 0, st, b.start, b.task_off, p.nb,
-                     p.W, p.chunk);
-  BH_HIP_CHECK(hipGetLastError());
-  {
-    int rc = exclusive_scan_u32(b.task_off, (u64)p.NB + 1, b.scan_tmp, st);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(make_tasks_kernel, dim3((p.NB + 1 + 255) / 256), dim3(256), 0, st, b.start, b.task_off, b.tasks,
-                     b.big, b.err, p.n, p.nb, p.W, p.chunk, p.max_big);
+  // 3. where the non-zero digits start in every window
+  hipLaunchKernelGGL(window_zero_count_kernel, dim3((p.W + 63) / 64), dim3(64), 0, st, src, b.zstart, p.n, p.W);
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
@@ -319,38 +270,30 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
 
 // bring-up aid: stages 1-3 only, results copied to the host (tests/test_gpu_parity.py)
 int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
-                    u32 *start_out, u32 *total_tasks_out) {
-  const MsmPlan p = make_plan(n, cbits);
+                    u32 *zstart_out) {
+  const MsmPlan p = make_plan(n, cbits, 0);
   hipStream_t st = c.stream;
   const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
   MsmBuffers b;
-  void *sc = nullptr;
   std::vector<void *> owned;
-  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); if (q) owned.push_back(q); return q; };
-  sc = alloc(n * 32);
+  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); owned.push_back(q); return q; };
+  void *sc = alloc(n * 32);
   b.pairs_a = (u64 *)alloc(npairs * 8);
   b.pairs_b = (u64 *)alloc(npairs * 8);
   b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(std::max<u64>(ncounts, p.NB + 1)) * 4);
-  b.start = (u32 *)alloc((u64)p.W * (p.nb + 1) * 4);
-  b.task_off = (u32 *)alloc(((u64)p.NB + 1) * 4);
-  b.tasks = (Task *)alloc(p.max_tasks * sizeof(Task));
-  b.big = (BigBucket *)alloc((u64)p.max_big * sizeof(BigBucket));
+  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
+  b.zstart = (u32 *)alloc((u64)p.W * 4);
   b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
   b.word_prefix = nullptr;
   int rc = BH_OK;
   for (void *q : owned) if (!q) rc = BH_ERR_HIP;
-  if (owned.size() != 10) rc = BH_ERR_HIP;
   const u64 *sorted = nullptr;
-  ErrFlags ef;
   if (rc == BH_OK && hipMemcpyAsync(sc, scalars_host, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
   if (rc == BH_OK && hipMemsetAsync(b.err, 0, sizeof(ErrFlags), st) != hipSuccess) rc = BH_ERR_HIP;
   if (rc == BH_OK) rc = msm_run_stages(p, b, sc, fmt, nullptr, 0, n, st, &sorted);
   if (rc == BH_OK && hipMemcpyAsync(pairs_out, sorted, npairs * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemcpyAsync(start_out, b.start, (u64)p.W * (p.nb + 1) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemcpyAsync(&ef, b.err, sizeof ef, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemcpyAsync(zstart_out, b.zstart, (u64)p.W * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
   if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
-  if (rc == BH_OK && total_tasks_out) *total_tasks_out = ef.total_tasks;
   for (void *q : owned) c.pool.release(q);
   return rc;
 }

@@ -8,17 +8,8 @@ struct ErrFlags {       // device-side status word block
   u32 eof;              // a dense entry found the base cursor at/after the end (multiexp.rs:55-61,74-80)
   u32 ident;            // an identity base was consumed (multiexp.rs:63-65)
   u32 ident_top;        // ... in the reference's top window, before the first EOF entry
-  u32 nbig;             // number of split buckets
-  u32 total_tasks;
-  u32 pad[3];
-};
-
-struct Task {
-  u32 begin, end;  // [begin, end) in the sorted pair array (global, window-major)
-  u32 dest;        // slot in pts[]: bucket index, or NB + task index for a split bucket
-};
-struct BigBucket {
-  u32 bucket, first_task, ntasks;
+  u32 nlong;            // number of long bucket runs queued for the workgroup-parallel merge
+  u32 pad[4];
 };
 
 enum { SUM_STRIDED = 1, SUM_BITS = 2 };
@@ -29,12 +20,17 @@ struct SumDesc {
   u32 inner;       // groups per outer index
   u32 stride;      // element stride inside a group
   u32 group_shift; // log2 of the elements spanned by one outer index
+  u32 istride;     // STRIDED: element offset between consecutive inner indices
+  u32 lanes;       // G: lanes cooperating on one output (power of two <= 64)
+};
+struct LongRun {   // a bucket whose entries span more than MERGE_WALK chunks
+  u32 w, lane, d;
 };
 
 struct MsmPlan {
-  u32 n, c, W, nb, NB, lo_bits, hi_bits, num_tiles, chunk, sort_passes;
-  u64 max_tasks;
-  u32 max_big;
+  u32 n, c, W, nb, NB, lo_bits, hi_bits, num_tiles, sort_passes;
+  u32 chunk;             // K: sorted entries per accumulation lane
+  u32 chunks_per_window; // ceil(n / K)
 };
 
 struct MsmJobImpl {
@@ -63,14 +59,12 @@ struct MsmJobImpl {
 // msm_stages.hip: curve-independent stages (digits, sort, bounds, tasks)
 struct MsmBuffers {
   u64 *pairs_a, *pairs_b;
-  u32 *counts, *scan_tmp, *start, *task_off, *word_prefix;
-  Task *tasks;
-  BigBucket *big;
+  u32 *counts, *scan_tmp, *zstart, *word_prefix;   // zstart[w] = #entries with digit 0 in window w
   ErrFlags *err;
 };
-MsmPlan make_plan(u64 n, unsigned forced_c);
+MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk);
 size_t scan_tmp_elems(u64 n);
-// runs stages 1-3 on `st`; *sorted_out = the sorted pair array (pairs_a or pairs_b)
+// runs stages 1-2 (+ per-window first non-zero position) on `st`; *sorted_out = sorted pairs
 int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
                    u64 skip, u64 n_bases, hipStream_t st, const u64 **sorted_out);
 

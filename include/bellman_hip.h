@@ -130,6 +130,8 @@ int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4);
 void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);
 /* tuning knob for experiments: window bits c (0 = automatic) */
 int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c);
+/* tuning knob: sorted entries per accumulation lane K (0 = default) */
+int bh_msm_set_chunk(bh_ctx *ctx, unsigned k);
 
 /* ---- fixed-base scalar multiplication (fixture / CRS generation; SURVEY §8 f4,
  * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device */
@@ -142,10 +144,10 @@ int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *
 int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
 /* r[i] = a[i] + b[i] on the curve (affine in, affine out) */
 int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
-/* runs MSM stages 1-3 (digits, radix sort, bucket bounds) for window size c and copies the
- * sorted (digit<<32|base) pairs [W*n] and bucket starts [W*(2^c+1)] back (bring-up aid) */
+/* runs MSM stages 1-3 (digits, radix sort, zero-digit count) for window size c and copies the
+ * sorted (digit<<32|base) pairs [W*n] and the per-window count of zero digits [W] back (bring-up aid) */
 int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *start_out_host, uint32_t *total_tasks_out);
+                       uint64_t *pairs_out_host, uint32_t *zstart_out_host);
 /* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);

@@ -182,7 +182,7 @@ def test_h_poly_pipeline(worker, n_evals):
 # ------------------------------------------------------------------------------ MSM stages
 @pytest.mark.parametrize("n,c", [(1, 4), (100, 4), (5000, 7), (70000, 11), (1 << 17, 16)])
 def test_msm_sort_stages(worker, n, c):
-    """digits + stable radix sort + bucket bounds against numpy."""
+    """digits + stable radix sort + zero-digit count against numpy."""
     from bellman_amd import _lib
 
     lib = _lib.load()
@@ -193,21 +193,16 @@ def test_msm_sort_stages(worker, n, c):
     W = (255 + c - 1) // c
     nb = 1 << c
     pairs = np.zeros(W * n, dtype=np.uint64)
-    start = np.zeros(W * (nb + 1), dtype=np.uint32)
-    tot = ctypes.c_uint32(0)
-    assert lib.bh_test_msm_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(start), ctypes.byref(tot)) == 0
+    zstart = np.zeros(W, dtype=np.uint32)
+    assert lib.bh_test_msm_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(zstart)) == 0
     ints = np.array(cref.arr_to_ints(sc), dtype=object)
-    nonempty = 0
     for w in range(W):
         digits = np.array([(int(v) >> (c * w)) & (nb - 1) for v in ints], dtype=np.uint64)
         order = np.argsort(digits, kind="stable")
         want = (digits[order] << np.uint64(32)) | order.astype(np.uint64)
         got = pairs[w * n : (w + 1) * n]
         assert np.array_equal(got, want), (w,)
-        st = start[w * (nb + 1) : (w + 1) * (nb + 1)]
-        assert np.array_equal(st, np.searchsorted(digits[order], np.arange(nb + 1), side="left").astype(np.uint32))
-        nonempty += len(set(digits[digits != 0].tolist()))
-    assert tot.value >= nonempty
+        assert zstart[w] == int((digits == 0).sum())
 
 
 # ------------------------------------------------------------------------------ MSM
@@ -380,6 +375,25 @@ def test_msm_window_bits_do_not_change_result(worker):
         _lib.load().bh_msm_set_window_bits(worker.ctx, 0)
 
 
+def test_msm_chunk_size_does_not_change_result(worker):
+    """The accumulation chunk K only moves the boundaries of partial sums."""
+    import bellman_amd
+    from bellman_amd import _lib
+
+    n = 6000
+    bases = cref.gen_bases(1, n, a=8, b=5)
+    sc = _scalars(n, 19)
+    sc[100:400] = sc[100]  # a bucket spanning many chunks in every window
+    hb = bellman_amd.Bases(worker, 1, bases)
+    rc, want = cref.multiexp(1, bases, 0, None, sc)
+    try:
+        for k in (1, 2, 3, 7, 32, 100, 10000):
+            _lib.load().bh_msm_set_chunk(worker.ctx, k)
+            assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want), k
+    finally:
+        _lib.load().bh_msm_set_chunk(worker.ctx, 0)
+
+
 def test_msm_2_20_config_c2(worker):
     """BASELINE config C2: 2^20-base G1 MSM, bit-exact vs the restated multiexp, plus linearity."""
     import bellman_amd
@@ -391,7 +405,7 @@ def test_msm_2_20_config_c2(worker):
     got, ms = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, timed=True).wait()
     rc, want = cref.multiexp(1, bases, 0, None, sc, threads=cref.lib().orc_max_threads())
     assert rc == 0 and np.array_equal(got, want)
-    print("G1 MSM 2^20 device ms:", ms)
+    print("G1 MSM 2^20 device ms [total, sort, accumulate, reduce]:", ms)
     # linearity: MSM(s, B[:h]) + MSM(s, B[h:]) == MSM(s, B)
     h = n // 2
     lo = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc[:h]).wait()
