@@ -19,7 +19,7 @@ EXPORTS = [
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
     "bh_bases_register", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
-    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_msm_set_window_bits", "bh_msm_set_chunk",
+    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
     "bh_fixed_base_mul_dev",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host",
@@ -78,6 +78,8 @@ def load():
     lib.bh_msm_wait_profile.argtypes = [vp, vp, c.POINTER(c.c_float)]
     lib.bh_point_add.argtypes = [i32, vp, vp, vp, sz]
     lib.bh_point_add.restype = None
+    lib.bh_point_mul.argtypes = [i32, vp, vp, vp]
+    lib.bh_point_mul.restype = None
     lib.bh_msm_set_window_bits.argtypes = [vp, c.c_uint]
     lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
     lib.bh_test_fr_mul_dev.argtypes = [vp, vp, vp, vp, sz]

@@ -31,6 +31,8 @@ void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
 int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
                     u32 *zstart_out);
 void host_point_mul(int group, void *r, const void *a, const void *k);
+void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n);
+void devhdr_point_mul(int group, void *r, const void *a, const void *k);
 
 static std::atomic<unsigned> g_forced_c{0};
 
@@ -89,6 +91,12 @@ void bh_ctx_destroy(bh_ctx *ctx) {
     if (kv.second.icoset) (void)hipFree(kv.second.icoset);
   }
   ctx->c.pool.release_all();
+  for (auto &r : ctx->c.job_pool) {
+    for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
+    if (r.pinned) (void)hipHostFree(r.pinned);
+    if (r.stream) (void)hipStreamDestroy(r.stream);
+  }
+  ctx->c.job_pool.clear();
   if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }
@@ -361,7 +369,8 @@ void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
 void bh_test_fr_inv_host(void *r, const void *a, size_t n) {
   for (size_t i = 0; i < n; i++) fe_inv(((fr_t *)r)[i], ((const fr_t *)a)[i]);
 }
-void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { host_point_add(group, r, a, b, n); }
-void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { host_point_mul(group, r, a, k); }
+void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { devhdr_point_add(group, r, a, b, n); }
+void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { devhdr_point_mul(group, r, a, k); }
+void bh_point_mul(int group, void *r, const void *a, const void *k_canonical) { host_point_mul(group, r, a, k_canonical); }
 
 }  // extern "C"

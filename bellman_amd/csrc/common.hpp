@@ -71,6 +71,14 @@ class DevicePool {
   std::map<void *, size_t> live_;
 };
 
+// per-job HIP objects that are expensive to create: recycled across MSM jobs
+struct JobResources {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  void *pinned = nullptr;          // host-pinned landing buffer for the job's result
+  size_t pinned_bytes = 0;
+};
+
 struct FftTables {
   fr_t *tw = nullptr;      // omega_n^i, i < n
   fr_t *coset = nullptr;   // 7^i
@@ -85,6 +93,8 @@ struct Context {
   std::mutex fft_mu;
   std::map<uint32_t, FftTables> fft_tables;  // keyed by log_n
   int num_cus = 256;
+  std::mutex job_mu;
+  std::vector<JobResources> job_pool;
 };
 
 }  // namespace bh

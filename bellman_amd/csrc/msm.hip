@@ -36,27 +36,38 @@ __global__ void fe_mul_kernel(Fe<P> *r, const Fe<P> *a, const Fe<P> *b, u64 n) {
 }
 
 // ---- job management / dispatch (used by api.hip) ------------------------------------------------
+constexpr size_t JOB_PINNED_BYTES = 256 * 1024;   // >= W*c*sizeof(XYZZ<Fp2>) + flags for every plan
+
 MsmJobImpl *msm_job_new(Context *ctx, int group) {
   MsmJobImpl *j = new MsmJobImpl();
   j->ctx = ctx;
   j->group = group;
-  if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&j->ev_begin) != hipSuccess || hipEventCreate(&j->ev_end) != hipSuccess ||
-      hipEventCreate(&j->ev_sorted) != hipSuccess || hipEventCreate(&j->ev_accum) != hipSuccess) {
-    delete j;
-    return nullptr;
+  {
+    std::lock_guard<std::mutex> g(ctx->job_mu);
+    if (!ctx->job_pool.empty()) {
+      j->res = ctx->job_pool.back();
+      ctx->job_pool.pop_back();
+    }
   }
+  if (!j->res.stream) {
+    bool ok = hipStreamCreateWithFlags(&j->res.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&j->res.ev[i]) == hipSuccess;
+    if (ok) ok = hipHostMalloc(&j->res.pinned, JOB_PINNED_BYTES, hipHostMallocDefault) == hipSuccess;
+    j->res.pinned_bytes = JOB_PINNED_BYTES;
+    if (!ok) { delete j; return nullptr; }
+  }
+  j->stream = j->res.stream;
+  j->ev_begin = j->res.ev[0]; j->ev_sorted = j->res.ev[1]; j->ev_accum = j->res.ev[2]; j->ev_end = j->res.ev[3];
+  j->host_result = j->res.pinned;
   return j;
 }
 void msm_job_delete(MsmJobImpl *j) {
   if (!j) return;
   for (void *ptr : j->dev_allocs) j->ctx->pool.release(ptr);
-  if (j->host_result) (void)hipHostFree(j->host_result);
-  if (j->ev_begin) (void)hipEventDestroy(j->ev_begin);
-  if (j->ev_end) (void)hipEventDestroy(j->ev_end);
-  if (j->ev_sorted) (void)hipEventDestroy(j->ev_sorted);
-  if (j->ev_accum) (void)hipEventDestroy(j->ev_accum);
-  if (j->stream) (void)hipStreamDestroy(j->stream);
+  {
+    std::lock_guard<std::mutex> g(j->ctx->job_mu);
+    j->ctx->job_pool.push_back(j->res);
+  }
   delete j;
 }
 hipStream_t msm_job_stream(MsmJobImpl &job) { return job.stream; }
@@ -103,6 +114,12 @@ void host_point_add(int group, void *r, const void *a, const void *b, u64 n) {
 }
 void host_point_mul(int group, void *r, const void *a, const void *k) {
   if (group == BH_G1) host_point_mul_g1(r, a, k); else host_point_mul_g2(r, a, k);
+}
+void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n) {
+  if (group == BH_G1) devhdr_point_add_g1(r, a, b, n); else devhdr_point_add_g2(r, a, b, n);
+}
+void devhdr_point_mul(int group, void *r, const void *a, const void *k) {
+  if (group == BH_G1) devhdr_point_mul_g1(r, a, k); else devhdr_point_mul_g2(r, a, k);
 }
 
 }  // namespace bh

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "host_fp.hpp"
 #include "msm_scalar.cuh"
 #include "msm_types.hpp"
 
@@ -209,9 +210,23 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
 //   SUM_STRIDED: g = (outer, inner): elements in[(outer << group_shift) + inner*istride + t*stride], t < count
 //   SUM_BITS   : g = (outer, k):     elements in[(outer << group_shift) + i], i < count, bit k of i set
 template <class F>
-__global__ __launch_bounds__(64) void msm_sum_kernel(const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) {
+struct SumJob {
+  const XYZZ<F> *in;
+  XYZZ<F> *out;
+  SumDesc d;
+  u32 nblocks;   // 64-lane blocks assigned to this job
+};
+// two independent reductions per launch (rows + columns, then both bit-sum sets): they are
+// latency-bound, so sharing a launch lets the hardware overlap them.
+template <class F>
+__global__ __launch_bounds__(64) void msm_sum_kernel(SumJob<F> j0, SumJob<F> j1) {
+  const bool second = blockIdx.x >= j0.nblocks;
+  const SumDesc d = second ? j1.d : j0.d;
+  const XYZZ<F> *in = second ? j1.in : j0.in;
+  XYZZ<F> *out = second ? j1.out : j0.out;
+  const u32 blk = second ? blockIdx.x - j0.nblocks : blockIdx.x;
   const u32 G = d.lanes;
-  const u32 g = (blockIdx.x * 64 + threadIdx.x) / G;
+  const u32 g = (blk * 64 + threadIdx.x) / G;
   const u32 sub = threadIdx.x & (G - 1);
   XYZZ<F> acc;
   xyzz_set_identity(acc);
@@ -351,54 +366,62 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     while (g > 1 && g > count) g >>= 1;
     return g;
   };
-  auto launch_sum = [&](const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) -> int {
-    d.lanes = pick_lanes(d.groups, d.mode == SUM_BITS ? d.count / 2 : d.count);
-    const u64 lanes = (u64)d.groups * d.lanes;
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3((u32)((lanes + 63) / 64)), dim3(64), 0, st, in, out, d);
-    BH_HIP_CHECK(hipGetLastError());
-    return BH_OK;
+  auto make_job = [&](const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) {
+    SumJob<F> j;
+    d.lanes = d.groups ? pick_lanes(d.groups, d.mode == SUM_BITS ? std::max(1u, d.count / 2) : d.count) : 1;
+    j.in = in; j.out = out; j.d = d;
+    j.nblocks = (u32)(((u64)d.groups * d.lanes + 63) / 64);
+    return j;
   };
   {
-    SumDesc d;
-    int rc;
-    d.mode = SUM_STRIDED; d.groups = p.W * H; d.count = Lw; d.inner = H; d.stride = 1; d.istride = Lw; d.group_shift = p.c;
-    if ((rc = launch_sum(pts, rows, d))) return rc;
-    d.groups = p.W * Lw; d.count = H; d.inner = Lw; d.stride = Lw; d.istride = 1;
-    if ((rc = launch_sum(pts, cols, d))) return rc;
+    SumDesc dr, dc;
+    dr.mode = SUM_STRIDED; dr.groups = p.W * H; dr.count = Lw; dr.inner = H; dr.stride = 1; dr.istride = Lw; dr.group_shift = p.c;
+    dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
+    SumJob<F> j0 = make_job(pts, rows, dr), j1 = make_job(pts, cols, dc);
+    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(j0.nblocks + j1.nblocks), dim3(64), 0, st, j0, j1);
+    BH_HIP_CHECK(hipGetLastError());
     // U[w][p]: p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi)
-    d.mode = SUM_BITS; d.stride = 1; d.istride = 0;
-    d.groups = p.W * p.lo_bits; d.count = Lw; d.inner = p.lo_bits; d.group_shift = p.lo_bits;
-    if (d.groups && (rc = launch_sum(cols, bits, d))) return rc;
-    d.groups = p.W * p.hi_bits; d.count = H; d.inner = p.hi_bits; d.group_shift = p.hi_bits;
-    if ((rc = launch_sum(rows, bits + (u64)p.W * p.lo_bits, d))) return rc;
+    SumDesc bl, bh_;
+    bl.mode = SUM_BITS; bl.stride = 1; bl.istride = 0;
+    bl.groups = p.W * p.lo_bits; bl.count = Lw; bl.inner = std::max(1u, p.lo_bits); bl.group_shift = p.lo_bits;
+    bh_ = bl; bh_.groups = p.W * p.hi_bits; bh_.count = H; bh_.inner = p.hi_bits; bh_.group_shift = p.hi_bits;
+    j0 = make_job(cols, bits, bl); j1 = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
+    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(j0.nblocks + j1.nblocks), dim3(64), 0, st, j0, j1);
+    BH_HIP_CHECK(hipGetLastError());
   }
   BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
   // results to pinned host memory
   const size_t bits_bytes = (size_t)p.W * p.c * sizeof(XYZZ<F>);
   job.host_result_bytes = bits_bytes + sizeof(ErrFlags);
-  BH_HIP_CHECK(hipHostMalloc(&job.host_result, job.host_result_bytes, hipHostMallocDefault));
+  if (job.host_result_bytes > job.res.pinned_bytes) return BH_ERR_INVALID_ARG;
   BH_HIP_CHECK(hipMemcpyAsync(job.host_result, bits, bits_bytes, hipMemcpyDeviceToHost, st));
   BH_HIP_CHECK(hipMemcpyAsync((char *)job.host_result + bits_bytes, err, sizeof(ErrFlags), hipMemcpyDeviceToHost, st));
   return BH_OK;
 }
 
+template <> struct HostOf<FpOps> { typedef HostFpOps type; };
+template <> struct HostOf<Fp2Ops> { typedef HostFp2Ops type; };
+
 // host tail: result = sum_w sum_p 2^(c*w + p) U[w][p]
 //   bits layout: [W][lo_bits] column-bit sums, then [W][hi_bits] row-bit sums
 template <class F>
-static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits, Affine<F> *out) {
-  XYZZ<F> acc;
+static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, Affine<F> *out_dev_layout) {
+  typedef typename HostOf<F>::type H;   // 64-bit-limb host arithmetic, identical record layout
+  static_assert(sizeof(XYZZ<H>) == sizeof(XYZZ<F>) && sizeof(Affine<H>) == sizeof(Affine<F>), "layout");
+  const XYZZ<H> *bits = reinterpret_cast<const XYZZ<H> *>(bits_dev_layout);
+  XYZZ<H> acc;
   xyzz_set_identity(acc);
-  const XYZZ<F> *lo = bits, *hi = bits + (size_t)p.W * p.lo_bits;
+  const XYZZ<H> *lo = bits, *hi = bits + (size_t)p.W * p.lo_bits;
   for (int w = (int)p.W - 1; w >= 0; w--) {
     for (int b = (int)p.c - 1; b >= 0; b--) {
-      XYZZ<F> t;
+      XYZZ<H> t;
       xyzz_dbl(t, acc);
-      const XYZZ<F> &u = (b >= (int)p.lo_bits) ? hi[(size_t)w * p.hi_bits + (b - p.lo_bits)]
+      const XYZZ<H> &u = (b >= (int)p.lo_bits) ? hi[(size_t)w * p.hi_bits + (b - p.lo_bits)]
                                                : lo[(size_t)w * p.lo_bits + b];
       xyzz_add(acc, t, u);
     }
   }
-  xyzz_to_affine(*out, acc);
+  xyzz_to_affine(*reinterpret_cast<Affine<H> *>(out_dev_layout), acc);
 }
 
 template <class F>
@@ -444,8 +467,6 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   }
   for (void *ptr : job.dev_allocs) c.pool.release(ptr);
   job.dev_allocs.clear();
-  if (job.host_result) (void)hipHostFree(job.host_result);
-  job.host_result = nullptr;
   return rc;
 }
 
@@ -471,8 +492,36 @@ static int test_point_add_t(void *r, const void *a, const void *b, u64 n, hipStr
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
-template <class F>
+template <class FD>
 static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
+  typedef typename HostOf<FD>::type F;
+  for (u64 i = 0; i < n; i++) {
+    XYZZ<F> x, y, z;
+    xyzz_from_affine(x, ((const Affine<F> *)a)[i]);
+    xyzz_from_affine(y, ((const Affine<F> *)b)[i]);
+    xyzz_add(z, x, y);
+    xyzz_to_affine(((Affine<F> *)r)[i], z);
+  }
+}
+template <class FD>
+static void host_point_mul_t(void *r, const void *a, const u32 *k) {
+  typedef typename HostOf<FD>::type F;
+  XYZZ<F> acc;
+  xyzz_set_identity(acc);
+  const Affine<F> &base = *(const Affine<F> *)a;
+  for (int b = 255; b >= 0; b--) {
+    XYZZ<F> t;
+    xyzz_dbl(t, acc);
+    acc = t;
+    if (((k[b >> 5] >> (b & 31)) & 1) && !aff_is_identity(base)) xyzz_madd(acc, base);
+  }
+  xyzz_to_affine(*(Affine<F> *)r, acc);
+}
+
+// the same two helpers on the DEVICE headers compiled for the host (32-bit limbs): CPU-side unit
+// tests of ff.cuh / ec.cuh exactly as the kernels use them
+template <class F>
+static void devhdr_point_add_t(void *r, const void *a, const void *b, u64 n) {
   for (u64 i = 0; i < n; i++) {
     XYZZ<F> x, y, z;
     xyzz_from_affine(x, ((const Affine<F> *)a)[i]);
@@ -482,7 +531,7 @@ static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
   }
 }
 template <class F>
-static void host_point_mul_t(void *r, const void *a, const u32 *k) {
+static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) {
   XYZZ<F> acc;
   xyzz_set_identity(acc);
   const Affine<F> &base = *(const Affine<F> *)a;
@@ -515,6 +564,12 @@ static void host_point_mul_t(void *r, const void *a, const u32 *k) {
   }                                                                                                           \
   void host_point_mul_##SUFFIX(void *r, const void *a, const void *k) {                                       \
     host_point_mul_t<OPS>(r, a, (const u32 *)k);                                                              \
+  }                                                                                                           \
+  void devhdr_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n) {                              \
+    devhdr_point_add_t<OPS>(r, a, b, n);                                                                      \
+  }                                                                                                           \
+  void devhdr_point_mul_##SUFFIX(void *r, const void *a, const void *k) {                                     \
+    devhdr_point_mul_t<OPS>(r, a, (const u32 *)k);                                                            \
   }
 
 }  // namespace bh

@@ -41,8 +41,9 @@ struct MsmJobImpl {
   hipEvent_t ev_sorted = nullptr, ev_accum = nullptr;   // stage boundaries (profiling)
   MsmPlan plan;
   std::vector<void *> dev_allocs;     // returned to the pool on wait
-  void *host_result = nullptr;        // pinned: W*c XYZZ + ErrFlags
+  void *host_result = nullptr;        // pinned (owned by `res`): W*c XYZZ + ErrFlags
   size_t host_result_bytes = 0;
+  JobResources res;
   int early_rc = BH_OK;               // immediate result (n == 0 etc.)
   bool trivial = false;
   // inputs needed again by the (rare) error-resolution pass
@@ -83,5 +84,9 @@ void host_point_add_g1(void *r, const void *a, const void *b, u64 n);
 void host_point_add_g2(void *r, const void *a, const void *b, u64 n);
 void host_point_mul_g1(void *r, const void *a, const void *k);
 void host_point_mul_g2(void *r, const void *a, const void *k);
+void devhdr_point_add_g1(void *r, const void *a, const void *b, u64 n);
+void devhdr_point_add_g2(void *r, const void *a, const void *b, u64 n);
+void devhdr_point_mul_g1(void *r, const void *a, const void *k);
+void devhdr_point_mul_g2(void *r, const void *a, const void *k);
 
 }  // namespace bh

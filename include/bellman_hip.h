@@ -128,6 +128,9 @@ int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4);
 /* r[i] = a[i] + b[i] for affine records on the HOST - used to fold the per-GPU partial results of
  * a base-sharded MSM after the all-gather, and g_a/g_b/g_c in create_proof. */
 void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);
+/* r = [k] a on the HOST, k = 32-byte canonical little-endian scalar: the five single scalar
+ * multiplications of create_proof (groth16/src/prover.rs:326-338, 342, 351) */
+void bh_point_mul(int group, void *r, const void *a, const void *k_canonical);
 /* tuning knob for experiments: window bits c (0 = automatic) */
 int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c);
 /* tuning knob: sorted entries per accumulation lane K (0 = default) */

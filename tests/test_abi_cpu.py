@@ -111,3 +111,24 @@ def test_host_fr_inverse_matches_oracle(lib):
     for i in range(20):
         cref.lib().orc_fr_inv(_p(want[i : i + 1]), _p(np.ascontiguousarray(a[i : i + 1])))
     assert np.array_equal(r, want)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_fast_host_group_ops_match_oracle(lib, group):
+    """bh_point_add / bh_point_mul: the 64-bit-limb host arithmetic used for serial tails."""
+    n = 8
+    w = 12 if group == 1 else 24
+    A = cref.gen_bases(group, n, a=15, b=4)
+    B = cref.gen_bases(group, n, a=2, b=9)
+    B[0] = A[0]
+    B[1] = 0
+    A[2] = 0
+    B[3] = cref.point_mul(group, A[3], bls.Q - 1)
+    out = np.zeros((n, w), dtype=np.uint64)
+    lib.bh_point_add(group, _p(out), _p(A), _p(B), n)
+    assert np.array_equal(out, np.stack([cref.point_add(group, A[i], B[i]) for i in range(n)]))
+    for k in (0, 1, 5, bls.Q - 1, random.Random(8).randrange(bls.Q)):
+        ka = np.array(cref.int_to_limbs(k, 4), dtype=np.uint64)
+        o = np.zeros(w, dtype=np.uint64)
+        lib.bh_point_mul(group, _p(o), _p(A[5]), _p(ka))
+        assert np.array_equal(o, cref.point_mul(group, A[5], k))
