@@ -1,0 +1,46 @@
+"""Base-sharded MSM across the GPUs of one node.
+
+sum_i s_i*P_i is a sum of independent terms: rank r runs the full single-GPU Pippenger on its
+contiguous shard and produces ONE group element; the partial results (96 B for G1, 192 B for G2)
+are exchanged with one all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) and folded
+locally on every rank with the library's host group law - RCCL has no user-defined reduction op,
+so a literal reduce cannot add curve points.  The exchange is a few hundred bytes: latency-bound.
+"""
+
+import numpy as np
+
+from .multiexp import point_add
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous split of n terms over `world` ranks (first ranks take the remainder)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def fold_partials(partial, group, device=None, process_group=None):
+    """all-gather every rank's partial affine record and add them up (same result on all ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(process_group)
+    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=process_group)
+    total = parts[0].cpu().numpy().view(np.uint64)
+    for p in parts[1:]:
+        total = point_add(group, total, p.cpu().numpy().view(np.uint64))
+    return total
+
+
+def sharded_multiexp(worker, bases_shard, density_map, scalars_shard, group, device=None, process_group=None,
+                     **kw):
+    """multiexp over this rank's shard, then the fold.  `bases_shard`/`scalars_shard` are the
+    rank-local pieces (see shard_bounds)."""
+    from .multiexp import multiexp
+
+    part = multiexp(worker, bases_shard, density_map, scalars_shard, **kw).wait()
+    return fold_partials(part, group, device=device, process_group=process_group)
