@@ -21,6 +21,7 @@ EXPORTS = [
     "bh_bases_register", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
     "bh_fixed_base_mul_dev",
+    "bh_groth16_params_create", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host",
 ]
@@ -82,6 +83,11 @@ def load():
     lib.bh_point_mul.restype = None
     lib.bh_msm_set_window_bits.argtypes = [vp, c.c_uint]
     lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
+    lib.bh_groth16_params_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, c.POINTER(vp)]
+    lib.bh_groth16_params_release.argtypes = [vp]
+    lib.bh_groth16_params_release.restype = None
+    lib.bh_groth16_prove_assignment.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    lib.bh_groth16_prove_demo.argtypes = [vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.bh_test_fr_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]

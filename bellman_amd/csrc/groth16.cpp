@@ -1,0 +1,504 @@
+// Host side of groth16::create_proof over the C ABI (see groth16.hpp for the reference map).
+#include "groth16.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
+#include <memory>
+
+#define BH_TRACE(...) do { if (getenv("BH_DEBUG")) { fprintf(stderr, "[groth16] " __VA_ARGS__); fputc(10, stderr); fflush(stderr); } } while (0)
+
+namespace bellman {
+namespace {
+typedef unsigned __int128 u128;
+const uint64_t FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+const uint64_t FR_INV = 0xfffffffeffffffffULL;
+const uint64_t FR_R[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
+const uint64_t FR_R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+
+inline bool geq_mod(const uint64_t *a) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > FR_MOD[i]) return true;
+    if (a[i] < FR_MOD[i]) return false;
+  }
+  return true;
+}
+inline void sub_mod(uint64_t *a) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - FR_MOD[i] - (uint64_t)br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a[j] * b[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * FR_INV;
+    c = ((u128)m * FR_MOD[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * FR_MOD[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  if (t[4] || geq_mod(t)) sub_mod(t);
+  memcpy(r, t, 4 * sizeof(uint64_t));
+}
+}  // namespace
+
+Fr Fr::zero() { Fr r; memset(r.l, 0, sizeof r.l); return r; }
+Fr Fr::one() { Fr r; memcpy(r.l, FR_R, sizeof FR_R); return r; }
+Fr Fr::from_u64(uint64_t v) {
+  uint64_t c[4] = {v, 0, 0, 0};
+  Fr r;
+  mont_mul(r.l, c, FR_R2);
+  return r;
+}
+Fr Fr::operator+(const Fr &o) const {
+  Fr r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)l[i] + o.l[i];
+    r.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if (geq_mod(r.l)) sub_mod(r.l);
+  return r;
+}
+Fr Fr::operator-(const Fr &o) const {
+  Fr r;
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)l[i] - o.l[i] - (uint64_t)br;
+    r.l[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)r.l[i] + FR_MOD[i];
+      r.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+Fr Fr::operator*(const Fr &o) const { Fr r; mont_mul(r.l, l, o.l); return r; }
+Fr Fr::neg() const { return Fr::zero() - *this; }
+void Fr::to_canonical(uint64_t out[4]) const {
+  const uint64_t one[4] = {1, 0, 0, 0};
+  mont_mul(out, l, one);
+}
+}  // namespace bellman
+
+namespace groth16 {
+using namespace bellman;
+
+bool G1Affine::is_identity() const { uint64_t o = 0; for (uint64_t x : v) o |= x; return o == 0; }
+bool G2Affine::is_identity() const { uint64_t o = 0; for (uint64_t x : v) o |= x; return o == 0; }
+
+static void check(int rc) {
+  switch (rc) {
+    case BH_OK: return;
+    case BH_ERR_UNEXPECTED_IDENTITY: throw SynthesisError(rc, "UnexpectedIdentity");
+    case BH_ERR_UNEXPECTED_EOF: throw SynthesisError(rc, "IoError(UnexpectedEof): expected more bases from source");
+    case BH_ERR_DEGREE_TOO_LARGE: throw SynthesisError(rc, "PolynomialDegreeTooLarge");
+    default: throw std::runtime_error("bellman_hip: HIP/runtime failure (no CPU fallback)");
+  }
+}
+
+Parameters::Parameters(bh_ctx *c, const VerifyingKey &k, const G1Affine *hq, size_t nh, const G1Affine *lq, size_t nl,
+                       const G1Affine *aq, size_t na, const G1Affine *b1, size_t nb1, const G2Affine *b2, size_t nb2)
+    : ctx(c), vk(k) {
+  check(bh_bases_register(ctx, BH_G1, hq, nh, 96, -1, &h));
+  check(bh_bases_register(ctx, BH_G1, lq, nl, 96, -1, &l));
+  check(bh_bases_register(ctx, BH_G1, aq, na, 96, -1, &a));
+  check(bh_bases_register(ctx, BH_G1, b1, nb1, 96, -1, &b_g1));
+  check(bh_bases_register(ctx, BH_G2, b2, nb2, 192, -1, &b_g2));
+}
+Parameters::~Parameters() {
+  bh_bases_release(ctx, h); bh_bases_release(ctx, l); bh_bases_release(ctx, a);
+  bh_bases_release(ctx, b_g1); bh_bases_release(ctx, b_g2);
+}
+
+// ---- prover.rs:19-55 ------------------------------------------------------------------------------
+static Fr eval(const LinearCombination &lc, DensityTracker *input_density, DensityTracker *aux_density,
+               const std::vector<Fr> &input_assignment, const std::vector<Fr> &aux_assignment) {
+  Fr acc = Fr::zero();
+  const Fr one = Fr::one();
+  for (const auto &term : lc.as_ref()) {
+    const Variable &var = term.first;
+    const Fr &coeff = term.second;
+    if (coeff.is_zero()) continue;          // zero coefficients count for neither value nor density (:31)
+    Fr tmp;
+    if (var.kind == Index::Input) {
+      tmp = input_assignment[var.idx];
+      if (input_density) input_density->inc(var.idx);
+    } else {
+      tmp = aux_assignment[var.idx];
+      if (aux_density) aux_density->inc(var.idx);
+    }
+    if (coeff != one) tmp = tmp * coeff;
+    acc = acc + tmp;
+  }
+  return acc;
+}
+
+// ---- prover.rs:73-162 -----------------------------------------------------------------------------
+Variable ProvingAssignment::alloc(const std::function<Fr()> &f) {
+  aux_assignment.push_back(f());
+  a_aux_density.add_element();
+  b_aux_density.add_element();
+  return Variable::new_unchecked(Index::Aux, aux_assignment.size() - 1);
+}
+Variable ProvingAssignment::alloc_input(const std::function<Fr()> &f) {
+  input_assignment.push_back(f());
+  b_input_density.add_element();
+  return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
+}
+void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) {
+  const LinearCombination la = fa(LinearCombination::zero()), lb = fb(LinearCombination::zero()),
+                          lc = fc(LinearCombination::zero());
+  // inputs have full density in the A query; there is no C query (prover.rs:119-141)
+  a.push_back(eval(la, nullptr, &a_aux_density, input_assignment, aux_assignment));
+  b.push_back(eval(lb, &b_input_density, &b_aux_density, input_assignment, aux_assignment));
+  c.push_back(eval(lc, nullptr, nullptr, input_assignment, aux_assignment));
+}
+
+namespace {
+struct DevBuf {
+  bh_ctx *ctx;
+  void *p = nullptr;
+  DevBuf(bh_ctx *c, size_t bytes) : ctx(c) { check(bh_dev_alloc(ctx, bytes, &p)); }
+  ~DevBuf() { if (p) bh_dev_free(ctx, p); }
+  DevBuf(const DevBuf &) = delete;
+};
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+template <class A> A add_pts(int group, const A &x, const A &y) { A r; bh_point_add(group, &r, &x, &y, 1); return r; }
+template <class A> A mul_pt(int group, const A &x, const Fr &k) {
+  uint64_t kc[4];
+  k.to_canonical(kc);
+  A r;
+  bh_point_mul(group, &r, &x, kc);
+  return r;
+}
+}  // namespace
+
+// ---- prover.rs:217-360 ----------------------------------------------------------------------------
+Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  bh_ctx *ctx = params.ctx;
+  const double t0 = now_ms();
+  const VerifyingKey &vk = params.vk;
+  const size_t n_cons = prover.a.size();
+  // EvaluationDomain::from_coeffs (domain.rs:47-79)
+  uint32_t log_m = 0;
+  size_t m = 1;
+  while (m < n_cons) {
+    m *= 2;
+    log_m++;
+    if (log_m >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
+  }
+  // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
+  // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
+  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
+  {
+    std::vector<Fr> pad(m, Fr::zero());
+    const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
+    void *dst[3] = {da.p, db.p, dc.p};
+    for (int i = 0; i < 3; i++) {
+      memcpy(pad.data(), src[i]->data(), n_cons * sizeof(Fr));
+      check(bh_dev_upload(ctx, dst[i], pad.data(), m * 32));
+    }
+  }
+  BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);
+  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, nullptr));
+  BH_TRACE("h poly done");
+  const double t1 = now_ms();
+  bh_msm_job *h_job = nullptr;
+  check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244
+
+  BH_TRACE("h msm issued");
+  // assignments: uploaded once, shared by seven multiexps (prover.rs:248-318)
+  const size_t n_in = prover.input_assignment.size(), n_aux = prover.aux_assignment.size();
+  DevBuf d_in(ctx, n_in * 32 + 32), d_aux(ctx, n_aux * 32 + 32);
+  check(bh_dev_upload(ctx, d_in.p, prover.input_assignment.data(), n_in * 32));
+  if (n_aux) check(bh_dev_upload(ctx, d_aux.p, prover.aux_assignment.data(), n_aux * 32));
+  auto upload_density = [&](const DensityTracker &d) {
+    const size_t nw = (d.get_query_size() + 63) / 64;
+    std::unique_ptr<DevBuf> buf(new DevBuf(ctx, nw * 8 + 8));
+    if (nw) check(bh_dev_upload(ctx, buf->p, d.words(), nw * 8));
+    return buf;
+  };
+  auto dens_a_aux = upload_density(prover.a_aux_density);
+  auto dens_b_in = upload_density(prover.b_input_density);
+  auto dens_b_aux = upload_density(prover.b_aux_density);
+
+  bh_msm_job *l_job, *a_in_job, *a_aux_job, *b1_in_job, *b1_aux_job, *b2_in_job, *b2_aux_job;
+  check(bh_msm_async_dev(ctx, params.l, 0, d_aux.p, n_aux, BH_SCALARS_MONT, nullptr, 0, &l_job));
+  // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
+  check(bh_msm_async_dev(ctx, params.a, 0, d_in.p, n_in, BH_SCALARS_MONT, nullptr, 0, &a_in_job));
+  check(bh_msm_async_dev(ctx, params.a, n_in, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_a_aux->p, n_aux,
+                         &a_aux_job));
+  const size_t b_in_total = prover.b_input_density.get_total_density();
+  // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
+  check(bh_msm_async_dev(ctx, params.b_g1, 0, d_in.p, n_in, BH_SCALARS_MONT, (const uint64_t *)dens_b_in->p, n_in, &b1_in_job));
+  check(bh_msm_async_dev(ctx, params.b_g1, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_b_aux->p, n_aux,
+                         &b1_aux_job));
+  check(bh_msm_async_dev(ctx, params.b_g2, 0, d_in.p, n_in, BH_SCALARS_MONT, (const uint64_t *)dens_b_in->p, n_in, &b2_in_job));
+  check(bh_msm_async_dev(ctx, params.b_g2, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_b_aux->p, n_aux,
+                         &b2_aux_job));
+
+  BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
+  // every job must be waited on (it owns device resources), even when an earlier one fails
+  int rcs[8];
+  G1Affine h_res, l_res, a_in, a_aux, b1_in, b1_aux;
+  G2Affine b2_in, b2_aux;
+  // prover.rs:339-354 waits in this order: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
+  rcs[0] = bh_msm_wait(a_in_job, &a_in);
+  rcs[1] = bh_msm_wait(a_aux_job, &a_aux);
+  rcs[2] = bh_msm_wait(b1_in_job, &b1_in);
+  rcs[3] = bh_msm_wait(b1_aux_job, &b1_aux);
+  rcs[4] = bh_msm_wait(b2_in_job, &b2_in);
+  rcs[5] = bh_msm_wait(b2_aux_job, &b2_aux);
+  rcs[6] = bh_msm_wait(h_job, &h_res);
+  rcs[7] = bh_msm_wait(l_job, &l_res);
+  const double t2 = now_ms();
+  BH_TRACE("waits done rc=%d %d %d %d %d %d %d %d", rcs[0], rcs[1], rcs[2], rcs[3], rcs[4], rcs[5], rcs[6], rcs[7]);
+
+  if (vk.delta_g1.is_identity() || vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
+  for (int i = 0; i < 8; i++) check(rcs[i]);                      // first failing `?` in wait order
+
+  G1Affine g_a = add_pts(BH_G1, mul_pt(BH_G1, vk.delta_g1, r), vk.alpha_g1);   // :326-327
+  G2Affine g_b = add_pts(BH_G2, mul_pt(BH_G2, vk.delta_g2, s), vk.beta_g2);    // :328-329
+  const Fr rs = r * s;
+  G1Affine g_c = mul_pt(BH_G1, vk.delta_g1, rs);                                // :331-338
+  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.alpha_g1, s));
+  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.beta_g1, r));
+  G1Affine a_answer = add_pts(BH_G1, a_in, a_aux);                              // :339-343
+  g_a = add_pts(BH_G1, g_a, a_answer);
+  a_answer = mul_pt(BH_G1, a_answer, s);
+  g_c = add_pts(BH_G1, g_c, a_answer);
+  G1Affine b1_answer = add_pts(BH_G1, b1_in, b1_aux);                           // :345-354
+  G2Affine b2_answer = add_pts(BH_G2, b2_in, b2_aux);
+  g_b = add_pts(BH_G2, g_b, b2_answer);
+  b1_answer = mul_pt(BH_G1, b1_answer, r);
+  g_c = add_pts(BH_G1, g_c, b1_answer);
+  g_c = add_pts(BH_G1, g_c, h_res);
+  g_c = add_pts(BH_G1, g_c, l_res);
+  if (tm) {
+    tm->h_poly_ms = (float)(t1 - t0);
+    tm->msm_ms = (float)(t2 - t1);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+  return Proof{g_a, g_b, g_c};
+}
+
+// ---- prover.rs:182-215 ----------------------------------------------------------------------------
+Proof create_proof(Circuit &circuit, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  ProvingAssignment prover;
+  prover.alloc_input([] { return Fr::one(); });
+  circuit.synthesize(prover);
+  for (size_t i = 0; i < prover.input_assignment.size(); i++) {
+    prover.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+                   [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+  }
+  const double t1 = now_ms();
+  BH_TRACE("synthesised: %zu constraints", prover.a.size());
+  ProveTimings local;
+  Proof p = prove_assignment(prover, params, r, s, &local);
+  if (tm) {
+    *tm = local;
+    tm->synthesis_ms = (float)(t1 - t0);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// demo circuits, written against the mirror exactly like bellman user code
+// ---------------------------------------------------------------------------------------------------
+// MiMCDemo: /root/reference/groth16/tests/common/mod.rs:37-129 (LongsightF322p3)
+class MiMCDemo : public Circuit {
+ public:
+  Fr xl, xr;
+  const Fr *constants;
+  size_t rounds;
+  void synthesize(ConstraintSystem &cs) override {
+    Fr xl_value = xl, xr_value = xr;
+    Variable xlv = cs.alloc([&] { return xl_value; });
+    Variable xrv = cs.alloc([&] { return xr_value; });
+    for (size_t i = 0; i < rounds; i++) {
+      const Fr ci = constants[i];
+      const Fr t0 = xl_value + ci;
+      const Fr tmp_value = t0 * t0;
+      Variable tmp = cs.alloc([&] { return tmp_value; });
+      cs.enforce([&](LinearCombination lc) { return lc + xlv + std::make_pair(ci, ConstraintSystem::one()); },
+                 [&](LinearCombination lc) { return lc + xlv + std::make_pair(ci, ConstraintSystem::one()); },
+                 [&](LinearCombination lc) { return lc + tmp; });
+      const Fr new_xl_value = t0 * tmp_value + xr_value;
+      Variable new_xl = (i == rounds - 1) ? cs.alloc_input([&] { return new_xl_value; })
+                                          : cs.alloc([&] { return new_xl_value; });
+      cs.enforce([&](LinearCombination lc) { return lc + tmp; },
+                 [&](LinearCombination lc) { return lc + xlv + std::make_pair(ci, ConstraintSystem::one()); },
+                 [&](LinearCombination lc) { return lc + new_xl - xrv; });
+      xrv = xlv; xr_value = xl_value;
+      xlv = new_xl; xl_value = new_xl_value;
+    }
+  }
+};
+
+// Synthetic multiplicative chain: M rounds
+//   even i: (x_i + k_i) * (x_i + k'_i) = x_{i+1}       (x_i in the A and B queries)
+//   odd  i: (x_i + k_i + 0*x_0) * (k'_i)  = x_{i+1}    (x_i only in A; a zero-coefficient term, prover.rs:31)
+// and finally x_M * 1 = out (public input).  Constants from SplitMix64(seed).
+class ChainCircuit : public Circuit {
+ public:
+  uint64_t seed;
+  size_t rounds;
+  Fr x0;
+  static uint64_t splitmix(uint64_t &st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  }
+  void synthesize(ConstraintSystem &cs) override {
+    uint64_t st = seed;
+    Fr x_value = x0;
+    Variable x = cs.alloc([&] { return x_value; });
+    const Variable first = x;
+    for (size_t i = 0; i < rounds; i++) {
+      const Fr k = Fr::from_u64(splitmix(st)), k2 = Fr::from_u64(splitmix(st) | 1);
+      const Fr lhs = x_value + k;
+      const Fr rhs = (i & 1) ? k2 : (x_value + k2);
+      const Fr next_value = lhs * rhs;
+      Variable next = cs.alloc([&] { return next_value; });
+      if (i & 1) {
+        cs.enforce([&](LinearCombination lc) { return lc + x + std::make_pair(k, ConstraintSystem::one()) + std::make_pair(Fr::zero(), first); },
+                   [&](LinearCombination lc) { return lc + std::make_pair(k2, ConstraintSystem::one()); },
+                   [&](LinearCombination lc) { return lc + next; });
+      } else {
+        cs.enforce([&](LinearCombination lc) { return lc + x + std::make_pair(k, ConstraintSystem::one()); },
+                   [&](LinearCombination lc) { return lc + x + std::make_pair(k2, ConstraintSystem::one()); },
+                   [&](LinearCombination lc) { return lc + next; });
+      }
+      x = next;
+      x_value = next_value;
+    }
+    Variable out = cs.alloc_input([&] { return x_value; });
+    cs.enforce([&](LinearCombination lc) { return lc + x; }, [&](LinearCombination lc) { return lc + ConstraintSystem::one(); },
+               [&](LinearCombination lc) { return lc + out; });
+  }
+};
+
+}  // namespace groth16
+
+// ---------------------------------------------------------------------------------------------------
+// C entry points (declared in include/bellman_hip.h)
+// ---------------------------------------------------------------------------------------------------
+struct bh_params {
+  groth16::Parameters *p;
+};
+
+extern "C" {
+
+int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta_g1, const void *beta_g2,
+                             const void *delta_g1, const void *delta_g2, const void *h, size_t nh, const void *l,
+                             size_t nl, const void *a, size_t na, const void *b_g1, size_t nb1, const void *b_g2,
+                             size_t nb2, bh_params **out) {
+  try {
+    groth16::VerifyingKey vk;
+    memcpy(&vk.alpha_g1, alpha_g1, 96); memcpy(&vk.beta_g1, beta_g1, 96); memcpy(&vk.beta_g2, beta_g2, 192);
+    memcpy(&vk.delta_g1, delta_g1, 96); memcpy(&vk.delta_g2, delta_g2, 192);
+    *out = new bh_params{new groth16::Parameters(ctx, vk, (const groth16::G1Affine *)h, nh, (const groth16::G1Affine *)l, nl,
+                                                 (const groth16::G1Affine *)a, na, (const groth16::G1Affine *)b_g1, nb1,
+                                                 (const groth16::G2Affine *)b_g2, nb2)};
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (...) { return BH_ERR_HIP; }
+}
+void bh_groth16_params_release(bh_params *p) {
+  if (!p) return;
+  delete p->p;
+  delete p;
+}
+
+static int run_guarded(const std::function<groth16::Proof()> &f, void *proof_out) {
+  try {
+    groth16::Proof p = f();
+    memcpy(proof_out, &p.a, 96);
+    memcpy((char *)proof_out + 96, &p.b, 192);
+    memcpy((char *)proof_out + 288, &p.c, 96);
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (...) { return BH_ERR_HIP; }
+}
+
+int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const void *b_evals, const void *c_evals,
+                                size_t n_constraints, const void *input_assignment, size_t n_inputs,
+                                const void *aux_assignment, size_t n_aux, const uint64_t *a_aux_density,
+                                const uint64_t *b_input_density, const uint64_t *b_aux_density, const void *r,
+                                const void *s, void *proof_out, float *timings4) {
+  using namespace groth16;
+  ProvingAssignment pa;
+  auto fill = [](std::vector<Fr> &v, const void *src, size_t n) { v.resize(n); if (n) memcpy(v.data(), src, n * 32); };
+  fill(pa.a, a_evals, n_constraints); fill(pa.b, b_evals, n_constraints); fill(pa.c, c_evals, n_constraints);
+  fill(pa.input_assignment, input_assignment, n_inputs); fill(pa.aux_assignment, aux_assignment, n_aux);
+  auto fill_d = [](bellman::DensityTracker &d, const uint64_t *w, size_t n) {
+    for (size_t i = 0; i < n; i++) { d.add_element(); if ((w[i >> 6] >> (i & 63)) & 1) d.inc(i); }
+  };
+  fill_d(pa.a_aux_density, a_aux_density, n_aux);
+  fill_d(pa.b_input_density, b_input_density, n_inputs);
+  fill_d(pa.b_aux_density, b_aux_density, n_aux);
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = run_guarded([&] { return prove_assignment(pa, *params->p, rr, ss, &tm); }, proof_out);
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed, const void *witness,
+                          const void *constants, const void *r, const void *s, void *proof_out, float *timings4) {
+  using namespace groth16;
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc;
+  if (circuit_kind == 0) {   // MiMC: witness = xl | xr, constants = `size` round constants (Montgomery Fr)
+    MiMCDemo c;
+    memcpy(&c.xl, witness, 32); memcpy(&c.xr, (const char *)witness + 32, 32);
+    c.constants = (const Fr *)constants;
+    c.rounds = size;
+    rc = run_guarded([&] { return create_proof(c, *params->p, rr, ss, &tm); }, proof_out);
+  } else if (circuit_kind == 1) {   // chain: witness = x0, `size` rounds
+    ChainCircuit c;
+    c.seed = seed; c.rounds = size;
+    memcpy(&c.x0, witness, 32);
+    rc = run_guarded([&] { return create_proof(c, *params->p, rr, ss, &tm); }, proof_out);
+  } else {
+    return BH_ERR_INVALID_ARG;
+  }
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+}  // extern "C"

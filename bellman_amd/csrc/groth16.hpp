@@ -1,0 +1,164 @@
+// C++ host mirror of the circuit-facing and prover-facing API of bellman for the proving hot path.
+// Same names, argument meaning and error behaviour as the reference (the Rust toolchain is absent
+// from this image, so the host side above the C ABI is C++ where the reference is compiled code):
+//
+//   bellman::{Variable, Index, LinearCombination, ConstraintSystem, Circuit, SynthesisError}
+//                                         /root/reference/src/lib.rs:156-437
+//   bellman::multiexp::DensityTracker     /root/reference/src/multiexp.rs:117-157
+//   groth16::{Proof, VerifyingKey, Parameters (as ParameterSource), create_proof}
+//                                         /root/reference/groth16/src/lib.rs:25-30,219-245,411-473
+//                                         /root/reference/groth16/src/prover.rs:19-361
+//
+// Synthesis (user code + LC evaluation) runs on the host exactly as in the reference; every FFT
+// and MSM goes through the C ABI of include/bellman_hip.h to the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <functional>
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "../../include/bellman_hip.h"
+
+namespace bellman {
+
+// ---- scalar field element (bls12_381::Scalar): 4x64 Montgomery limbs, little-endian -------------
+struct Fr {
+  uint64_t l[4];
+  static Fr zero();
+  static Fr one();
+  static Fr from_u64(uint64_t v);
+  bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+  bool operator==(const Fr &o) const { return memcmp(l, o.l, sizeof l) == 0; }
+  bool operator!=(const Fr &o) const { return !(*this == o); }
+  Fr operator+(const Fr &o) const;
+  Fr operator-(const Fr &o) const;
+  Fr operator*(const Fr &o) const;
+  Fr neg() const;
+  void to_canonical(uint64_t out[4]) const;   // the bits of Exponent::Bits (multiexp.rs:179)
+};
+
+// ---- src/lib.rs:303-319 -------------------------------------------------------------------------
+struct SynthesisError : std::runtime_error {
+  int code;   // the C-ABI code: 1 UnexpectedIdentity, 2 IoError(UnexpectedEof), 3 PolynomialDegreeTooLarge, 4 AssignmentMissing
+  SynthesisError(int c, const char *what) : std::runtime_error(what), code(c) {}
+};
+
+// ---- src/lib.rs:163-185 -------------------------------------------------------------------------
+enum class Index { Input, Aux };
+struct Variable {
+  Index kind;
+  size_t idx;
+  static Variable new_unchecked(Index k, size_t i) { return Variable{k, i}; }
+};
+
+// ---- src/lib.rs:190-300: ordered (variable, coeff) list, duplicates are NOT merged ---------------
+class LinearCombination {
+ public:
+  static LinearCombination zero() { return LinearCombination(); }
+  LinearCombination operator+(Variable v) const { return *this + std::make_pair(Fr::one(), v); }
+  LinearCombination operator-(Variable v) const { return *this - std::make_pair(Fr::one(), v); }
+  LinearCombination operator+(std::pair<Fr, Variable> t) const {
+    LinearCombination r(*this);
+    r.terms_.push_back({t.second, t.first});
+    return r;
+  }
+  LinearCombination operator-(std::pair<Fr, Variable> t) const { return *this + std::make_pair(t.first.neg(), t.second); }
+  const std::vector<std::pair<Variable, Fr>> &as_ref() const { return terms_; }
+
+ private:
+  std::vector<std::pair<Variable, Fr>> terms_;
+};
+
+typedef std::function<LinearCombination(LinearCombination)> LcFn;
+
+// ---- src/lib.rs:374-437 -------------------------------------------------------------------------
+class ConstraintSystem {
+ public:
+  virtual ~ConstraintSystem() {}
+  static Variable one() { return Variable::new_unchecked(Index::Input, 0); }
+  virtual Variable alloc(const std::function<Fr()> &f) = 0;
+  virtual Variable alloc_input(const std::function<Fr()> &f) = 0;
+  virtual void enforce(const LcFn &a, const LcFn &b, const LcFn &c) = 0;
+};
+
+// ---- src/lib.rs:156-159 -------------------------------------------------------------------------
+class Circuit {
+ public:
+  virtual ~Circuit() {}
+  virtual void synthesize(ConstraintSystem &cs) = 0;
+};
+
+// ---- src/multiexp.rs:117-157 --------------------------------------------------------------------
+class DensityTracker {
+ public:
+  void add_element() {
+    if ((len_ & 63) == 0) words_.push_back(0);
+    len_++;
+  }
+  void inc(size_t idx) {
+    uint64_t &w = words_[idx >> 6];
+    const uint64_t bit = uint64_t(1) << (idx & 63);
+    if (!(w & bit)) { w |= bit; total_++; }
+  }
+  size_t get_total_density() const { return total_; }
+  size_t get_query_size() const { return len_; }
+  const uint64_t *words() const { return words_.data(); }
+
+ private:
+  std::vector<uint64_t> words_;   // LSB0, like BitVec<usize, Lsb0>
+  size_t len_ = 0, total_ = 0;
+};
+
+}  // namespace bellman
+
+namespace groth16 {
+using bellman::Fr;
+
+struct G1Affine { uint64_t v[12]; bool is_identity() const; };   // x | y, Montgomery; all-zero = identity
+struct G2Affine { uint64_t v[24]; bool is_identity() const; };
+
+struct Proof { G1Affine a; G2Affine b; G1Affine c; };             // groth16/src/lib.rs:25-30
+
+struct VerifyingKey {                                             // groth16/src/lib.rs:91-117 (prover-relevant part)
+  G1Affine alpha_g1, beta_g1;
+  G2Affine beta_g2;
+  G1Affine delta_g1;
+  G2Affine delta_g2;
+};
+
+// `&Parameters` as ParameterSource (groth16/src/lib.rs:435-473): the five query vectors live in HBM.
+class Parameters {
+ public:
+  Parameters(bh_ctx *ctx, const VerifyingKey &vk, const G1Affine *h, size_t nh, const G1Affine *l, size_t nl,
+             const G1Affine *a, size_t na, const G1Affine *b_g1, size_t nb1, const G2Affine *b_g2, size_t nb2);
+  ~Parameters();
+  Parameters(const Parameters &) = delete;
+  bh_ctx *ctx;
+  VerifyingKey vk;
+  bh_bases *h = nullptr, *l = nullptr, *a = nullptr, *b_g1 = nullptr, *b_g2 = nullptr;
+};
+
+// prover.rs:57-162: the ConstraintSystem that records evaluations, assignments and query densities
+class ProvingAssignment : public bellman::ConstraintSystem {
+ public:
+  bellman::DensityTracker a_aux_density, b_input_density, b_aux_density;
+  std::vector<Fr> a, b, c;
+  std::vector<Fr> input_assignment, aux_assignment;
+  bellman::Variable alloc(const std::function<Fr()> &f) override;
+  bellman::Variable alloc_input(const std::function<Fr()> &f) override;
+  void enforce(const bellman::LcFn &a, const bellman::LcFn &b, const bellman::LcFn &c) override;
+};
+
+struct ProveTimings { float synthesis_ms, h_poly_ms, msm_ms, total_ms; };
+
+// prover.rs:182-361.  Throws bellman::SynthesisError.
+Proof create_proof(bellman::Circuit &circuit, Parameters &params, const Fr &r, const Fr &s,
+                   ProveTimings *timings = nullptr);
+// prover.rs:217-360 on an already synthesised assignment (input constraints already appended)
+Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s,
+                       ProveTimings *timings = nullptr);
+
+}  // namespace groth16

@@ -405,7 +405,7 @@ template <> struct HostOf<Fp2Ops> { typedef HostFp2Ops type; };
 // host tail: result = sum_w sum_p 2^(c*w + p) U[w][p]
 //   bits layout: [W][lo_bits] column-bit sums, then [W][hi_bits] row-bit sums
 template <class F>
-static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, Affine<F> *out_dev_layout) {
+static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, void *out_dev_layout) {
   typedef typename HostOf<F>::type H;   // 64-bit-limb host arithmetic, identical record layout
   static_assert(sizeof(XYZZ<H>) == sizeof(XYZZ<F>) && sizeof(Affine<H>) == sizeof(Affine<F>), "layout");
   const XYZZ<H> *bits = reinterpret_cast<const XYZZ<H> *>(bits_dev_layout);
@@ -421,7 +421,9 @@ static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, Affi
       xyzz_add(acc, t, u);
     }
   }
-  xyzz_to_affine(*reinterpret_cast<Affine<H> *>(out_dev_layout), acc);
+  Affine<H> res;   // caller buffers carry no alignment guarantee: go through an aligned local
+  xyzz_to_affine(res, acc);
+  memcpy(out_dev_layout, &res, sizeof res);
 }
 
 template <class F>
@@ -462,7 +464,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     } else if (ef.ident) {
       rc = BH_ERR_UNEXPECTED_IDENTITY;
     } else {
-      msm_host_tail<F>(p, (const XYZZ<F> *)job.host_result, (Affine<F> *)out_affine);
+      msm_host_tail<F>(p, (const XYZZ<F> *)job.host_result, out_affine);
     }
   }
   for (void *ptr : job.dev_allocs) c.pool.release(ptr);
@@ -492,57 +494,51 @@ static int test_point_add_t(void *r, const void *a, const void *b, u64 n, hipStr
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
-template <class FD>
-static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
-  typedef typename HostOf<FD>::type F;
+// Host-side group helpers.  Caller records are plain byte buffers without alignment guarantees,
+// so every access goes through aligned locals.
+template <class F>
+static void generic_point_add(void *r, const void *a, const void *b, u64 n) {
   for (u64 i = 0; i < n; i++) {
+    Affine<F> pa, pb, pr;
+    memcpy(&pa, (const char *)a + i * sizeof pa, sizeof pa);
+    memcpy(&pb, (const char *)b + i * sizeof pb, sizeof pb);
     XYZZ<F> x, y, z;
-    xyzz_from_affine(x, ((const Affine<F> *)a)[i]);
-    xyzz_from_affine(y, ((const Affine<F> *)b)[i]);
+    xyzz_from_affine(x, pa);
+    xyzz_from_affine(y, pb);
     xyzz_add(z, x, y);
-    xyzz_to_affine(((Affine<F> *)r)[i], z);
+    xyzz_to_affine(pr, z);
+    memcpy((char *)r + i * sizeof pr, &pr, sizeof pr);
   }
 }
-template <class FD>
-static void host_point_mul_t(void *r, const void *a, const u32 *k) {
-  typedef typename HostOf<FD>::type F;
+template <class F>
+static void generic_point_mul(void *r, const void *a, const void *k) {
+  Affine<F> base, res;
+  u32 kw[8];
+  memcpy(&base, a, sizeof base);
+  memcpy(kw, k, sizeof kw);
   XYZZ<F> acc;
   xyzz_set_identity(acc);
-  const Affine<F> &base = *(const Affine<F> *)a;
   for (int b = 255; b >= 0; b--) {
     XYZZ<F> t;
     xyzz_dbl(t, acc);
     acc = t;
-    if (((k[b >> 5] >> (b & 31)) & 1) && !aff_is_identity(base)) xyzz_madd(acc, base);
+    if (((kw[b >> 5] >> (b & 31)) & 1) && !aff_is_identity(base)) xyzz_madd(acc, base);
   }
-  xyzz_to_affine(*(Affine<F> *)r, acc);
+  xyzz_to_affine(res, acc);
+  memcpy(r, &res, sizeof res);
 }
-
-// the same two helpers on the DEVICE headers compiled for the host (32-bit limbs): CPU-side unit
-// tests of ff.cuh / ec.cuh exactly as the kernels use them
-template <class F>
-static void devhdr_point_add_t(void *r, const void *a, const void *b, u64 n) {
-  for (u64 i = 0; i < n; i++) {
-    XYZZ<F> x, y, z;
-    xyzz_from_affine(x, ((const Affine<F> *)a)[i]);
-    xyzz_from_affine(y, ((const Affine<F> *)b)[i]);
-    xyzz_add(z, x, y);
-    xyzz_to_affine(((Affine<F> *)r)[i], z);
-  }
+// fast path: 64-bit-limb host arithmetic
+template <class FD> static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
+  generic_point_add<typename HostOf<FD>::type>(r, a, b, n);
 }
-template <class F>
-static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) {
-  XYZZ<F> acc;
-  xyzz_set_identity(acc);
-  const Affine<F> &base = *(const Affine<F> *)a;
-  for (int b = 255; b >= 0; b--) {
-    XYZZ<F> t;
-    xyzz_dbl(t, acc);
-    acc = t;
-    if (((k[b >> 5] >> (b & 31)) & 1) && !aff_is_identity(base)) xyzz_madd(acc, base);
-  }
-  xyzz_to_affine(*(Affine<F> *)r, acc);
+template <class FD> static void host_point_mul_t(void *r, const void *a, const u32 *k) {
+  generic_point_mul<typename HostOf<FD>::type>(r, a, k);
 }
+// the DEVICE headers compiled for the host (32-bit limbs): CPU-side unit tests of ff.cuh / ec.cuh
+template <class F> static void devhdr_point_add_t(void *r, const void *a, const void *b, u64 n) {
+  generic_point_add<F>(r, a, b, n);
+}
+template <class F> static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) { generic_point_mul<F>(r, a, k); }
 
 #define BH_INSTANTIATE_MSM(SUFFIX, OPS)                                                                       \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \

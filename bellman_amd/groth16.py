@@ -1,0 +1,208 @@
+"""`groth16::create_proof` mirror (reference: groth16/src/prover.rs:19-361) for Python callers.
+
+Circuits are written against `ConstraintSystem` exactly like bellman user code; synthesis and
+linear-combination evaluation run on the host (as in the reference), everything after
+`circuit.synthesize` - the h-polynomial FFT pipeline and the eight multiexps - runs on the GPU
+through bh_groth16_prove_assignment.  Field elements are Python ints in [0, q).
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .errors import check
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_R = (1 << 256) % Q
+_MASK = (1 << 64) - 1
+INPUT, AUX = 0, 1
+
+
+def fr_to_mont_array(vals):
+    """ints in [0,q) -> [n,4] uint64 Montgomery limbs (the bytes of bls12_381::Scalar)."""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        m = (v % Q) * _R % Q
+        out[i] = [(m >> (64 * k)) & _MASK for k in range(4)]
+    return out
+
+
+class Variable:
+    """src/lib.rs:163-185"""
+
+    __slots__ = ("kind", "idx")
+
+    def __init__(self, kind, idx):
+        self.kind, self.idx = kind, idx
+
+
+class LinearCombination:
+    """src/lib.rs:190-300: ordered (variable, coeff) terms, duplicates not merged."""
+
+    def __init__(self, terms=None):
+        self.terms = list(terms or [])
+
+    @staticmethod
+    def zero():
+        return LinearCombination()
+
+    def __add__(self, other):
+        coeff, var = (1, other) if isinstance(other, Variable) else other
+        return LinearCombination(self.terms + [(var, coeff % Q)])
+
+    def __sub__(self, other):
+        coeff, var = (1, other) if isinstance(other, Variable) else other
+        return LinearCombination(self.terms + [(var, (-coeff) % Q)])
+
+
+class ConstraintSystem:
+    """src/lib.rs:374-437 (subset used by circuits: one, alloc, alloc_input, enforce)."""
+
+    @staticmethod
+    def one():
+        return Variable(INPUT, 0)
+
+
+class _Density:
+    """src/multiexp.rs:117-157"""
+
+    def __init__(self):
+        self.bv = []
+
+    def add_element(self):
+        self.bv.append(False)
+
+    def inc(self, i):
+        self.bv[i] = True
+
+    def get_total_density(self):
+        return sum(self.bv)
+
+    def words(self):
+        n = len(self.bv)
+        padded = np.zeros(((n + 63) // 64 + 1) * 64, dtype=np.uint8)
+        padded[:n] = np.asarray(self.bv, dtype=np.uint8)
+        return np.packbits(padded, bitorder="little").view(np.uint64).copy()
+
+
+class ProvingAssignment(ConstraintSystem):
+    """prover.rs:57-162"""
+
+    def __init__(self):
+        self.a_aux_density, self.b_input_density, self.b_aux_density = _Density(), _Density(), _Density()
+        self.a, self.b, self.c = [], [], []
+        self.input_assignment, self.aux_assignment = [], []
+
+    def alloc(self, f):
+        self.aux_assignment.append(f() % Q)
+        self.a_aux_density.add_element()
+        self.b_aux_density.add_element()
+        return Variable(AUX, len(self.aux_assignment) - 1)
+
+    def alloc_input(self, f):
+        self.input_assignment.append(f() % Q)
+        self.b_input_density.add_element()
+        return Variable(INPUT, len(self.input_assignment) - 1)
+
+    def _eval(self, lc, input_density, aux_density):
+        """prover.rs:19-55"""
+        acc = 0
+        for var, coeff in lc.terms:
+            if coeff == 0:
+                continue
+            if var.kind == INPUT:
+                tmp = self.input_assignment[var.idx]
+                if input_density is not None:
+                    input_density.inc(var.idx)
+            else:
+                tmp = self.aux_assignment[var.idx]
+                if aux_density is not None:
+                    aux_density.inc(var.idx)
+            if coeff != 1:
+                tmp = tmp * coeff % Q
+            acc = (acc + tmp) % Q
+        return acc
+
+    def enforce(self, a, b, c):
+        z = LinearCombination.zero()
+        self.a.append(self._eval(a(z), None, self.a_aux_density))
+        self.b.append(self._eval(b(z), self.b_input_density, self.b_aux_density))
+        self.c.append(self._eval(c(z), None, None))
+
+
+class Proof:
+    """groth16/src/lib.rs:25-30: affine records (numpy uint64): a [12], b [24], c [12]."""
+
+    def __init__(self, raw):
+        self.a, self.b, self.c = raw[:12].copy(), raw[12:36].copy(), raw[36:48].copy()
+
+
+class Parameters:
+    """`&Parameters` as ParameterSource (groth16/src/lib.rs:435-473); query vectors live in HBM."""
+
+    def __init__(self, worker, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, h, l, a, b_g1, b_g2):
+        lib = _lib.load()
+        self.worker = worker
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2)]
+        qs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, w) for x, w in ((h, 12), (l, 12), (a, 12), (b_g1, 12), (b_g2, 24))]
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        h_ = ctypes.c_void_p()
+        check(lib.bh_groth16_params_create(worker.ctx, *[p(x) for x in arrs], p(qs[0]), qs[0].shape[0], p(qs[1]),
+                                           qs[1].shape[0], p(qs[2]), qs[2].shape[0], p(qs[3]), qs[3].shape[0],
+                                           p(qs[4]), qs[4].shape[0], ctypes.byref(h_)), "Parameters")
+        self._h = h_
+
+    def release(self):
+        if self._h:
+            _lib.load().bh_groth16_params_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def prove_assignment(prover, params, r, s, timings=None):
+    """prover.rs:217-360 on a synthesised ProvingAssignment."""
+    lib = _lib.load()
+    a, b, c = (fr_to_mont_array(v) for v in (prover.a, prover.b, prover.c))
+    ia, aa = fr_to_mont_array(prover.input_assignment), fr_to_mont_array(prover.aux_assignment)
+    d1, d2, d3 = prover.a_aux_density.words(), prover.b_input_density.words(), prover.b_aux_density.words()
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_assignment(params._h, p(a), p(b), p(c), a.shape[0], p(ia), ia.shape[0], p(aa), aa.shape[0],
+                                          p(d1), p(d2), p(d3), p(rs[0:1]), p(rs[1:2]), p(out), tm), "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)
+
+
+def create_proof(circuit, params, r, s, timings=None):
+    """prover.rs:182-215: `circuit` is a callable circuit(cs) (the Circuit::synthesize body)."""
+    prover = ProvingAssignment()
+    prover.alloc_input(lambda: 1)
+    circuit(prover)
+    for i in range(len(prover.input_assignment)):
+        prover.enforce(lambda lc, i=i: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
+    return prove_assignment(prover, params, r, s, timings)
+
+
+def create_proof_demo(params, kind, size, seed, witness, constants, r, s, timings=None):
+    """create_proof on one of the C++ demo circuits (groth16.cpp): 0 = MiMCDemo, 1 = chain."""
+    lib = _lib.load()
+    wit = fr_to_mont_array(list(witness))
+    con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_demo(params._h, kind, size, seed, p(wit), p(con), p(rs[0:1]), p(rs[1:2]), p(out), tm),
+          "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)

@@ -142,6 +142,35 @@ int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host,
                           const void *scalars_dev, size_t n, int scalar_fmt, void *out_dev,
                           void *stream);
 
+/* ---- groth16::create_proof (groth16/src/prover.rs:182-361) --------------------------------------
+ * bh_params = `&Parameters` as ParameterSource (groth16/src/lib.rs:435-473): the verifying-key
+ * elements the prover uses plus the five query vectors (h, l, a, b_g1, b_g2), registered in HBM.
+ * A proof is written as affine records a (96 B) | b (192 B) | c (96 B).
+ * The C++ mirror of Circuit / ConstraintSystem / LinearCombination / ProvingAssignment lives in
+ * bellman_amd/csrc/groth16.hpp; these entry points expose it to other host languages. */
+typedef struct bh_params bh_params;
+int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta_g1, const void *beta_g2,
+                             const void *delta_g1, const void *delta_g2, const void *h, size_t nh,
+                             const void *l, size_t nl, const void *a, size_t na, const void *b_g1,
+                             size_t nb1, const void *b_g2, size_t nb2, bh_params **out);
+void bh_groth16_params_release(bh_params *p);
+/* prover.rs:217-360 on the fields of a synthesised ProvingAssignment (prover.rs:57-71): a/b/c
+ * evaluations (n_constraints, input constraints of :208-215 already appended), input/aux
+ * assignments (Montgomery Fr), the three density bitmaps (LSB0 words), r and s (Montgomery Fr).
+ * timings4 (optional): [synthesis, h block, multiexps, total] host milliseconds. */
+int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const void *b_evals,
+                                const void *c_evals, size_t n_constraints, const void *input_assignment,
+                                size_t n_inputs, const void *aux_assignment, size_t n_aux,
+                                const uint64_t *a_aux_density, const uint64_t *b_input_density,
+                                const uint64_t *b_aux_density, const void *r, const void *s,
+                                void *proof_out, float *timings4);
+/* create_proof on a circuit written in C++ against the mirror (like bellman user code):
+ * kind 0 = MiMCDemo (groth16/tests/common/mod.rs; witness = xl|xr, constants = `size` Fr),
+ * kind 1 = synthetic multiplicative chain of `size` rounds (witness = x0). */
+int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed,
+                          const void *witness, const void *constants, const void *r, const void *s,
+                          void *proof_out, float *timings4);
+
 /* ---- self-test hooks used by tests/ (element-wise field / group ops on the device) ---- */
 int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
 int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);

@@ -1,0 +1,103 @@
+"""Circuits used by the prover tests, written once against the ConstraintSystem interface shared by
+the oracle restatement (oracle/pyref/core.py) and the product's Python mirror (bellman_amd/groth16.py).
+The C++ versions of the same circuits live in bellman_amd/csrc/groth16.cpp."""
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+MASK64 = (1 << 64) - 1
+MIMC_ROUNDS = 322
+
+
+def mimc_hash(xl, xr, constants):
+    """groth16/tests/common/mod.rs:20-35"""
+    for c in constants:
+        t = (xl + c) % Q
+        xl, xr = (t * t % Q * t + xr) % Q, xl
+    return xl
+
+
+def mimc_circuit(xl, xr, constants):
+    """MiMCDemo::synthesize, groth16/tests/common/mod.rs:48-129"""
+
+    def synth(cs):
+        xl_v, xr_v = xl, xr
+        xlv = cs.alloc(lambda: xl_v)
+        xrv = cs.alloc(lambda: xr_v)
+        n = len(constants)
+        for i, ci in enumerate(constants):
+            t0 = (xl_v + ci) % Q
+            tmp_v = t0 * t0 % Q
+            tmp = cs.alloc(lambda: tmp_v)
+            cs.enforce(lambda lc: lc + xlv + (ci, cs.one()), lambda lc: lc + xlv + (ci, cs.one()), lambda lc: lc + tmp)
+            new_v = (t0 * tmp_v + xr_v) % Q
+            new_xl = cs.alloc_input(lambda: new_v) if i == n - 1 else cs.alloc(lambda: new_v)
+            cs.enforce(lambda lc: lc + tmp, lambda lc: lc + xlv + (ci, cs.one()), lambda lc: lc + new_xl - xrv)
+            xrv, xr_v = xlv, xl_v
+            xlv, xl_v = new_xl, new_v
+
+    return synth
+
+
+def _splitmix(state):
+    state = (state + 0x9E3779B97F4A7C15) & MASK64
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return state, z ^ (z >> 31)
+
+
+def chain_constants(rounds, seed):
+    st = seed & MASK64
+    ks = []
+    for _ in range(rounds):
+        st, k = _splitmix(st)
+        st, k2 = _splitmix(st)
+        ks.append((k % Q, (k2 | 1) % Q))
+    return ks
+
+
+def chain_circuit(rounds, seed, x0):
+    """ChainCircuit::synthesize of groth16.cpp (synthetic R1CS of SURVEY.md 8d)."""
+
+    def synth(cs):
+        x_v = x0 % Q
+        x = cs.alloc(lambda: x_v)
+        first = x
+        for i, (k, k2) in enumerate(chain_constants(rounds, seed)):
+            lhs = (x_v + k) % Q
+            rhs = k2 if (i & 1) else (x_v + k2) % Q
+            nxt_v = lhs * rhs % Q
+            nxt = cs.alloc(lambda: nxt_v)
+            if i & 1:
+                cs.enforce(lambda lc: lc + x + (k, cs.one()) + (0, first), lambda lc: lc + (k2, cs.one()), lambda lc: lc + nxt)
+            else:
+                cs.enforce(lambda lc: lc + x + (k, cs.one()), lambda lc: lc + x + (k2, cs.one()), lambda lc: lc + nxt)
+            x, x_v = nxt, nxt_v
+        out = cs.alloc_input(lambda: x_v)
+        cs.enforce(lambda lc: lc + x, lambda lc: lc + cs.one(), lambda lc: lc + out)
+
+    return synth
+
+
+def chain_assignment_fast(rounds, seed, x0):
+    """The ProvingAssignment the chain circuit produces (after create_proof's input constraints),
+    computed in closed form - for sizes where generic Python synthesis is too slow."""
+    xs = [x0 % Q]
+    a_ev, b_ev, c_ev = [], [], []
+    for i, (k, k2) in enumerate(chain_constants(rounds, seed)):
+        x = xs[-1]
+        lhs = (x + k) % Q
+        rhs = k2 if (i & 1) else (x + k2) % Q
+        nxt = lhs * rhs % Q
+        a_ev.append(lhs)
+        b_ev.append(rhs)
+        c_ev.append(nxt)
+        xs.append(nxt)
+    out = xs[-1]
+    a_ev.append(out); b_ev.append(1); c_ev.append(out)  # x_M * 1 = out
+    a_ev += [1, out]; b_ev += [0, 0]; c_ev += [0, 0]    # input_i * 0 = 0 (prover.rs:208-215)
+    n_aux = rounds + 1
+    a_aux_density = [True] * n_aux
+    b_aux_density = [(i % 2 == 0) and i < rounds for i in range(n_aux)]
+    b_input_density = [True, False]
+    return dict(a=a_ev, b=b_ev, c=c_ev, input_assignment=[1, out], aux_assignment=xs,
+                a_aux_density=a_aux_density, b_input_density=b_input_density, b_aux_density=b_aux_density)

@@ -132,3 +132,22 @@ def test_fast_host_group_ops_match_oracle(lib, group):
         o = np.zeros(w, dtype=np.uint64)
         lib.bh_point_mul(group, _p(o), _p(A[5]), _p(ka))
         assert np.array_equal(o, cref.point_mul(group, A[5], k))
+
+
+def test_host_group_ops_accept_unaligned_buffers(lib):
+    """Regression (first GPU prover run): caller records are only 8-byte aligned in general."""
+    A = cref.gen_bases(1, 2, a=3, b=1)
+    raw = np.zeros(12 * 3 + 1, dtype=np.uint64)
+    base = raw.ctypes.data
+    off = 1 if (base % 16 == 0) else 0           # force an address that is 8 mod 16
+    a = raw[off : off + 12]
+    b = raw[off + 12 : off + 24]
+    r = raw[off + 24 : off + 36]
+    a[:] = A[0]
+    b[:] = A[1]
+    assert a.ctypes.data % 16 == 8
+    lib.bh_point_add(1, _p(r), _p(a), _p(b), 1)
+    assert np.array_equal(r, cref.point_add(1, A[0], A[1]))
+    k = np.array(cref.int_to_limbs(12345, 4), dtype=np.uint64)
+    lib.bh_point_mul(1, _p(r), _p(a), _p(k))
+    assert np.array_equal(r, cref.point_mul(1, A[0], 12345))

@@ -1,0 +1,144 @@
+"""GPU parity of groth16::create_proof (prover.rs:182-361) - every proof element compared exactly
+with the oracle's.  Covers BASELINE configs C1 (MiMC-322, 646 constraints) and the synthetic chain
+circuit of C4 at reduced and full (2^20) size, through both host mirrors (Python circuit ->
+bh_groth16_prove_assignment; C++ circuit -> bh_groth16_prove_demo)."""
+
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cprover, cref  # noqa: E402
+from oracle.cengine import CBls12  # noqa: E402
+from oracle.pyref import bls12_381 as bls  # noqa: E402
+from oracle.pyref.generator import generate_parameters  # noqa: E402
+from oracle.pyref.prover import create_proof as oracle_create_proof  # noqa: E402
+from tests import circuits  # noqa: E402
+
+Q = bls.Q
+TOXIC = dict(alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+
+
+@pytest.fixture(scope="module")
+def worker():
+    import bellman_amd
+
+    w = bellman_amd.Worker(0)
+    yield w
+    w.close()
+
+
+def _arr(b):
+    return np.frombuffer(b, dtype=np.uint64)
+
+
+def _product_params(worker, p):
+    from bellman_amd import groth16 as pg
+
+    G1, G2 = CBls12.G1, CBls12.G2
+    return pg.Parameters(worker, _arr(p.vk.alpha_g1), _arr(p.vk.beta_g1), _arr(p.vk.beta_g2), _arr(p.vk.delta_g1),
+                         _arr(p.vk.delta_g2), G1.to_array(p.h), G1.to_array(p.l), G1.to_array(p.a), G1.to_array(p.b_g1),
+                         G2.to_array(p.b_g2))
+
+
+def _same(proof, a, b, c):
+    return proof.a.tobytes() == bytes(a) and proof.b.tobytes() == bytes(b) and proof.c.tobytes() == bytes(c)
+
+
+def test_mimc_322_config_c1(worker):
+    """groth16/tests/mimc.rs with fixed toxic waste / constants / r,s; 646 constraints -> m = 2^10."""
+    from bellman_amd import groth16 as pg
+
+    rnd = random.Random(322)
+    cons = [rnd.randrange(Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr = rnd.randrange(Q), rnd.randrange(Q)
+    r, s = rnd.randrange(Q), rnd.randrange(Q)
+    circ = circuits.mimc_circuit(xl, xr, cons)
+    p = generate_parameters(CBls12, circuits.mimc_circuit(0, 0, cons), CBls12.G1.gen, CBls12.G2.gen, **TOXIC)
+    assert (len(p.h), len(p.l), len(p.a), len(p.b_g1)) == (1023, 645, 646, 323)   # h 1023, l 645, a 2+644, b 1+322
+    want = oracle_create_proof(CBls12, circ, p, r, s)
+    pp = _product_params(worker, p)
+    tm = [0, 0, 0, 0]
+    got = pg.create_proof(circ, pp, r, s, tm)                      # Python circuit
+    assert _same(got, want.a, want.b, want.c)
+    got2 = pg.create_proof_demo(pp, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s, tm)   # C++ MiMCDemo
+    assert _same(got2, want.a, want.b, want.c)
+    print("MiMC-322 create_proof host ms [synthesis, h, msm, total]:", tm)
+    # a proof for a different witness differs (sanity against constant outputs)
+    got3 = pg.create_proof_demo(pp, 0, circuits.MIMC_ROUNDS, 0, [xl + 1, xr], cons, r, s)
+    assert not _same(got3, want.a, want.b, want.c)
+
+
+def _chain_setup(worker, rounds, seed):
+    """Synthetic CRS (distinct prime-order points; not a valid trusted setup - parity only)."""
+    from bellman_amd import groth16 as pg
+
+    n_cons = rounds + 3
+    m = 1
+    while m < n_cons:
+        m *= 2
+    n_aux = rounds + 1
+    nb = (rounds + 1) // 2 + 2
+    h = cref.gen_bases(1, m - 1, a=11, b=3)
+    l = cref.gen_bases(1, n_aux, a=5, b=7)
+    a = cref.gen_bases(1, n_aux + 2, a=2, b=9)
+    b1 = cref.gen_bases(1, nb, a=13, b=4)
+    b2 = cref.gen_bases(2, nb, a=17, b=6)
+    g1, g2 = cref.g1_generator(), cref.g2_generator()
+    vk = dict(alpha_g1=cref.point_mul(1, g1, 101), beta_g1=cref.point_mul(1, g1, 102), beta_g2=cref.point_mul(2, g2, 102),
+              delta_g1=cref.point_mul(1, g1, 103), delta_g2=cref.point_mul(2, g2, 103))
+    pp = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l, a, b1, b2)
+    return pp, vk, (h, l, a, b1, b2)
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 61, 4093])
+def test_chain_circuit_python_and_cpp_mirrors(worker, rounds):
+    from bellman_amd import groth16 as pg
+
+    seed, x0 = 7 + rounds, 123456789
+    r, s = 0x1234567 + rounds, 0x7654321
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    f = circuits.chain_assignment_fast(rounds, seed, x0)
+    want = cprover.prove_assignment(f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"],
+                                    f["b_input_density"], f["b_aux_density"], vk, h, l, a, b1, b2, r, s)
+    got_cpp = pg.create_proof_demo(pp, 1, rounds, seed, [x0], None, r, s)
+    assert _same(got_cpp, want[0].tobytes(), want[1].tobytes(), want[2].tobytes())
+    if rounds <= 61:
+        got_py = pg.create_proof(circuits.chain_circuit(rounds, seed, x0), pp, r, s)
+        assert _same(got_py, want[0].tobytes(), want[1].tobytes(), want[2].tobytes())
+
+
+def test_chain_2_20_config_c4(worker):
+    """BASELINE config C4: full create_proof at 2^20 constraints (4 large G1 + 1 large G2 multiexp,
+    7 FFTs), bit-exact against the C restatement of the prover."""
+    from bellman_amd import groth16 as pg
+
+    rounds = (1 << 20) - 3
+    seed, x0, r, s = 2020, 987654321, 0xABCDEF0123, 0x123456789AB
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    tm = [0, 0, 0, 0]
+    got = pg.create_proof_demo(pp, 1, rounds, seed, [x0], None, r, s, tm)
+    print("2^20-constraint create_proof host ms [synthesis, h, msm, total]:", tm)
+    f = circuits.chain_assignment_fast(rounds, seed, x0)
+    want = cprover.prove_assignment(f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"],
+                                    f["b_input_density"], f["b_aux_density"], vk, h, l, a, b1, b2, r, s,
+                                    threads=cref.lib().orc_max_threads())
+    assert _same(got, want[0].tobytes(), want[1].tobytes(), want[2].tobytes())
+
+
+def test_create_proof_error_paths(worker):
+    """UnexpectedIdentity for an identity delta (prover.rs:320-324); EOF when a query is too short."""
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+    from bellman_amd import groth16 as pg
+
+    rounds, seed, x0 = 20, 3, 99
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    zero1 = np.zeros(12, dtype=np.uint64)
+    bad = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], zero1, vk["delta_g2"], h, l, a, b1, b2)
+    with pytest.raises(UnexpectedIdentity):
+        pg.create_proof_demo(bad, 1, rounds, seed, [x0], None, 5, 6)
+    short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l[:-1], a, b1, b2)
+    with pytest.raises(UnexpectedEof):
+        pg.create_proof_demo(short, 1, rounds, seed, [x0], None, 5, 6)

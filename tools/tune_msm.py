@@ -6,19 +6,27 @@ import bellman_amd
 from bellman_amd import _lib
 from bench import splitmix_scalars, G1_GEN_MONT
 
+G2_GEN_MONT = np.array([0xF5F28FA202940A10, 0xB3F5FB2687B4961A, 0xA1A893B53E2AE580, 0x9894999D1A3CAEE9, 0x6F67B7631863366B, 0x058191924350BCD7,
+                        0xA5A9C0759E23F606, 0xAAA0C59DBCCD60C3, 0x3BB17E18E2867806, 0x1B1AB6CC8541B367, 0xC2B6ED0EF2158547, 0x11922A097360EDF3,
+                        0x4C730AF860494C4A, 0x597CFA1F5E369C5A, 0xE7E6856CAA0A635A, 0xBBEFB5E96E0D495F, 0x07D3A975F0EF25A2, 0x0083FD8E7E80DAE5,
+                        0xADC0FC92DF64B05D, 0x18AA270A2B1461DC, 0x86ADAC6A3BE4EBA0, 0x79495C4EC93DA33A, 0xE7175850A43CCAED, 0x0B2BC2A163DE1BF2], dtype=np.uint64)
+
 def main():
     log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     cs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [13, 14, 15, 16]
     ks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [16, 32, 64]
+    group = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    words = 12 if group == 1 else 24
     lib = _lib.load()
     w = bellman_amd.Worker(0)
     n = 1 << log_n
     t = splitmix_scalars(n, 1)
-    dt, dout = w.alloc(n * 32), w.alloc(n * 96)
+    dt, dout = w.alloc(n * 32), w.alloc(n * 8 * words)
     w.upload(dt, t)
-    assert lib.bh_fixed_base_mul_dev(w.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+    gen = G1_GEN_MONT if group == 1 else G2_GEN_MONT
+    assert lib.bh_fixed_base_mul_dev(w.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
     w.synchronize()
-    bases = bellman_amd.Bases.wrap_device(w, 1, dout, n)
+    bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
     s = splitmix_scalars(n, 2)
     ds = w.alloc(n * 32)
     w.upload(ds, s)
@@ -35,6 +43,6 @@ def main():
             if ref is None:
                 ref = r
             assert np.array_equal(r, ref)
-            print("log_n=%d c=%2d K=%3d  total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" % (log_n, c, k, *best), flush=True)
+            print("G%d " % group + "log_n=%d c=%2d K=%3d  total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" % (log_n, c, k, *best), flush=True)
 
 main()
