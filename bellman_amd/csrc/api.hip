@@ -261,6 +261,7 @@ int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c) {
 }
 int bh_msm_set_chunk(bh_ctx *ctx, unsigned k) {
   (void)ctx;
+  // bits 8..23: chunk K; bits 24/25 (k = 0x10000 / 0x20000 ored in): force register / LDS accumulator
   g_forced_c.store((g_forced_c.load() & 0xffu) | (k << 8));
   return BH_OK;
 }

@@ -362,7 +362,8 @@ struct Fp2Ops {
   BH_HD static void neg(T &r, const T &a) { fe_neg(r.c0, a.c0); fe_neg(r.c1, a.c1); }
   BH_HD static void dbl(T &r, const T &a) { add(r, a, a); }
   BH_HD static void mul(T &r, const T &a, const T &b) {
-    // Karatsuba: 3 Fp products
+    // Karatsuba: 3 Fp products.  (Measured: making this an out-of-line by-value call passes 16 of the
+    // 48 argument words through scratch and is 1.6x slower on the G2 accumulate kernel.)
     fp_t t0, t1, t2, t3;
     t0 = fp_mul_call(a.c0, b.c0);
     t1 = fp_mul_call(a.c1, b.c1);

@@ -32,31 +32,28 @@ inline void sub_mod(uint64_t *a) {
     br = (d >> 64) & 1;
   }
 }
-inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
-  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
-    u128 c = 0;
-    for (int j = 0; j < 4; j++) {
-      c += (u128)a[j] * b[i] + t[j];
-      t[j] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[4];
-    t[4] = (uint64_t)c;
-    t[5] = (uint64_t)(c >> 64);
-    const uint64_t m = t[0] * FR_INV;
-    c = ((u128)m * FR_MOD[0] + t[0]) >> 64;
-    for (int j = 1; j < 4; j++) {
-      c += (u128)m * FR_MOD[j] + t[j];
-      t[j - 1] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[4];
-    t[3] = (uint64_t)c;
-    t[4] = t[5] + (uint64_t)(c >> 64);
+// 4x64 CIOS Montgomery product, fully unrolled (synthesis is the serial part of create_proof)
+__attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define BH_ROW(bi)                                                                        \
+  {                                                                                       \
+    u128 c = (u128)a[0] * (bi) + t0; t0 = (uint64_t)c; c >>= 64;                          \
+    c += (u128)a[1] * (bi) + t1; t1 = (uint64_t)c; c >>= 64;                              \
+    c += (u128)a[2] * (bi) + t2; t2 = (uint64_t)c; c >>= 64;                              \
+    c += (u128)a[3] * (bi) + t3; t3 = (uint64_t)c; c >>= 64;                              \
+    c += t4; t4 = (uint64_t)c; const uint64_t t5 = (uint64_t)(c >> 64);                   \
+    const uint64_t m = t0 * FR_INV;                                                       \
+    c = ((u128)m * FR_MOD[0] + t0) >> 64;                                                 \
+    c += (u128)m * FR_MOD[1] + t1; t0 = (uint64_t)c; c >>= 64;                            \
+    c += (u128)m * FR_MOD[2] + t2; t1 = (uint64_t)c; c >>= 64;                            \
+    c += (u128)m * FR_MOD[3] + t3; t2 = (uint64_t)c; c >>= 64;                            \
+    c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                             \
   }
-  if (t[4] || geq_mod(t)) sub_mod(t);
-  memcpy(r, t, 4 * sizeof(uint64_t));
+  BH_ROW(b[0]) BH_ROW(b[1]) BH_ROW(b[2]) BH_ROW(b[3])
+#undef BH_ROW
+  uint64_t t[4] = {t0, t1, t2, t3};
+  if (t4 || geq_mod(t)) sub_mod(t);
+  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
 }
 }  // namespace
 
@@ -140,9 +137,9 @@ static Fr eval(const LinearCombination &lc, DensityTracker *input_density, Densi
                const std::vector<Fr> &input_assignment, const std::vector<Fr> &aux_assignment) {
   Fr acc = Fr::zero();
   const Fr one = Fr::one();
-  for (const auto &term : lc.as_ref()) {
-    const Variable &var = term.first;
-    const Fr &coeff = term.second;
+  for (size_t t = 0; t < lc.size(); t++) {
+    const Variable &var = lc[t].first;
+    const Fr &coeff = lc[t].second;
     if (coeff.is_zero()) continue;          // zero coefficients count for neither value nor density (:31)
     Fr tmp;
     if (var.kind == Index::Input) {
@@ -152,25 +149,26 @@ static Fr eval(const LinearCombination &lc, DensityTracker *input_density, Densi
       tmp = aux_assignment[var.idx];
       if (aux_density) aux_density->inc(var.idx);
     }
-    if (coeff != one) tmp = tmp * coeff;
+    if (tmp == one) tmp = coeff;            // 1 * coeff (the ubiquitous `(c, CS::one())` terms)
+    else if (coeff != one) tmp = tmp * coeff;
     acc = acc + tmp;
   }
   return acc;
 }
 
 // ---- prover.rs:73-162 -----------------------------------------------------------------------------
-Variable ProvingAssignment::alloc(const std::function<Fr()> &f) {
+Variable ProvingAssignment::alloc(ValueFn f) {
   aux_assignment.push_back(f());
   a_aux_density.add_element();
   b_aux_density.add_element();
   return Variable::new_unchecked(Index::Aux, aux_assignment.size() - 1);
 }
-Variable ProvingAssignment::alloc_input(const std::function<Fr()> &f) {
+Variable ProvingAssignment::alloc_input(ValueFn f) {
   input_assignment.push_back(f());
   b_input_density.add_element();
   return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
 }
-void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) {
+void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
   const LinearCombination la = fa(LinearCombination::zero()), lb = fb(LinearCombination::zero()),
                           lc = fc(LinearCombination::zero());
   // inputs have full density in the A query; there is no C query (prover.rs:119-141)

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <functional>
+#include <type_traits>
 #include <stdexcept>
 #include <utility>
 #include <vector>
@@ -55,33 +56,64 @@ struct Variable {
 };
 
 // ---- src/lib.rs:190-300: ordered (variable, coeff) list, duplicates are NOT merged ---------------
+// Terms live inline for the common short combinations (no heap traffic during synthesis, which is
+// the serial part of create_proof); longer ones spill to a vector.
 class LinearCombination {
  public:
+  typedef std::pair<Variable, Fr> Term;
   static LinearCombination zero() { return LinearCombination(); }
-  LinearCombination operator+(Variable v) const { return *this + std::make_pair(Fr::one(), v); }
-  LinearCombination operator-(Variable v) const { return *this - std::make_pair(Fr::one(), v); }
-  LinearCombination operator+(std::pair<Fr, Variable> t) const {
-    LinearCombination r(*this);
-    r.terms_.push_back({t.second, t.first});
-    return r;
-  }
-  LinearCombination operator-(std::pair<Fr, Variable> t) const { return *this + std::make_pair(t.first.neg(), t.second); }
-  const std::vector<std::pair<Variable, Fr>> &as_ref() const { return terms_; }
+  LinearCombination() : n_(0) {}
+  LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one()); return r; }
+  LinearCombination operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
+  LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
+  LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
+  LinearCombination operator+(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
+  LinearCombination operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
+  LinearCombination operator-(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
+  LinearCombination operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  size_t size() const { return n_; }
+  const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
 
  private:
-  std::vector<std::pair<Variable, Fr>> terms_;
+  static constexpr size_t INLINE = 4;
+  void push(Variable v, const Fr &c) {
+    if (n_ < INLINE) inl_[n_] = Term(v, c); else more_.push_back(Term(v, c));
+    n_++;
+  }
+  Term inl_[INLINE];
+  std::vector<Term> more_;
+  size_t n_;
 };
 
-typedef std::function<LinearCombination(LinearCombination)> LcFn;
+// Non-owning callable reference (two pointers, never allocates): the C++ stand-in for the
+// monomorphised `FnOnce` parameters of ConstraintSystem::{alloc, enforce} (src/lib.rs:385-416).
+// The referenced callable only has to live for the duration of the call it is passed to.
+template <class Sig> class FunctionRef;
+template <class R, class... Args>
+class FunctionRef<R(Args...)> {
+ public:
+  template <class F>
+  FunctionRef(F &&f) : obj_((void *)&f), call_([](void *o, Args... args) -> R {
+    return (*reinterpret_cast<typename std::remove_reference<F>::type *>(o))(std::forward<Args>(args)...);
+  }) {}
+  R operator()(Args... args) const { return call_(obj_, std::forward<Args>(args)...); }
+
+ private:
+  void *obj_;
+  R (*call_)(void *, Args...);
+};
+
+typedef FunctionRef<LinearCombination(LinearCombination)> LcFn;
+typedef FunctionRef<Fr()> ValueFn;
 
 // ---- src/lib.rs:374-437 -------------------------------------------------------------------------
 class ConstraintSystem {
  public:
   virtual ~ConstraintSystem() {}
   static Variable one() { return Variable::new_unchecked(Index::Input, 0); }
-  virtual Variable alloc(const std::function<Fr()> &f) = 0;
-  virtual Variable alloc_input(const std::function<Fr()> &f) = 0;
-  virtual void enforce(const LcFn &a, const LcFn &b, const LcFn &c) = 0;
+  virtual Variable alloc(ValueFn f) = 0;
+  virtual Variable alloc_input(ValueFn f) = 0;
+  virtual void enforce(LcFn a, LcFn b, LcFn c) = 0;
 };
 
 // ---- src/lib.rs:156-159 -------------------------------------------------------------------------
@@ -147,9 +179,9 @@ class ProvingAssignment : public bellman::ConstraintSystem {
   bellman::DensityTracker a_aux_density, b_input_density, b_aux_density;
   std::vector<Fr> a, b, c;
   std::vector<Fr> input_assignment, aux_assignment;
-  bellman::Variable alloc(const std::function<Fr()> &f) override;
-  bellman::Variable alloc_input(const std::function<Fr()> &f) override;
-  void enforce(const bellman::LcFn &a, const bellman::LcFn &b, const bellman::LcFn &c) override;
+  bellman::Variable alloc(bellman::ValueFn f) override;
+  bellman::Variable alloc_input(bellman::ValueFn f) override;
+  void enforce(bellman::LcFn a, bellman::LcFn b, bellman::LcFn c) override;
 };
 
 struct ProveTimings { float synthesis_ms, h_poly_ms, msm_ms, total_ms; };

@@ -61,7 +61,9 @@ __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lan
   return true;
 }
 
-template <class F>
+// LDS_ACC: the running bucket sum lives in the lane's LDS slot instead of 48/96 VGPRs - for G2 this
+// is the difference between spilling at one wave per SIMD and fitting two.
+template <class F, bool LDS_ACC>
 __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const u32 *zstart,
                                                              const Affine<F> *bases, XYZZ<F> *pts,
                                                              XYZZ<F> *head, XYZZ<F> *tail, u32 n, u32 c,
@@ -71,9 +73,11 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   const u64 *src = pairs + (u64)w * n;
   ChunkView v;
   if (lane >= chunks_per_window || !chunk_view(src, n, zstart[w], lane, K, v)) return;
-  XYZZ<F> *bucket = pts + ((u64)w << c);
+  XYZZ<F> *bucket = pts + ((u64)w << (c - 1)) - 1;   // bucket[d], d = |digit| in [1, 2^(c-1)]
   const u64 slot = (u64)w * chunks_per_window + lane;
-  XYZZ<F> acc;
+  __shared__ XYZZ<F> lds_acc[LDS_ACC ? 128 : 1];
+  XYZZ<F> reg_acc;
+  XYZZ<F> &acc = LDS_ACC ? lds_acc[threadIdx.x] : reg_acc;
   xyzz_set_identity(acc);
   u32 cur = v.d_first;
   bool saw_identity = false;
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
       xyzz_set_identity(acc);
       cur = d;
     }
-    const Affine<F> q = bases[(u32)e];
+    Affine<F> q = bases[(u32)e & 0x7fffffffu];
     if (aff_is_identity(q)) { saw_identity = true; continue; }
+    if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
     xyzz_madd(acc, q);
   }
   if (cur == v.d_first && v.head_partial) head[slot] = acc;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
       return;
     }
   }
-  pts[((u64)w << c) + d] = acc;
+  pts[((u64)w << (c - 1)) + d - 1] = acc;
 }
 
 // shuffle-based tree reduction of per-lane points over groups of G consecutive lanes
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
     if (tid < 64) {
       if (tid < LONG_THREADS / 64) acc = wave_part[tid]; else xyzz_set_identity(acc);
       group_reduce_points<F>(acc, LONG_THREADS / 64);
-      if (tid == 0) pts[((u64)lr.w << c) + lr.d] = acc;
+      if (tid == 0) pts[((u64)lr.w << (c - 1)) + lr.d - 1] = acc;
     }
     __syncthreads();
   }
@@ -216,15 +221,20 @@ struct SumJob {
   SumDesc d;
   u32 nblocks;   // 64-lane blocks assigned to this job
 };
-// two independent reductions per launch (rows + columns, then both bit-sum sets): they are
-// latency-bound, so sharing a launch lets the hardware overlap them.
+// up to three independent reductions per launch (rows + columns, then the bit-sum sets and the
+// plain window totals): they are latency-bound, so sharing a launch lets the hardware overlap them.
 template <class F>
-__global__ __launch_bounds__(64) void msm_sum_kernel(SumJob<F> j0, SumJob<F> j1) {
-  const bool second = blockIdx.x >= j0.nblocks;
-  const SumDesc d = second ? j1.d : j0.d;
-  const XYZZ<F> *in = second ? j1.in : j0.in;
-  XYZZ<F> *out = second ? j1.out : j0.out;
-  const u32 blk = second ? blockIdx.x - j0.nblocks : blockIdx.x;
+struct SumJobs {
+  SumJob<F> j[3];
+};
+template <class F>
+__global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
+  u32 blk = blockIdx.x;
+  u32 which = 0;
+  if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
+  const SumDesc d = jobs.j[which].d;
+  const XYZZ<F> *in = jobs.j[which].in;
+  XYZZ<F> *out = jobs.j[which].out;
   const u32 G = d.lanes;
   const u32 g = (blk * 64 + threadIdx.x) / G;
   const u32 sub = threadIdx.x & (G - 1);
@@ -294,9 +304,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                        u64 n, int fmt, const u64 *density_dev, unsigned forced_c) {
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
-  const MsmPlan p = make_plan(n, forced_c & 0xffu, forced_c >> 8);
+  const MsmPlan p = make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu);
+  // accumulator placement: bit 24 of the tuning word forces registers, bit 25 forces LDS
+  const bool lds_acc = (forced_c & (1u << 25)) ? true : (forced_c & (1u << 24)) ? false : (F::WORDS == 24);
   job.plan = p;
   if ((u64)p.W * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
+  if (n_bases >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;        // base index shares its word with the sign bit
   auto alloc = [&](size_t bytes) -> void * {
     void *ptr = c.pool.acquire(bytes);
     if (ptr) job.dev_allocs.push_back(ptr);
@@ -315,11 +328,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   XYZZ<F> *head = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
   XYZZ<F> *tail = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
   // serial walk bound: 4x the average number of chunks per bucket, at least 8
-  const u32 walk = std::max<u32>(8, 4 * ((p.n >> p.c) / p.chunk + 1));
+  const u32 walk = std::max<u32>(8, 4 * ((p.n >> (p.c - 1)) / p.chunk + 1));
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
   LongRun *long_runs = (LongRun *)alloc((u64)max_long * sizeof(LongRun));
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
   XYZZ<F> *rowcol = (XYZZ<F> *)alloc((u64)p.W * (H + Lw) * sizeof(XYZZ<F>));
+  // per window: (c-1) bit sums U[w][p] followed by W plain totals T[w]
   XYZZ<F> *bits = (XYZZ<F> *)alloc((u64)p.W * p.c * sizeof(XYZZ<F>));
   b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
   b.word_prefix = nullptr;
@@ -345,8 +359,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
   {
     const dim3 grid((p.chunks_per_window + 127) / 128, p.W);
-    hipLaunchKernelGGL(msm_accumulate_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart,
-                       (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    if (lds_acc)
+      hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart,
+                         (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    else
+      hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart,
+                         (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
     BH_HIP_CHECK(hipGetLastError());
     BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
     hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
@@ -374,19 +392,26 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     return j;
   };
   {
+    const u32 cb = p.c - 1;   // bits of a bucket index
     SumDesc dr, dc;
-    dr.mode = SUM_STRIDED; dr.groups = p.W * H; dr.count = Lw; dr.inner = H; dr.stride = 1; dr.istride = Lw; dr.group_shift = p.c;
+    dr.mode = SUM_STRIDED; dr.groups = p.W * H; dr.count = Lw; dr.inner = H; dr.stride = 1; dr.istride = Lw; dr.group_shift = cb;
     dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
-    SumJob<F> j0 = make_job(pts, rows, dr), j1 = make_job(pts, cols, dc);
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(j0.nblocks + j1.nblocks), dim3(64), 0, st, j0, j1);
+    SumJobs<F> js;
+    js.j[0] = make_job(pts, rows, dr); js.j[1] = make_job(pts, cols, dc); js.j[2] = js.j[1]; js.j[2].nblocks = 0;
+    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
-    // U[w][p]: p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi)
-    SumDesc bl, bh_;
+    // sum_idx (idx+1) B[idx] = sum_p 2^p U[p] + T, idx = hi*2^l + lo:
+    //   U[w][p], p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi),
+    //   T[w] = plain sum of all buckets = sum of the row sums.
+    SumDesc bl, bh_, bt;
     bl.mode = SUM_BITS; bl.stride = 1; bl.istride = 0;
     bl.groups = p.W * p.lo_bits; bl.count = Lw; bl.inner = std::max(1u, p.lo_bits); bl.group_shift = p.lo_bits;
-    bh_ = bl; bh_.groups = p.W * p.hi_bits; bh_.count = H; bh_.inner = p.hi_bits; bh_.group_shift = p.hi_bits;
-    j0 = make_job(cols, bits, bl); j1 = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(j0.nblocks + j1.nblocks), dim3(64), 0, st, j0, j1);
+    bh_ = bl; bh_.groups = p.W * p.hi_bits; bh_.count = H; bh_.inner = std::max(1u, p.hi_bits); bh_.group_shift = p.hi_bits;
+    bt.mode = SUM_STRIDED; bt.groups = p.W; bt.count = H; bt.inner = 1; bt.stride = 1; bt.istride = 0; bt.group_shift = p.hi_bits;
+    js.j[0] = make_job(cols, bits, bl);
+    js.j[1] = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
+    js.j[2] = make_job(rows, bits + (u64)p.W * cb, bt);
+    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
   }
   BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
@@ -402,8 +427,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
 template <> struct HostOf<FpOps> { typedef HostFpOps type; };
 template <> struct HostOf<Fp2Ops> { typedef HostFp2Ops type; };
 
-// host tail: result = sum_w sum_p 2^(c*w + p) U[w][p]
-//   bits layout: [W][lo_bits] column-bit sums, then [W][hi_bits] row-bit sums
+// host tail: result = sum_w 2^(c*w) (sum_p 2^p U[w][p] + T[w])
+//   bits layout: [W][lo_bits] column-bit sums, [W][hi_bits] row-bit sums, [W] window totals
 template <class F>
 static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, void *out_dev_layout) {
   typedef typename HostOf<F>::type H;   // 64-bit-limb host arithmetic, identical record layout
@@ -411,14 +436,23 @@ static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, void
   const XYZZ<H> *bits = reinterpret_cast<const XYZZ<H> *>(bits_dev_layout);
   XYZZ<H> acc;
   xyzz_set_identity(acc);
-  const XYZZ<H> *lo = bits, *hi = bits + (size_t)p.W * p.lo_bits;
+  const u32 cb = p.c - 1;
+  const XYZZ<H> *lo = bits, *hi = bits + (size_t)p.W * p.lo_bits, *tot = bits + (size_t)p.W * cb;
   for (int w = (int)p.W - 1; w >= 0; w--) {
     for (int b = (int)p.c - 1; b >= 0; b--) {
       XYZZ<H> t;
       xyzz_dbl(t, acc);
-      const XYZZ<H> &u = (b >= (int)p.lo_bits) ? hi[(size_t)w * p.hi_bits + (b - p.lo_bits)]
-                                               : lo[(size_t)w * p.lo_bits + b];
-      xyzz_add(acc, t, u);
+      acc = t;
+      if (b < (int)cb) {
+        const XYZZ<H> &u = (b >= (int)p.lo_bits) ? hi[(size_t)w * p.hi_bits + (b - p.lo_bits)]
+                                                 : lo[(size_t)w * p.lo_bits + b];
+        xyzz_add(t, acc, u);
+        acc = t;
+      }
+      if (b == 0) {   // the "+1" of the bucket weights
+        xyzz_add(t, acc, tot[w]);
+        acc = t;
+      }
     }
   }
   Affine<H> res;   // caller buffers carry no alignment guarantee: go through an aligned local

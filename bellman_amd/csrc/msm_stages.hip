@@ -122,9 +122,15 @@ __global__ void msm_digits_kernel(const void *scalars, int fmt, u32 n, const u64
   }
   fr_t s;
   if (live) load_scalar(scalars, i, fmt, s);
+  // signed-digit recoding, low to high with carry; pair = |d| << 32 | sign << 31 | base index
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
   for (u32 w = 0; w < W; w++) {
-    u32 d = live ? extract_bits(s, w * c, c) : 0;
-    pairs[(u64)w * n + i] = ((u64)d << 32) | (u32)k;
+    u32 v = (live ? extract_bits(s, w * c, c) : 0) + carry;
+    u32 neg = 0;
+    carry = 0;
+    if (v > half) { v = (1u << c) - v; neg = (v != 0); carry = 1; }
+    pairs[(u64)w * n + i] = ((u64)v << 32) | ((u64)neg << 31) | ((u32)k & 0x7fffffffu);
   }
 }
 
@@ -217,11 +223,14 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   if (c > 16) c = 16;
   if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
   p.c = (u32)c;
-  p.W = (255 + p.c - 1) / p.c;          // (0..NUM_BITS).step_by(c), multiexp.rs:288-290
-  p.nb = 1u << p.c;
+  // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
+  // applied to the base (y -> -y) when it is loaded.  ceil(256/c) windows always leave room for
+  // the final carry (the top window holds < 2^(c-1) because scalars are < 2^255).
+  p.W = (256 + p.c - 1) / p.c;
+  p.nb = 1u << (p.c - 1);
   p.NB = p.W * p.nb;
-  p.lo_bits = p.c / 2;
-  p.hi_bits = p.c - p.lo_bits;
+  p.lo_bits = (p.c - 1) / 2;
+  p.hi_bits = (p.c - 1) - p.lo_bits;
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
   p.chunk = forced_chunk ? forced_chunk : 32;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;

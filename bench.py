@@ -59,6 +59,67 @@ G1_GEN_MONT = np.array(  # BLS12-381 G1 generator, Montgomery limbs (x | y)
 )
 
 
+G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1 | y.c0 | y.c1)
+    [0xF5F28FA202940A10, 0xB3F5FB2687B4961A, 0xA1A893B53E2AE580, 0x9894999D1A3CAEE9, 0x6F67B7631863366B, 0x058191924350BCD7,
+     0xA5A9C0759E23F606, 0xAAA0C59DBCCD60C3, 0x3BB17E18E2867806, 0x1B1AB6CC8541B367, 0xC2B6ED0EF2158547, 0x11922A097360EDF3,
+     0x4C730AF860494C4A, 0x597CFA1F5E369C5A, 0xE7E6856CAA0A635A, 0xBBEFB5E96E0D495F, 0x07D3A975F0EF25A2, 0x0083FD8E7E80DAE5,
+     0xADC0FC92DF64B05D, 0x18AA270A2B1461DC, 0x86ADAC6A3BE4EBA0, 0x79495C4EC93DA33A, 0xE7175850A43CCAED, 0x0B2BC2A163DE1BF2],
+    dtype=np.uint64,
+)
+
+
+def bench_create_proof(worker, lib, log_n, proofs=3):
+    """BASELINE config C4: groth16::create_proof on a synthetic 2^log_n-constraint R1CS (the C++
+    chain circuit of groth16.cpp), synthetic CRS generated on the device by the product's
+    fixed-base kernel (distinct prime-order points; not a trusted setup - timing only)."""
+    from bellman_amd import groth16 as pg
+
+    rounds = (1 << log_n) - 3
+    n_aux = rounds + 1
+    nb = (rounds + 1) // 2 + 2
+
+    def gen(group, n, seed):
+        words = 12 if group == 1 else 24
+        t = splitmix_scalars(n, seed)
+        dt, dout = worker.alloc(n * 32), worker.alloc(n * 8 * words)
+        worker.upload(dt, t)
+        g = G1_GEN_MONT if group == 1 else G2_GEN_MONT
+        assert lib.bh_fixed_base_mul_dev(worker.ctx, group, g.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+        worker.synchronize()
+        out = np.empty((n, words), dtype=np.uint64)
+        worker.download(out, dout)
+        worker.free(dt)
+        worker.free(dout)
+        return out
+
+    h, l = gen(1, (1 << log_n) - 1, 11), gen(1, n_aux, 12)
+    a, b1, b2 = gen(1, n_aux + 2, 13), gen(1, nb, 14), gen(2, nb, 15)
+    vk1, vk2 = gen(1, 3, 16), gen(2, 2, 17)
+    params = pg.Parameters(worker, vk1[0], vk1[1], vk2[0], vk1[2], vk2[1], h, l, a, b1, b2)
+    tms = []
+    for i in range(proofs + 1):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        pg.create_proof_demo(params, 1, rounds, 2020 + i, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
+        wall = (time.perf_counter() - t0) * 1e3
+        if i:
+            tms.append(tm + [wall])
+    params.release()
+    m = np.mean(np.array(tms), axis=0)
+    gpu_part = float(m[1] + m[2])
+    return {
+        "workload": "groth16::create_proof, synthetic multiplicative-chain R1CS, 2^%d constraints, 1 public input "
+                    "(BASELINE.json configs[3]): 7 FFTs + fused quotient, 4 large G1 + 1 large G2 multiexp (+3 small)" % log_n,
+        "proofs_per_s": round(1e3 / float(m[4]), 3),
+        "ms_total": round(float(m[4]), 2),
+        "ms_host_synthesis": round(float(m[0]), 2),
+        "ms_h_block_incl_upload": round(float(m[1]), 2),
+        "ms_multiexps": round(float(m[2]), 2),
+        "proofs_per_s_excluding_host_synthesis": round(1e3 / (float(m[4]) - float(m[0])), 3),
+        "samples": proofs,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proof", action="store_true", help="skip the create_proof (config C4) measurement")
+    ap.add_argument("--proof-log-n", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -197,6 +260,17 @@ def main():
                 "sample": "same 2^%d-term G1 MSM, 1 run, C restatement of bellman's rayon path "
                           "(c=%d, %d window tasks, %d host threads available)" % (args.log_n, c_ref, windows, threads),
             }
+        if not args.no_proof and not distributed:
+            out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n)
+        # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of
+        # this same command (profiles/r1_pmc_accumulate.json), if it matches this workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_accumulate.json")))
+            if pmc.get("log_n") == args.log_n:
+                out["roofline"]["traffic"] = int((pmc["FETCH_SIZE"]["per_launch_kb_mean"] + pmc["WRITE_SIZE"]["per_launch_kb_mean"]) * 1024)
+                out["roofline"]["traffic_note"] = "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB x 1024 from profiles/r1_pmc_*; read side uncorrected (lower bound)"
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -182,7 +182,7 @@ def test_h_poly_pipeline(worker, n_evals):
 # ------------------------------------------------------------------------------ MSM stages
 @pytest.mark.parametrize("n,c", [(1, 4), (100, 4), (5000, 7), (70000, 11), (1 << 17, 16)])
 def test_msm_sort_stages(worker, n, c):
-    """digits + stable radix sort + zero-digit count against numpy."""
+    """signed digits + stable radix sort + zero-digit count against numpy."""
     from bellman_amd import _lib
 
     lib = _lib.load()
@@ -190,19 +190,33 @@ def test_msm_sort_stages(worker, n, c):
     if n > 10:
         sc[3] = 0
         sc[4] = sc[5]
-    W = (255 + c - 1) // c
-    nb = 1 << c
+    W = (256 + c - 1) // c
+    half = 1 << (c - 1)
     pairs = np.zeros(W * n, dtype=np.uint64)
     zstart = np.zeros(W, dtype=np.uint32)
     assert lib.bh_test_msm_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(zstart)) == 0
-    ints = np.array(cref.arr_to_ints(sc), dtype=object)
+    ints = cref.arr_to_ints(sc)
+    # signed-digit recoding: d in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) == scalar
+    mags = np.zeros((W, n), dtype=np.uint64)
+    negs = np.zeros((W, n), dtype=np.uint64)
+    for i, v in enumerate(ints):
+        carry, acc = 0, 0
+        for w in range(W):
+            d = ((v >> (c * w)) & ((1 << c) - 1)) + carry
+            carry = 0
+            if d > half:
+                d -= 1 << c
+                carry = 1
+            acc += d << (c * w)
+            mags[w, i], negs[w, i] = abs(d), 1 if d < 0 else 0
+        assert carry == 0 and acc == v
+    idx = np.arange(n, dtype=np.uint64)
     for w in range(W):
-        digits = np.array([(int(v) >> (c * w)) & (nb - 1) for v in ints], dtype=np.uint64)
-        order = np.argsort(digits, kind="stable")
-        want = (digits[order] << np.uint64(32)) | order.astype(np.uint64)
+        order = np.argsort(mags[w], kind="stable")
+        want = (mags[w][order] << np.uint64(32)) | (negs[w][order] << np.uint64(31)) | idx[order]
         got = pairs[w * n : (w + 1) * n]
         assert np.array_equal(got, want), (w,)
-        assert zstart[w] == int((digits == 0).sum())
+        assert zstart[w] == int((mags[w] == 0).sum())
 
 
 # ------------------------------------------------------------------------------ MSM

@@ -34,7 +34,7 @@ def main():
     for c in cs:
         for k in ks:
             lib.bh_msm_set_window_bits(w.ctx, c)
-            lib.bh_msm_set_chunk(w.ctx, k)
+            lib.bh_msm_set_chunk(w.ctx, k | (int(os.environ.get('BH_ACC', '0')) << 16))
             best = None
             for it in range(4):
                 r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
