@@ -212,26 +212,6 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
     log_m++;
     if (log_m >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
   }
-  // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
-  // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
-  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
-  {
-    std::vector<Fr> pad(m, Fr::zero());
-    const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
-    void *dst[3] = {da.p, db.p, dc.p};
-    for (int i = 0; i < 3; i++) {
-      memcpy(pad.data(), src[i]->data(), n_cons * sizeof(Fr));
-      check(bh_dev_upload(ctx, dst[i], pad.data(), m * 32));
-    }
-  }
-  BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);
-  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, nullptr));
-  BH_TRACE("h poly done");
-  const double t1 = now_ms();
-  bh_msm_job *h_job = nullptr;
-  check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244
-
-  BH_TRACE("h msm issued");
   // assignments: uploaded once, shared by seven multiexps (prover.rs:248-318)
   const size_t n_in = prover.input_assignment.size(), n_aux = prover.aux_assignment.size();
   DevBuf d_in(ctx, n_in * 32 + 32), d_aux(ctx, n_aux * 32 + 32);
@@ -261,6 +241,28 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   check(bh_msm_async_dev(ctx, params.b_g2, 0, d_in.p, n_in, BH_SCALARS_MONT, (const uint64_t *)dens_b_in->p, n_in, &b2_in_job));
   check(bh_msm_async_dev(ctx, params.b_g2, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_b_aux->p, n_aux,
                          &b2_aux_job));
+
+  // The seven multiexps above only need the assignments, so they are already running on their own
+  // streams while the h block below uploads a/b/c and runs its FFTs (the reference issues h first,
+  // prover.rs:221-245; the order of issue is unobservable, the order of waits is kept).
+  // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
+  // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
+  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
+  {
+    std::vector<Fr> pad(m, Fr::zero());
+    const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
+    void *dst[3] = {da.p, db.p, dc.p};
+    for (int i = 0; i < 3; i++) {
+      memcpy(pad.data(), src[i]->data(), n_cons * sizeof(Fr));
+      check(bh_dev_upload(ctx, dst[i], pad.data(), m * 32));
+    }
+  }
+  BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);
+  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, nullptr));
+  BH_TRACE("h poly done");
+  const double t1 = now_ms();
+  bh_msm_job *h_job = nullptr;
+  check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
   // every job must be waited on (it owns device resources), even when an earlier one fails

@@ -113,11 +113,34 @@ def bench_create_proof(worker, lib, log_n, proofs=3):
         "proofs_per_s": round(1e3 / float(m[4]), 3),
         "ms_total": round(float(m[4]), 2),
         "ms_host_synthesis": round(float(m[0]), 2),
-        "ms_h_block_incl_upload": round(float(m[1]), 2),
-        "ms_multiexps": round(float(m[2]), 2),
+        "ms_issue_7_multiexps_then_h_block_incl_uploads": round(float(m[1]), 2),
+        "ms_h_multiexp_and_waits": round(float(m[2]), 2),
         "proofs_per_s_excluding_host_synthesis": round(1e3 / (float(m[4]) - float(m[0])), 3),
         "samples": proofs,
     }
+
+
+def bench_fft(worker, lib, log_n=22, iters=10):
+    """BASELINE config C3: 2^22-point radix-2 FFT / iFFT / coset variants, vector resident in HBM."""
+    n = 1 << log_n
+    data = splitmix_scalars(n, 3)
+    d = worker.alloc(n * 32)
+    worker.upload(d, data)
+    out = {"workload": "EvaluationDomain fft/ifft/coset_fft/icoset_fft, 2^%d Fr elements resident in HBM "
+                       "(BASELINE.json configs[2])" % log_n, "algorithmic_bytes_per_element": 64}
+    for mode, name in [(0, "fft"), (1, "ifft"), (2, "coset_fft"), (3, "icoset_fft")]:
+        for _ in range(2):
+            assert lib.bh_fft_fr_dev(worker.ctx, d, log_n, mode, None) == 0
+        worker.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            lib.bh_fft_fr_dev(worker.ctx, d, log_n, mode, None)
+        worker.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[name] = {"ms": round(dt * 1e3, 4), "algorithmic_GBps": round(64.0 * n / dt / 1e9, 1),
+                     "frac_of_8TBps": round(64.0 * n / dt / 8e12, 4), "Gbutterflies_per_s": round(n / 2 * log_n / dt / 1e9, 1)}
+    worker.free(d)
+    return out
 
 
 def main():
@@ -261,6 +284,7 @@ def main():
                           "(c=%d, %d window tasks, %d host threads available)" % (args.log_n, c_ref, windows, threads),
             }
         if not args.no_proof and not distributed:
+            out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of
         # this same command (profiles/r1_pmc_accumulate.json), if it matches this workload
