@@ -377,12 +377,20 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
   // G lanes per output chosen so that each launch is about one wavefront per SIMD.
   XYZZ<F> *rows = rowcol, *cols = rowcol + (u64)p.W * H;
+  // lanes per output: minimise (serial adds per lane + tree depth) x (waves per SIMD, at least 1);
+  // these kernels are latency-bound chains of point additions, not throughput-bound.
   auto pick_lanes = [&](u32 groups, u32 count) {
-    u32 g = 64;
-    const u64 target = (u64)c.num_cus * 4 * 64 * 2;   // about two waves per SIMD
-    while (g > 4 && (u64)groups * g > target) g >>= 1;
-    while (g > 1 && g > count) g >>= 1;
-    return g;
+    const double simds = (double)c.num_cus * 4;
+    u32 best = 1;
+    double best_cost = 1e30;
+    for (u32 g = 1, lg = 0; g <= 64; g <<= 1, lg++) {
+      if (g > count && g > 1) break;
+      const double steps = (double)((count + g - 1) / g) + lg;
+      const double waves = (double)groups * g / 64.0;
+      const double cost = steps * std::max(1.0, waves / simds);
+      if (cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return best;
   };
   auto make_job = [&](const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) {
     SumJob<F> j;

@@ -218,10 +218,12 @@ static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
 MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   MsmPlan p;
   p.n = (u32)n;
-  int c = (int)ilog2(n ? n : 1) - 4;   // average bucket ~16 entries; tuned on MI355X (tools/tune_msm.py)
+  // Window size from the MI355X sweep (profiles/r1_tune_small_sizes.txt, r1_tune_c_K_sweep.txt):
+  // sizes whose top window is not a sliver (256 = 32*8 = 16*16, 20*13 leaves 9 bits) avoid a
+  // few huge buckets; larger c trades bucket-reduction work against accumulation passes.
+  const u32 lg = ilog2(n ? n : 1);
+  int c = lg <= 13 ? 8 : lg <= 17 ? 13 : 16;
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
   // applied to the base (y -> -y) when it is loaded.  ceil(256/c) windows always leave room for
@@ -232,7 +234,9 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   p.lo_bits = (p.c - 1) / 2;
   p.hi_bits = (p.c - 1) - p.lo_bits;
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
-  p.chunk = forced_chunk ? forced_chunk : 32;
+  // K entries per lane: 32 once the chip is full, fewer for small problems so that the serial chain
+  // per lane shrinks instead of leaving SIMDs idle (same sweep)
+  p.chunk = forced_chunk ? forced_chunk : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
   return p;
