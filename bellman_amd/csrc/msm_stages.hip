@@ -223,7 +223,7 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   // few huge buckets; larger c trades bucket-reduction work against accumulation passes.
   const u32 lg = ilog2(n ? n : 1);
   int c = lg <= 13 ? 8 : lg <= 17 ? 13 : 16;
-  if (c < 4) c = 4;
+  if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
   // applied to the base (y -> -y) when it is loaded.  ceil(256/c) windows always leave room for
