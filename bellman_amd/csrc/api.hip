@@ -105,14 +105,16 @@ uint32_t bh_ctx_log_num_cus(const bh_ctx *ctx) {
   while ((1u << (p + 1)) <= (uint32_t)ctx->c.num_cus) p++;
   return p;
 }
+// served from the context's size-bucketed pool: hipMalloc / hipFree synchronise the device and a
+// prover allocates the same handful of vectors for every proof
 int bh_dev_alloc(bh_ctx *ctx, size_t bytes, void **dev_ptr) {
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  BH_HIP_CHECK(hipMalloc(dev_ptr, bytes ? bytes : 16));
-  return BH_OK;
+  *dev_ptr = ctx->c.pool.acquire(bytes);
+  return *dev_ptr ? BH_OK : BH_ERR_HIP;
 }
 int bh_dev_free(bh_ctx *ctx, void *dev_ptr) {
-  (void)ctx;
-  BH_HIP_CHECK(hipFree(dev_ptr));
+  // callers free after synchronising on the work that used the buffer (bh_msm_wait / bh_ctx_synchronize)
+  ctx->c.pool.release(dev_ptr);
   return BH_OK;
 }
 int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
@@ -256,7 +258,7 @@ size_t bh_bases_len(const bh_bases *b) { return b->n; }
 // ---- multiexp -----------------------------------------------------------------------------------
 int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c) {
   (void)ctx;
-  g_forced_c.store((g_forced_c.load() & ~0xffu) | (c & 0xffu));
+  g_forced_c.store((g_forced_c.load() & ~0xffu) | (c & 0xffu));   // c <= 24
   return BH_OK;
 }
 int bh_msm_set_chunk(bh_ctx *ctx, unsigned k) {

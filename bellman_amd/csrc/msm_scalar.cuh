@@ -11,7 +11,7 @@ __device__ __forceinline__ void load_scalar(const void *scalars, u64 i, int fmt,
   if (fmt == BH_SCALARS_MONT) fe_from_mont(s, s);
 }
 __device__ __forceinline__ u32 extract_bits(const fr_t &s, u32 lo, u32 width) {
-  // bits [lo, lo+width) of the 256-bit little-endian value (width <= 16)
+  // bits [lo, lo+width) of the 256-bit little-endian value (width <= 31)
   if (lo >= 256) return 0;
   u32 w = lo >> 5, sh = lo & 31;
   u64 two = s.l[w];

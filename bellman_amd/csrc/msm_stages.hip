@@ -223,7 +223,7 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   // few huge buckets; larger c trades bucket-reduction work against accumulation passes.
   const u32 lg = ilog2(n ? n : 1);
   int c = lg <= 13 ? 8 : lg <= 17 ? 13 : 16;
-  if (forced_c) c = (int)std::min(16u, std::max(2u, forced_c));
+  if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
   // applied to the base (y -> -y) when it is loaded.  ceil(256/c) windows always leave room for
@@ -237,6 +237,8 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   // K entries per lane: 32 once the chip is full, fewer for small problems so that the serial chain
   // per lane shrinks instead of leaving SIMDs idle (same sweep)
   p.chunk = forced_chunk ? forced_chunk : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
+  // never let a typical bucket span many chunks: the chunk merge is serial per bucket
+  if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, n >> (p.c - 1));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
   return p;

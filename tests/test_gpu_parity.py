@@ -291,6 +291,35 @@ def test_msm_density_skip_and_montgomery_scalars(worker, group):
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_bases_register_rust_struct_layout(worker, group):
+    """bh_bases_register with a record stride and an `infinity` flag byte: the in-memory layout of
+    bls12_381's G1Affine/G2Affine { x, y, infinity: Choice }.  A flagged record is
+    the identity whatever its coordinate bytes say."""
+    import bellman_amd
+    from bellman_amd import UnexpectedIdentity
+
+    n = 500
+    w = 12 if group == 1 else 24
+    rec = w * 8
+    stride = rec + 8
+    bases = cref.gen_bases(group, n, a=21, b=2)
+    raw = np.zeros((n, stride), dtype=np.uint8)
+    raw[:, :rec] = bases.view(np.uint8).reshape(n, rec)
+    raw[:, rec + 1 :] = 0xAB  # padding garbage
+    raw[77, rec] = 1  # identity flag set on a record that still carries coordinates
+    sc = _scalars(n, 23)
+    hb = bellman_amd.Bases(worker, group, raw, stride=stride, inf_offset=rec)
+    with pytest.raises(UnexpectedIdentity):
+        bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    sc[77] = 0  # an identity under a zero scalar is skipped (multiexp.rs:245)
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    ref_bases = bases.copy()
+    ref_bases[77] = 0
+    rc, want = cref.multiexp(group, ref_bases, 0, None, sc)
+    assert rc == 0 and np.array_equal(got, want)
+
+
 def test_msm_skewed_scalars_split_buckets(worker):
     """All scalars equal / boolean-heavy witnesses: exercises the split-bucket path."""
     import bellman_amd
