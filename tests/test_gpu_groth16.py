@@ -142,3 +142,42 @@ def test_create_proof_error_paths(worker):
     short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l[:-1], a, b1, b2)
     with pytest.raises(UnexpectedEof):
         pg.create_proof_demo(short, 1, rounds, seed, [x0], None, 5, 6)
+
+
+def test_golden_fixtures_on_device(worker):
+    """tests/golden/bls12_381_small.json (frozen pyref outputs): FFT x4, MSM G1/G2 with density + skip,
+    and a 3-round MiMC proof, all through the C ABI."""
+    import json
+    import os
+
+    import bellman_amd
+    from bellman_amd import _lib
+    from bellman_amd import groth16 as pg
+
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bls12_381_small.json")))
+    ints = lambda xs: [int(x, 16) for x in xs]  # noqa: E731
+    lib = _lib.load()
+    mont = cref.fr_to_mont(cref.ints_to_arr(ints(G["fft8"]["input"]), 4))
+    for mode, name in enumerate(("fft", "ifft", "coset_fft", "icoset_fft")):
+        buf = mont.copy()
+        assert lib.bh_fft_fr(worker.ctx, buf.ctypes.data_as(__import__("ctypes").c_void_p), 3, mode) == 0
+        assert cref.arr_to_ints(cref.fr_from_mont(buf)) == ints(G["fft8"][name]), name
+    for gname, group in (("g1", 1), ("g2", 2)):
+        m = G["msm_" + gname]
+        gen = cref.g1_generator() if group == 1 else cref.g2_generator()
+        bases = np.stack([cref.point_mul(group, gen, k) for k in ints(m["base_scalars"])])
+        hb = bellman_amd.Bases(worker, group, bases)
+        got = bellman_amd.multiexp(worker, hb, bellman_amd.DensityTracker(m["density"]), cref.ints_to_arr(ints(m["scalars"]), 4),
+                                   skip=m["skip"]).wait()
+        pt = (cref.g1_to_py if group == 1 else cref.g2_to_py)(got)[0]
+        want = m["result"]
+        flat = lambda p: [int(x, 16) for x in (p if group == 1 else p[0] + p[1])]  # noqa: E731
+        assert (list(pt) if group == 1 else list(pt[0]) + list(pt[1])) == flat(want)
+    m = G["mimc3_proof"]
+    cons, xl, xr, r, s = ints(m["constants"]), int(m["xl"], 16), int(m["xr"], 16), int(m["r"], 16), int(m["s"], 16)
+    p = generate_parameters(CBls12, circuits.mimc_circuit(0, 0, cons), CBls12.G1.gen, CBls12.G2.gen, **m["toxic"])
+    pp = _product_params(worker, p)
+    for proof in (pg.create_proof(circuits.mimc_circuit(xl, xr, cons), pp, r, s), pg.create_proof_demo(pp, 0, 3, 0, [xl, xr], cons, r, s)):
+        a, b, c = cref.g1_to_py(proof.a)[0], cref.g2_to_py(proof.b)[0], cref.g1_to_py(proof.c)[0]
+        assert [hex(a[0]), hex(a[1])] == m["a"] and [hex(c[0]), hex(c[1])] == m["c"]
+        assert [[hex(b[0][0]), hex(b[0][1])], [hex(b[1][0]), hex(b[1][1])]] == m["b"]
