@@ -118,11 +118,13 @@ int bh_dev_free(bh_ctx *ctx, void *dev_ptr) {
   return BH_OK;
 }
 int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));   // entry points may be called from any host thread
   BH_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
   BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   return BH_OK;
 }
 int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   BH_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
   BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   return BH_OK;
@@ -137,6 +139,7 @@ int bh_ctx_synchronize(bh_ctx *ctx) {
 int bh_fft_fr_dev(bh_ctx *ctx, void *data_dev, uint32_t log_n, int mode, void *stream) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
   if (mode < 0 || mode > 3) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   hipStream_t st = pick_stream(ctx, stream);
   void *scratch = nullptr;
   if (log_n > 10) {
@@ -179,6 +182,7 @@ int bh_fr_distribute_powers_dev(bh_ctx *ctx, void *a, size_t n, const void *g_ho
 }
 int bh_h_poly_fr_dev(bh_ctx *ctx, void *a, void *b, void *c, uint32_t log_n, void *stream) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   hipStream_t st = pick_stream(ctx, stream);
   void *scratch = ctx->c.pool.acquire(sizeof(fr_t) << log_n);
   if (!scratch) return BH_ERR_HIP;

@@ -125,20 +125,22 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
     }
     return;
   }
+  // ordered so that at most four temporaries are live at once (PP and PPP die early): the G2
+  // instantiation is register-bound
   F::sqr(pp, p);
-  F::mul(ppp, p, pp);
-  F::mul(qq, acc.x, pp);   // Q = X1*PP
+  F::mul(ppp, p, pp);                 // p dead
+  F::mul(qq, acc.x, pp);              // Q = X1*PP
+  F::mul(acc.zz, acc.zz, pp);         // ZZ3 = ZZ1*PP          (pp dead)
+  F::mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1*PPP
   F::sqr(t, r);
   F::sub(t, t, ppp);
   F::sub(t, t, qq);
-  F::sub(t, t, qq);        // X3 = R^2 - PPP - 2Q
+  F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
+  F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
   F::sub(qq, qq, t);
-  F::mul(qq, r, qq);       // R*(Q - X3)
-  F::mul(acc.y, acc.y, ppp);
-  F::sub(acc.y, qq, acc.y);
+  F::mul(qq, r, qq);                  // R*(Q - X3)            (r dead)
+  F::sub(acc.y, qq, ppp);
   acc.x = t;
-  F::mul(acc.zz, acc.zz, pp);
-  F::mul(acc.zzz, acc.zzz, ppp);
 }
 
 // add-2008-s: r = a + b (general)
@@ -168,22 +170,23 @@ BH_HD void xyzz_add(XYZZ<F> &r, const XYZZ<F> &a, const XYZZ<F> &b) {
     }
     return;
   }
+  // (r may alias a: every read of a.x / a.y / b.x / b.y happened above; zz / zzz are read here)
   F::sqr(pp, p);
-  F::mul(ppp, p, pp);
-  F::mul(q, u1, pp);
+  F::mul(ppp, p, pp);                 // p dead
+  F::mul(q, u1, pp);                  // u1 dead
+  F::mul(t, a.zz, b.zz);
+  F::mul(r.zz, t, pp);                // pp dead
+  F::mul(t, a.zzz, b.zzz);
+  F::mul(r.zzz, t, ppp);
   F::sqr(t, rr);
   F::sub(t, t, ppp);
   F::sub(t, t, q);
-  F::sub(t, t, q);         // X3
+  F::sub(t, t, q);                    // X3
+  F::mul(s1, s1, ppp);                // ppp dead
   F::sub(q, q, t);
   F::mul(q, rr, q);
-  F::mul(s1, s1, ppp);
   F::sub(r.y, q, s1);
   r.x = t;
-  F::mul(t, a.zz, b.zz);
-  F::mul(r.zz, t, pp);
-  F::mul(t, a.zzz, b.zzz);
-  F::mul(r.zzz, t, ppp);
 }
 
 // XYZZ -> affine (one field inversion): x = X/ZZ, y = Y/ZZZ
