@@ -12,9 +12,10 @@
 // Structure (MI355X-first): n = R_0 * R_1 * ... * R_{L-1} (R_p = 2^r_p <= 256, L <= 4).
 // Pass p transforms, for every already-fixed prefix, the R_p-point sub-FFT along stride M_p
 // entirely inside LDS (tile = R_p rows x C columns of 32-byte elements, 32 KiB), multiplies
-// by the inter-pass twiddle w_N^(j'*k) and writes back IN PLACE.  The last pass has no
-// twiddle and writes the digit-reversed result to its natural position (out-of-place into a
-// scratch buffer), tiled over the FIRST digit so stores are contiguous 256-byte runs.
+// by the inter-pass twiddle w_N^(j'*k) and writes back to the same positions (pass 0 moves the
+// data into a scratch vector, middle passes work in place there).  The last pass has no twiddle
+// and scatters the digit-reversed result to its natural position back in the caller's vector,
+// tiled over the FIRST digit so stores are contiguous 128-256-byte runs.
 // Inside a tile the sub-FFT is a radix-2 DIT over LDS with the tile's twiddles (w_R^i)
 // staged in LDS.  Work per pass: one 32-B read + one 32-B write per element.
 #include "common.hpp"

@@ -483,7 +483,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     const size_t bits_bytes = (size_t)p.W * p.c * sizeof(XYZZ<F>);
     ErrFlags ef;
     memcpy(&ef, (char *)job.host_result + bits_bytes, sizeof ef);
-    if (ms) {  // [0] whole device pipeline, [1] digits+sort+tasks, [2] bucket accumulation, [3] reductions
+    if (ms) {  // [0] whole device pipeline, [1] digits+sort, [2] bucket accumulation, [3] reductions
       (void)hipEventElapsedTime(&ms[0], job.ev_begin, job.ev_end);
       (void)hipEventElapsedTime(&ms[1], job.ev_begin, job.ev_sorted);
       (void)hipEventElapsedTime(&ms[2], job.ev_sorted, job.ev_accum);

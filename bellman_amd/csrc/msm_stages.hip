@@ -7,19 +7,23 @@
 // fill): the result is a group element, so the order of additions is unobservable.
 //
 // Device pipeline (all on the job's stream, no host round trip until the very end):
-//   1. digits      one thread per scalar: density rank -> base index, c-bit digits for all
-//                  W = ceil(255/c) windows, written as (digit,base) pairs, window-major.
-//   2. sort        stable LSD radix sort of every window's pairs by digit, 8 bits per pass;
+//   1. digits      one thread per scalar: density rank -> base index; the scalar is recoded into
+//                  W = ceil(256/c) SIGNED c-bit digits (carry between windows) and written as
+//                  (|digit| << 32 | sign << 31 | base) pairs, window-major.       msm_stages.hip
+//   2. sort        stable LSD radix sort of every window's pairs by |digit|, 8 bits per pass;
 //                  ranking inside a tile uses wavefront ballots (match-any) + popcounts.
-//   3. chunks      the sorted stream of every window is cut into equal chunks of K entries: every
-//                  lane performs exactly K mixed additions whatever the bucket-size distribution.
+//   3. chunks      the sorted stream of every window (zero digits skipped) is cut into equal
+//                  chunks of K entries: every lane performs exactly K mixed additions whatever
+//                  the bucket-size distribution.
 //   4. accumulate  one lane per chunk: gather affine bases (L2 / Infinity-Cache resident: the
-//                  96 MiB base table fits the 256 MiB MALL) and XYZZ mixed-add them.
-//   5. reduce      sum_d d*B_d without a serial running sum: split d = hi*2^l + lo, take row
-//                  sums over lo and column sums over hi (wave tree-reductions), then per-bit
-//                  sums of those 2^l-entry vectors -> W*c partial points U_p with
-//                  result = sum_p 2^p U_p.
-//   6. tail        the 255-step double-and-add over U_p is inherently serial -> host.
+//                  96 MiB base table fits the 256 MiB MALL), negate for negative digits and
+//                  XYZZ mixed-add; buckets straddling chunk borders are folded by the merge
+//                  kernels (serial walk for short runs, one workgroup per long run).  msm_ec.cuh
+//   5. reduce      sum_i (i+1)*B_i without a serial running sum: split i = hi*2^l + lo, take row
+//                  sums over lo and column sums over hi (shuffle-tree reductions), then per-bit
+//                  sums of those vectors and the plain window totals -> W*c points.
+//   6. tail        result = sum_w 2^(c*w) (sum_p 2^p U[w][p] + T[w]): a 256-step double-and-add,
+//                  inherently serial -> host, 64-bit limbs (host_fp.hpp).
 #include <algorithm>
 #include <cmath>
 

@@ -57,7 +57,7 @@ struct MsmJobImpl {
 };
 
 
-// msm_stages.hip: curve-independent stages (digits, sort, bounds, tasks)
+// msm_stages.hip: curve-independent stages (signed digits, radix sort, zero-digit counts)
 struct MsmBuffers {
   u64 *pairs_a, *pairs_b;
   u32 *counts, *scan_tmp, *zstart, *word_prefix;   // zstart[w] = #entries with digit 0 in window w
