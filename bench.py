@@ -239,6 +239,24 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = world * n * args.steps / elapsed / 1e6
 
+    # extra information (not `value`): the same K steps issued with two jobs in flight, the way
+    # create_proof drives multiexp (prover.rs:244-318 issues all eight before the first wait): the
+    # latency-bound reduction of one MSM overlaps the bucket accumulation of the next
+    def issue():
+        return bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None,
+                                    scalars_dev=ctypes.c_void_p(s_dev.data_ptr()), n=n, timed=True)
+
+    barrier()
+    tp0 = time.perf_counter()
+    prev = issue()
+    for _ in range(args.steps - 1):
+        nxt = issue()
+        prev.wait()
+        prev = nxt
+    prev.wait()
+    barrier()
+    pipelined_value = world * n * args.steps / (time.perf_counter() - tp0) / 1e6
+
     out = None
     if rank == 0:
         acc_ms = float(stage[2])
@@ -260,8 +278,9 @@ def main():
                 "workload": "G1 Pippenger MSM, 2^%d (base,scalar) terms per GPU, FullDensity, inputs resident in HBM "
                             "(BASELINE.json configs[1])" % args.log_n,
                 "sharding": "bases split across ranks, one 96-B all-gather per step" if distributed else "single GPU",
-                "device_ms": {"pipeline": round(float(stage[0]), 4), "digits_sort_tasks": round(float(stage[1]), 4),
-                              "bucket_accumulate": round(acc_ms, 4), "reduce": round(float(stage[3]), 4)},
+                "device_ms": {"pipeline": round(float(stage[0]), 4), "digits_sort": round(float(stage[1]), 4),
+                              "bucket_accumulate": round(acc_ms, 4), "merge_reduce": round(float(stage[3]), 4)},
+                "value_with_2_jobs_in_flight": round(pipelined_value, 3),
             },
             "roofline": {
                 "bound": "hbm",
@@ -272,6 +291,13 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": None,
                 "note": "integer-ALU bound (v_mad_u64_u32), see DESIGN.md; bytes = 128 B/term x 2^%d" % args.log_n,
+                # the roofline that actually bounds this kernel: the v_mad_u64_u32 pipe.  Work per launch =
+                # W*n mixed additions x 10 field products x 351 mads (ff.cuh); peak = 26.2 T mad/s measured
+                # on this chip (profiles/r1_microbench_int.txt).
+                "alu": {"unit": "Tmad/s", "peak": 26.2,
+                        "achieved": round(16 * n * 10 * 351 / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
+                        "frac": round(16 * n * 10 * 351 / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
+                        "work": "16 windows x n mixed additions x 10 Fp products x 351 v_mad_u64_u32"},
             },
         }
         if not args.no_cpu_baseline:

@@ -473,3 +473,56 @@ def test_fixed_base_mul(worker, group):
     ints = cref.arr_to_ints(sc)
     for i in list(range(12)) + [100, 499]:
         assert np.array_equal(out[i], cref.point_mul(group, gen, ints[i])), i
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_msm_fuzz_random_shapes(worker, seed):
+    """Randomised sweep over sizes, densities, skips, scalar mixes and the tuning knobs (c, K): chunk /
+    bucket boundary handling (runs ending exactly on chunk borders, single-bucket chunks, long runs,
+    empty windows) must never change the group element."""
+    import bellman_amd
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    rnd = np.random.default_rng(1000 + seed)
+    try:
+        for _ in range(5):
+            group = 1 if rnd.random() < 0.75 else 2
+            n = int(rnd.choice([3, 17, 64, 65, 127, 500, 1023, 2048, 3001, 9000]))
+            if group == 2:
+                n = min(n, 2048)
+            sc = cref.random_fr(n, int(rnd.integers(1 << 30)))
+            mode = int(rnd.integers(5))
+            if mode == 1:  # few distinct scalars -> very long bucket runs
+                sc[:] = sc[rnd.integers(0, 3, size=n)]
+            elif mode == 2:  # small scalars: upper windows empty
+                sc[:, 1:] = 0
+            elif mode == 3:  # boolean-heavy witness
+                k = rnd.integers(0, 3, size=n)
+                sc[k == 0] = 0
+                sc[k == 1] = cref.ints_to_arr([1], 4)[0]
+            elif mode == 4:  # values near q and powers of two
+                sc[::3] = cref.ints_to_arr([Q - 1], 4)[0]
+                sc[1::3] = cref.ints_to_arr([1 << int(rnd.integers(1, 254))], 4)[0]
+            dens = None
+            nb, skip = n, 0
+            if rnd.random() < 0.5:
+                dens = rnd.random(n) < rnd.choice([0.1, 0.5, 0.9])
+                skip = int(rnd.integers(0, 5))
+                nb = int(dens.sum()) + skip
+            bases = cref.gen_bases(group, max(nb, 1), a=int(rnd.integers(1, 1000)), b=int(rnd.integers(1, 1000)))[:nb]
+            if nb > 10 and rnd.random() < 0.3:
+                bases[5] = bases[4]
+            c = int(rnd.choice([0, 2, 3, 4, 7, 8, 11, 13, 16]))
+            K = int(rnd.choice([0, 1, 2, 5, 8, 16, 33, 1000]))
+            lib.bh_msm_set_window_bits(worker.ctx, c)
+            lib.bh_msm_set_chunk(worker.ctx, K)
+            hb = bellman_amd.Bases(worker, group, bases)
+            dm = bellman_amd.FullDensity() if dens is None else bellman_amd.DensityTracker(dens)
+            got = bellman_amd.multiexp(worker, hb, dm, sc, skip=skip).wait()
+            rc, want = cref.multiexp(group, bases, skip, None if dens is None else cref.density_bitmap(dens), sc)
+            assert rc == 0
+            assert np.array_equal(got, want), (group, n, mode, c, K, skip, dens is not None)
+    finally:
+        lib.bh_msm_set_window_bits(worker.ctx, 0)
+        lib.bh_msm_set_chunk(worker.ctx, 0)
