@@ -300,7 +300,7 @@ def main():
                         "work": "16 windows x n mixed additions x 10 Fp products x 351 v_mad_u64_u32"},
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not distributed:   # rank 0 at N=1 only
             # CPU baseline: the oracle restatement of bellman's multicore path, timed here as the
             # reported baseline (never the thing shipped).  Sample = the same 2^log_n-term MSM, once.
             from oracle import cref
