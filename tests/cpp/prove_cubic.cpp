@@ -1,0 +1,76 @@
+// A C++ user of the bellman mirror (bellman_amd/csrc/groth16.hpp): proves knowledge of x with
+// x^3 + x + 5 = out - the classic R1CS example - exactly as one would write it against bellman:
+//   struct CubicDemo: Circuit { synthesize(cs) { alloc / alloc_input / enforce } }
+//   create_proof(circuit, params, r, s)
+// CRS points and r, s come from a binary file written by the test (tests/test_gpu_groth16.py);
+// the proof (a | b | c affine records, 384 bytes) is written to stdout as hex.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "../../bellman_amd/csrc/groth16.hpp"
+
+using namespace bellman;
+
+struct CubicDemo : Circuit {
+  Fr x;
+  void synthesize(ConstraintSystem &cs) override {
+    const Fr x2v = x * x, x3v = x2v * x, outv = x3v + x + Fr::from_u64(5);
+    Variable xv = cs.alloc([&] { return x; });
+    Variable x2 = cs.alloc([&] { return x2v; });
+    Variable x3 = cs.alloc([&] { return x3v; });
+    Variable out = cs.alloc_input([&] { return outv; });
+    cs.enforce([&](LinearCombination lc) { return lc + xv; }, [&](LinearCombination lc) { return lc + xv; },
+               [&](LinearCombination lc) { return lc + x2; });
+    cs.enforce([&](LinearCombination lc) { return lc + x2; }, [&](LinearCombination lc) { return lc + xv; },
+               [&](LinearCombination lc) { return lc + x3; });
+    // (x3 + x + 5) * 1 = out
+    cs.enforce([&](LinearCombination lc) { return lc + x3 + xv + std::make_pair(Fr::from_u64(5), ConstraintSystem::one()); },
+               [&](LinearCombination lc) { return lc + ConstraintSystem::one(); },
+               [&](LinearCombination lc) { return lc + out; });
+  }
+};
+
+template <class T> static std::vector<T> read_vec(FILE *f) {
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1) exit(3);
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) exit(3);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  groth16::VerifyingKey vk;
+  if (fread(&vk.alpha_g1, 96, 1, f) != 1 || fread(&vk.beta_g1, 96, 1, f) != 1 || fread(&vk.beta_g2, 192, 1, f) != 1 ||
+      fread(&vk.delta_g1, 96, 1, f) != 1 || fread(&vk.delta_g2, 192, 1, f) != 1) return 3;
+  auto h = read_vec<groth16::G1Affine>(f), l = read_vec<groth16::G1Affine>(f), a = read_vec<groth16::G1Affine>(f),
+       b1 = read_vec<groth16::G1Affine>(f);
+  auto b2 = read_vec<groth16::G2Affine>(f);
+  Fr x, r, s;
+  if (fread(&x, 32, 1, f) != 1 || fread(&r, 32, 1, f) != 1 || fread(&s, 32, 1, f) != 1) return 3;
+  fclose(f);
+
+  bh_ctx *ctx = nullptr;
+  if (bh_ctx_create(0, &ctx) != BH_OK) { fprintf(stderr, "no gfx950 device (no CPU fallback)\n"); return 4; }
+  int rc = 0;
+  try {
+    groth16::Parameters params(ctx, vk, h.data(), h.size(), l.data(), l.size(), a.data(), a.size(), b1.data(), b1.size(),
+                               b2.data(), b2.size());
+    CubicDemo circuit;
+    circuit.x = x;
+    groth16::Proof p = groth16::create_proof(circuit, params, r, s);
+    const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&p);
+    static_assert(sizeof(groth16::Proof) == 384, "a | b | c");
+    for (size_t i = 0; i < sizeof p; i++) printf("%02x", bytes[i]);
+    printf("\n");
+  } catch (const SynthesisError &e) {
+    fprintf(stderr, "SynthesisError %d: %s\n", e.code, e.what());
+    rc = 10 + e.code;
+  }
+  bh_ctx_destroy(ctx);
+  return rc;
+}
