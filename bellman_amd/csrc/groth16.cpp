@@ -185,6 +185,22 @@ struct DevBuf {
   ~DevBuf() { if (p) bh_dev_free(ctx, p); }
   DevBuf(const DevBuf &) = delete;
 };
+// Every issued multiexp owns device buffers and reads ours: if anything throws between issue and
+// wait, the jobs still in flight are drained before the DevBufs they read are released.
+struct JobSet {
+  std::vector<bh_msm_job **> slots;
+  void track(bh_msm_job **j) { slots.push_back(j); }
+  int wait(bh_msm_job *&j, void *out) {
+    bh_msm_job *job = j;
+    j = nullptr;
+    return bh_msm_wait(job, out);
+  }
+  ~JobSet() {
+    unsigned char sink[192];
+    for (bh_msm_job **s : slots)
+      if (*s) { (void)bh_msm_wait(*s, sink); *s = nullptr; }
+  }
+};
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -227,7 +243,13 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   auto dens_b_in = upload_density(prover.b_input_density);
   auto dens_b_aux = upload_density(prover.b_aux_density);
 
-  bh_msm_job *l_job, *a_in_job, *a_aux_job, *b1_in_job, *b1_aux_job, *b2_in_job, *b2_aux_job;
+  bh_msm_job *l_job = nullptr, *a_in_job = nullptr, *a_aux_job = nullptr, *b1_in_job = nullptr, *b1_aux_job = nullptr,
+             *b2_in_job = nullptr, *b2_aux_job = nullptr, *h_job = nullptr;
+  // h-block buffers are declared here so that `jobs` (declared after every buffer a job reads) is
+  // destroyed first and drains whatever is still in flight if an exception unwinds this frame
+  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
+  JobSet jobs;
+  for (bh_msm_job **j : {&l_job, &a_in_job, &a_aux_job, &b1_in_job, &b1_aux_job, &b2_in_job, &b2_aux_job, &h_job}) jobs.track(j);
   check(bh_msm_async_dev(ctx, params.l, 0, d_aux.p, n_aux, BH_SCALARS_MONT, nullptr, 0, &l_job));
   // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
   check(bh_msm_async_dev(ctx, params.a, 0, d_in.p, n_in, BH_SCALARS_MONT, nullptr, 0, &a_in_job));
@@ -247,7 +269,6 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   // prover.rs:221-245; the order of issue is unobservable, the order of waits is kept).
   // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
   // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
-  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
   {
     std::vector<Fr> pad(m, Fr::zero());
     const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
@@ -261,7 +282,6 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, nullptr));
   BH_TRACE("h poly done");
   const double t1 = now_ms();
-  bh_msm_job *h_job = nullptr;
   check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
@@ -270,14 +290,14 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   G1Affine h_res, l_res, a_in, a_aux, b1_in, b1_aux;
   G2Affine b2_in, b2_aux;
   // prover.rs:339-354 waits in this order: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
-  rcs[0] = bh_msm_wait(a_in_job, &a_in);
-  rcs[1] = bh_msm_wait(a_aux_job, &a_aux);
-  rcs[2] = bh_msm_wait(b1_in_job, &b1_in);
-  rcs[3] = bh_msm_wait(b1_aux_job, &b1_aux);
-  rcs[4] = bh_msm_wait(b2_in_job, &b2_in);
-  rcs[5] = bh_msm_wait(b2_aux_job, &b2_aux);
-  rcs[6] = bh_msm_wait(h_job, &h_res);
-  rcs[7] = bh_msm_wait(l_job, &l_res);
+  rcs[0] = jobs.wait(a_in_job, &a_in);
+  rcs[1] = jobs.wait(a_aux_job, &a_aux);
+  rcs[2] = jobs.wait(b1_in_job, &b1_in);
+  rcs[3] = jobs.wait(b1_aux_job, &b1_aux);
+  rcs[4] = jobs.wait(b2_in_job, &b2_in);
+  rcs[5] = jobs.wait(b2_aux_job, &b2_aux);
+  rcs[6] = jobs.wait(h_job, &h_res);
+  rcs[7] = jobs.wait(l_job, &l_res);
   const double t2 = now_ms();
   BH_TRACE("waits done rc=%d %d %d %d %d %d %d %d", rcs[0], rcs[1], rcs[2], rcs[3], rcs[4], rcs[5], rcs[6], rcs[7]);
 
