@@ -178,18 +178,23 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback in bellman_amd)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share one GPU to smoke-test the N>1
+    # path on a single-GPU box (RCCL itself needs one device per rank)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bellman_amd
     from bellman_amd import _lib, sharding
 
     lib = _lib.load()
-    worker = bellman_amd.Worker(local_rank)
+    worker = bellman_amd.Worker(device_index)
     n = 1 << args.log_n
 
     # ---- synthetic inputs, generated by the PRODUCT on the device (no oracle involved) --------
@@ -212,7 +217,7 @@ def main():
                                  n=n, timed=True)
         part, ms = w.wait()
         if distributed:   # one 96-byte all-gather over RCCL + local fold (bellman_amd/sharding.py)
-            return sharding.fold_partials(part, 1, device="cuda"), ms
+            return sharding.fold_partials(part, 1, device=coll_dev if coll_dev == "cuda" else None), ms
         return part, ms
 
     for _ in range(args.warmup):
@@ -232,7 +237,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     stage /= max(args.steps, 1)
