@@ -129,6 +129,11 @@ int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t byt
   BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   return BH_OK;
 }
+int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (bytes) BH_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, ctx->c.stream));
+  return BH_OK;
+}
 int bh_ctx_synchronize(bh_ctx *ctx) {
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   BH_HIP_CHECK(hipDeviceSynchronize());

@@ -270,12 +270,12 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
   // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
   {
-    std::vector<Fr> pad(m, Fr::zero());
+    // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
     const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
     void *dst[3] = {da.p, db.p, dc.p};
     for (int i = 0; i < 3; i++) {
-      memcpy(pad.data(), src[i]->data(), n_cons * sizeof(Fr));
-      check(bh_dev_upload(ctx, dst[i], pad.data(), m * 32));
+      if (m > n_cons) check(bh_dev_zero(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32));
+      check(bh_dev_upload(ctx, dst[i], src[i]->data(), n_cons * 32));
     }
   }
   BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);

@@ -59,6 +59,7 @@ int bh_dev_alloc(bh_ctx *ctx, size_t bytes, void **dev_ptr);
 int bh_dev_free(bh_ctx *ctx, void *dev_ptr);
 int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes);   /* hipMemsetAsync(0) on the context stream */
 int bh_ctx_synchronize(bh_ctx *ctx);
 
 /* ---- EvaluationDomain (src/domain.rs) ------------------------------------------------
