@@ -18,7 +18,7 @@ EXPORTS = [
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_ctx_synchronize",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
-    "bh_bases_register", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
+    "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
@@ -68,6 +68,7 @@ def load():
     lib.bh_h_poly_fr.argtypes = [vp, vp, vp, vp, sz, vp, c.POINTER(sz)]
     lib.bh_h_poly_fr_dev.argtypes = [vp, vp, vp, vp, u32, vp]
     lib.bh_bases_register.argtypes = [vp, i32, vp, sz, sz, c.c_long, c.POINTER(vp)]
+    lib.bh_bases_register_uncompressed.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]
     lib.bh_bases_wrap_dev.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]
     lib.bh_bases_release.argtypes = [vp, vp]
     lib.bh_bases_release.restype = None

@@ -49,6 +49,33 @@ __global__ void pack_bases_kernel(const unsigned char *raw, size_t stride, long 
     out[i * rec_words + w] = v;
   }
 }
+
+// Zcash uncompressed encoding -> device records: one thread per 48-byte big-endian coordinate.
+// coordinate order in: G1 x|y ; G2 x.c1|x.c0|y.c1|y.c0   out: G1 x|y ; G2 x.c0|x.c1|y.c0|y.c1
+__global__ void decode_uncompressed_kernel(const unsigned char *raw, u32 coords_per_point, fp_t *out, u64 n,
+                                           u32 *bad_flag) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * coords_per_point) return;
+  const u64 pt = t / coords_per_point;
+  const u32 ci = (u32)(t % coords_per_point);
+  const unsigned char *p0 = raw + pt * coords_per_point * 48;
+  const unsigned char flags = p0[0];
+  if (flags & 0x80) atomicOr(bad_flag, 1u);   // compressed form is not this entry point's format
+  const bool inf = (flags & 0x40) != 0;
+  const unsigned char *src = p0 + (size_t)ci * 48;
+  fp_t v;
+#pragma unroll
+  for (int w = 0; w < 12; w++) {   // limb w (little-endian) = bytes [44-4w, 48-4w) big-endian
+    const unsigned char *b = src + 44 - 4 * w;
+    u32 x = ((u32)b[0] << 24) | ((u32)b[1] << 16) | ((u32)b[2] << 8) | (u32)b[3];
+    if (ci == 0 && w == 11) x &= 0x1fffffffu;   // strip the three flag bits
+    v.l[w] = inf ? 0u : x;
+  }
+  if (!inf) fe_to_mont(v, v);
+  // G2 stores c1 before c0 on the wire
+  const u32 co = (coords_per_point == 4) ? (ci ^ 1u) : ci;
+  out[pt * coords_per_point + co] = v;
+}
 }  // namespace bh
 
 using namespace bh;
@@ -247,6 +274,34 @@ int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n,
     }
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
+  *out = new bh_bases{group, dev, n, true};
+  return BH_OK;
+}
+int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, bh_bases **out) {
+  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  const u32 cpp = group == BH_G1 ? 2 : 4;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *dev = nullptr, *raw = nullptr;
+  u32 *flag = nullptr;
+  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  int rc = BH_OK;
+  if (n) {
+    BH_HIP_CHECK(hipMalloc(&raw, n * rec + 4));
+    flag = (u32 *)((char *)raw + n * rec);
+    BH_HIP_CHECK(hipMemcpyAsync(raw, host_bytes, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
+    BH_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->c.stream));
+    const u64 threads = (u64)n * cpp;
+    hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, ctx->c.stream,
+                       (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, flag);
+    BH_HIP_CHECK(hipGetLastError());
+    u32 bad = 0;
+    BH_HIP_CHECK(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->c.stream));
+    BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+    BH_HIP_CHECK(hipFree(raw));
+    if (bad) rc = BH_ERR_INVALID_ARG;
+  }
+  if (rc != BH_OK) { (void)hipFree(dev); return rc; }
   *out = new bh_bases{group, dev, n, true};
   return BH_OK;
 }

@@ -74,6 +74,21 @@ class Bases:
         self.n = n
 
     @classmethod
+    def from_uncompressed(cls, worker, group, data):
+        """Bases from bellman's serialized CRS bytes (`Parameters::write`, groth16/src/lib.rs:258-287):
+        concatenated `to_uncompressed()` points; decoded on the device."""
+        rec = _WORDS[group] * 8
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        assert buf.size % rec == 0
+        self = cls.__new__(cls)
+        self.worker, self.group, self.n = worker, group, buf.size // rec
+        h = ctypes.c_void_p()
+        check(_lib.load().bh_bases_register_uncompressed(worker.ctx, group, buf.ctypes.data_as(ctypes.c_void_p), self.n,
+                                                         ctypes.byref(h)), "bases_register_uncompressed")
+        self._h = h
+        return self
+
+    @classmethod
     def wrap_device(cls, worker, group, dev_ptr, n):
         self = cls.__new__(cls)
         self.worker, self.group, self.n = worker, group, n

@@ -96,6 +96,14 @@ int bh_h_poly_fr_dev(bh_ctx *ctx, void *a_dev, void *b_dev, void *c_dev, uint32_
  * (the `infinity: Choice` of bls12_381's G1Affine/G2Affine), else identity == all-zero. */
 int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n, size_t stride,
                       long inf_offset, bh_bases **out);
+/* Same, straight from bellman's serialized CRS (`Parameters::write`, groth16/src/lib.rs:258-287):
+ * `n` uncompressed points in the Zcash encoding (`to_uncompressed()`: big-endian canonical
+ * coordinates, 96 B for G1 = x|y, 192 B for G2 = x.c1|x.c0|y.c1|y.c0, flag bits in the top of byte
+ * 0; the infinity flag yields the identity).  Byte order, flags and the conversion to Montgomery form
+ * are handled on the device.  Like `from_uncompressed_unchecked` (lib.rs:296-300) no on-curve or
+ * subgroup check is made; a compressed-form flag returns BH_ERR_INVALID_ARG. */
+int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n,
+                                   bh_bases **out);
 /* wrap an existing device array of packed 96/192-byte records (not owned) */
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 void bh_bases_release(bh_ctx *ctx, bh_bases *b);

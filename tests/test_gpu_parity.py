@@ -320,6 +320,31 @@ def test_bases_register_rust_struct_layout(worker, group):
     assert rc == 0 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_bases_from_serialized_crs_bytes(worker, group):
+    """bh_bases_register_uncompressed: bellman's on-disk query format (uncompressed Zcash encoding,
+    groth16/src/lib.rs:258-287) decoded on the device == the same points registered as records."""
+    import bellman_amd
+
+    n = 300
+    bases = cref.gen_bases(group, n, a=31, b=8)
+    bases[13] = 0  # serialises with the infinity flag
+    pts = (cref.g1_to_py if group == 1 else cref.g2_to_py)(bases)
+    enc = bls.g1_uncompressed if group == 1 else bls.g2_uncompressed
+    blob = b"".join(enc(p) for p in pts)
+    assert len(blob) == n * (96 if group == 1 else 192)
+    sc = _scalars(n, 29)
+    sc[13] = 0
+    hb = bellman_amd.Bases.from_uncompressed(worker, group, blob)
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    rc, want = cref.multiexp(group, bases, 0, None, sc)
+    assert rc == 0 and np.array_equal(got, want)
+    with pytest.raises(AssertionError):  # compressed-form flag is rejected (BH_ERR_INVALID_ARG)
+        bad = bytearray(blob)
+        bad[0] |= 0x80
+        bellman_amd.Bases.from_uncompressed(worker, group, bytes(bad))
+
+
 def test_msm_skewed_scalars_split_buckets(worker):
     """All scalars equal / boolean-heavy witnesses: exercises the split-bucket path."""
     import bellman_amd
