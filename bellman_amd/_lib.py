@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
 # every symbol include/bellman_hip.h declares
 EXPORTS = [
     "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus",
-    "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_ctx_synchronize",
+    "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
+    "bh_dev_zero_on", "bh_ctx_synchronize",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
@@ -58,6 +59,11 @@ def load():
     lib.bh_dev_upload.argtypes = [vp, vp, vp, sz]
     lib.bh_dev_download.argtypes = [vp, vp, vp, sz]
     lib.bh_dev_zero.argtypes = [vp, vp, sz]
+    lib.bh_stream_create.argtypes = [vp, c.POINTER(vp)]
+    lib.bh_stream_destroy.argtypes = [vp, vp]
+    lib.bh_stream_synchronize.argtypes = [vp, vp]
+    lib.bh_dev_upload_on.argtypes = [vp, vp, vp, sz, vp]
+    lib.bh_dev_zero_on.argtypes = [vp, vp, sz, vp]
     lib.bh_ctx_synchronize.argtypes = [vp]
     lib.bh_fft_fr.argtypes = [vp, vp, u32, i32]
     lib.bh_fft_fr_dev.argtypes = [vp, vp, u32, i32, vp]

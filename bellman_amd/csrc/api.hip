@@ -161,6 +161,33 @@ int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes) {
   if (bytes) BH_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, ctx->c.stream));
   return BH_OK;
 }
+int bh_stream_create(bh_ctx *ctx, void **stream) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  hipStream_t st = nullptr;
+  BH_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = (void *)st;
+  return BH_OK;
+}
+int bh_stream_destroy(bh_ctx *ctx, void *stream) {
+  (void)ctx;
+  if (stream) BH_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return BH_OK;
+}
+int bh_stream_synchronize(bh_ctx *ctx, void *stream) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  BH_HIP_CHECK(hipStreamSynchronize(pick_stream(ctx, stream)));
+  return BH_OK;
+}
+int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes, void *stream) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (bytes) BH_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, pick_stream(ctx, stream)));
+  return BH_OK;
+}
+int bh_dev_zero_on(bh_ctx *ctx, void *dev_ptr, size_t bytes, void *stream) {
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (bytes) BH_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, pick_stream(ctx, stream)));
+  return BH_OK;
+}
 int bh_ctx_synchronize(bh_ctx *ctx) {
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   BH_HIP_CHECK(hipDeviceSynchronize());

@@ -185,6 +185,13 @@ struct DevBuf {
   ~DevBuf() { if (p) bh_dev_free(ctx, p); }
   DevBuf(const DevBuf &) = delete;
 };
+struct ProofStream {   // uploads + h block of one proof; independent of other proofs in flight
+  bh_ctx *ctx;
+  void *st = nullptr;
+  explicit ProofStream(bh_ctx *c) : ctx(c) { check(bh_stream_create(ctx, &st)); }
+  ~ProofStream() { if (st) { (void)bh_stream_synchronize(ctx, st); (void)bh_stream_destroy(ctx, st); } }
+  ProofStream(const ProofStream &) = delete;
+};
 // Every issued multiexp owns device buffers and reads ours: if anything throws between issue and
 // wait, the jobs still in flight are drained before the DevBufs they read are released.
 struct JobSet {
@@ -231,18 +238,20 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   // assignments: uploaded once, shared by seven multiexps (prover.rs:248-318)
   const size_t n_in = prover.input_assignment.size(), n_aux = prover.aux_assignment.size();
   DevBuf d_in(ctx, n_in * 32 + 32), d_aux(ctx, n_aux * 32 + 32);
-  check(bh_dev_upload(ctx, d_in.p, prover.input_assignment.data(), n_in * 32));
-  if (n_aux) check(bh_dev_upload(ctx, d_aux.p, prover.aux_assignment.data(), n_aux * 32));
+  ProofStream ps(ctx);
+  check(bh_dev_upload_on(ctx, d_in.p, prover.input_assignment.data(), n_in * 32, ps.st));
+  if (n_aux) check(bh_dev_upload_on(ctx, d_aux.p, prover.aux_assignment.data(), n_aux * 32, ps.st));
   auto upload_density = [&](const DensityTracker &d) {
     const size_t nw = (d.get_query_size() + 63) / 64;
     std::unique_ptr<DevBuf> buf(new DevBuf(ctx, nw * 8 + 8));
-    if (nw) check(bh_dev_upload(ctx, buf->p, d.words(), nw * 8));
+    if (nw) check(bh_dev_upload_on(ctx, buf->p, d.words(), nw * 8, ps.st));
     return buf;
   };
   auto dens_a_aux = upload_density(prover.a_aux_density);
   auto dens_b_in = upload_density(prover.b_input_density);
   auto dens_b_aux = upload_density(prover.b_aux_density);
 
+  check(bh_stream_synchronize(ctx, ps.st));   // the multiexp jobs run on their own streams
   bh_msm_job *l_job = nullptr, *a_in_job = nullptr, *a_aux_job = nullptr, *b1_in_job = nullptr, *b1_aux_job = nullptr,
              *b2_in_job = nullptr, *b2_aux_job = nullptr, *h_job = nullptr;
   // h-block buffers are declared here so that `jobs` (declared after every buffer a job reads) is
@@ -274,12 +283,12 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
     const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
     void *dst[3] = {da.p, db.p, dc.p};
     for (int i = 0; i < 3; i++) {
-      if (m > n_cons) check(bh_dev_zero(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32));
-      check(bh_dev_upload(ctx, dst[i], src[i]->data(), n_cons * 32));
+      if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
+      check(bh_dev_upload_on(ctx, dst[i], src[i]->data(), n_cons * 32, ps.st));
     }
   }
   BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);
-  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, nullptr));
+  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, ps.st));   // synchronises ps.st before returning
   BH_TRACE("h poly done");
   const double t1 = now_ms();
   check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244

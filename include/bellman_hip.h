@@ -60,6 +60,13 @@ int bh_dev_free(bh_ctx *ctx, void *dev_ptr);
 int bh_dev_upload(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int bh_dev_download(bh_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes);   /* hipMemsetAsync(0) on the context stream */
+/* caller-owned streams (opaque hipStream_t) so that independent proofs issued from different host
+ * threads do not serialise on the context stream; the *_on variants enqueue and return */
+int bh_stream_create(bh_ctx *ctx, void **stream);
+int bh_stream_destroy(bh_ctx *ctx, void *stream);
+int bh_stream_synchronize(bh_ctx *ctx, void *stream);
+int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int bh_dev_zero_on(bh_ctx *ctx, void *dev_ptr, size_t bytes, void *stream);
 int bh_ctx_synchronize(bh_ctx *ctx);
 
 /* ---- EvaluationDomain (src/domain.rs) ------------------------------------------------
