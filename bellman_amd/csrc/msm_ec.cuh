@@ -304,7 +304,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                        u64 n, int fmt, const u64 *density_dev, unsigned forced_c) {
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
-  const MsmPlan p = make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu);
+  const MsmPlan p = make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu, F::WORDS == 24);
   // accumulator placement: bit 24 of the tuning word forces registers, bit 25 forces LDS
   const bool lds_acc = (forced_c & (1u << 25)) ? true : (forced_c & (1u << 24)) ? false : (F::WORDS == 24);
   job.plan = p;

@@ -219,7 +219,7 @@ __global__ void window_zero_count_kernel(const u64 *pairs, u32 *zstart, u32 n, u
 
 static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
 
-MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
+MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   MsmPlan p;
   p.n = (u32)n;
   // Window size from the MI355X sweep (profiles/r1_tune_small_sizes.txt, r1_tune_c_K_sweep.txt):
@@ -240,7 +240,7 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk) {
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
   // K entries per lane: 32 once the chip is full, fewer for small problems so that the serial chain
   // per lane shrinks instead of leaving SIMDs idle (same sweep)
-  p.chunk = forced_chunk ? forced_chunk : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
+  p.chunk = forced_chunk ? forced_chunk : (lg <= 11 ? 8 : lg <= 17 ? 16 : g2 ? 64 : 32);   // G2: fewer, costlier partials
   // never let a typical bucket span many chunks: the chunk merge is serial per bucket
   if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, n >> (p.c - 1));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
@@ -290,7 +290,7 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
 // bring-up aid: stages 1-3 only, results copied to the host (tests/test_gpu_parity.py)
 int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
                     u32 *zstart_out) {
-  const MsmPlan p = make_plan(n, cbits, 0);
+  const MsmPlan p = make_plan(n, cbits, 0, false);
   hipStream_t st = c.stream;
   const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
   MsmBuffers b;

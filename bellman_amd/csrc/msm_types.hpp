@@ -63,7 +63,7 @@ struct MsmBuffers {
   u32 *counts, *scan_tmp, *zstart, *word_prefix;   // zstart[w] = #entries with digit 0 in window w
   ErrFlags *err;
 };
-MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk);
+MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2);
 size_t scan_tmp_elems(u64 n);
 // runs stages 1-2 (+ per-window first non-zero position) on `st`; *sorted_out = sorted pairs
 int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
