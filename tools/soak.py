@@ -1,0 +1,47 @@
+"""Soak: many MSMs / FFTs / proofs of varying sizes through one context; reports device-memory drift."""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bellman_amd
+from bellman_amd import _lib
+from bench import splitmix_scalars, G1_GEN_MONT
+
+def free_mb():
+    return torch.cuda.mem_get_info()[0] / 2**20
+
+def main():
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    n = 1 << 18
+    t = splitmix_scalars(n, 1)
+    dt, dout = w.alloc(n * 32), w.alloc(n * 96)
+    w.upload(dt, t)
+    assert lib.bh_fixed_base_mul_dev(w.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+    w.synchronize()
+    bases = bellman_amd.Bases.wrap_device(w, 1, dout, n)
+    rnd = np.random.default_rng(5)
+    ref = {}
+    marks = []
+    t0 = time.time()
+    for it in range(300):
+        m = int(rnd.choice([1, 77, 1000, 4096, 30000, 1 << 16, 1 << 18]))
+        sc = splitmix_scalars(m, 100 + m)
+        jobs = [bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), sc) for _ in range(int(rnd.integers(1, 4)))]
+        for j in jobs:
+            r = j.wait()
+            assert np.array_equal(ref.setdefault(m, r), r)
+        if it % 10 == 0:
+            lg = int(rnd.integers(4, 19))
+            d = bellman_amd.EvaluationDomain.from_coeffs(w, splitmix_scalars(1 << lg, it))
+            d.coset_fft(); d.icoset_fft(); d.into_coeffs()
+        if it % 50 == 0:
+            w.synchronize()
+            marks.append(round(free_mb()))
+    w.synchronize()
+    marks.append(round(free_mb()))
+    print("free MiB over time:", marks, "elapsed %.1fs" % (time.time() - t0))
+    assert marks[-1] >= marks[1] - 64, "device memory keeps shrinking"
+    print("soak ok")
+
+main()
