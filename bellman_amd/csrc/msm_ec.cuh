@@ -238,7 +238,12 @@ __global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
   const u32 G = d.lanes;
   const u32 g = (blk * 64 + threadIdx.x) / G;
   const u32 sub = threadIdx.x & (G - 1);
-  XYZZ<F> acc;
+  // G2: partial sums live in LDS slots (an XYZZ<Fp2> accumulator is 96 VGPRs) and the tree reads the
+  // partner's slot directly; G1 keeps registers + shuffles
+  constexpr bool LDS_ACC = (F::WORDS == 24);
+  __shared__ XYZZ<F> lds_acc[LDS_ACC ? 64 : 1];
+  XYZZ<F> reg_acc;
+  XYZZ<F> &acc = LDS_ACC ? lds_acc[threadIdx.x] : reg_acc;
   xyzz_set_identity(acc);
   if (g < d.groups) {
     const u32 outer = g / d.inner, in_idx = g % d.inner;
@@ -259,7 +264,18 @@ __global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
       }
     }
   }
-  group_reduce_points<F>(acc, G);
+  if (LDS_ACC) {
+    for (u32 off = G >> 1; off >= 1; off >>= 1) {
+      __syncthreads();
+      if (sub < off) {
+        XYZZ<F> r;
+        xyzz_add(r, lds_acc[threadIdx.x], lds_acc[threadIdx.x + off]);
+        lds_acc[threadIdx.x] = r;
+      }
+    }
+  } else {
+    group_reduce_points<F>(acc, G);
+  }
   if (sub == 0 && g < d.groups) out[g] = acc;
 }
 
