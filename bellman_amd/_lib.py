@@ -23,6 +23,8 @@ EXPORTS = [
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
+    "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev",
+    "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host",
 ]
@@ -96,6 +98,15 @@ def load():
     lib.bh_groth16_params_release.restype = None
     lib.bh_groth16_prove_assignment.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     lib.bh_groth16_prove_demo.argtypes = [vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.bh_r1cs_create.argtypes = [vp, sz, sz, sz, vp, vp, sz, c.POINTER(vp)]
+    lib.bh_r1cs_release.argtypes = [vp]
+    lib.bh_r1cs_release.restype = None
+    lib.bh_r1cs_shape.argtypes = [vp, c.POINTER(sz), c.POINTER(sz), c.POINTER(sz)]
+    lib.bh_r1cs_density.argtypes = [vp, i32, c.POINTER(vp), c.POINTER(vp), c.POINTER(sz)]
+    lib.bh_r1cs_eval_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, c.c_uint32, vp]
+    lib.bh_groth16_prove_witness.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp]
+    lib.bh_groth16_demo_r1cs.argtypes = [vp, i32, sz, c.c_uint64, vp, c.POINTER(vp)]
+    lib.bh_groth16_prove_demo_r1cs.argtypes = [vp, vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.bh_test_fr_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]

@@ -6,8 +6,9 @@
 
 #include <chrono>
 #include <memory>
+#include <unordered_map>
 
-#define BH_TRACE(...) do { if (getenv("BH_DEBUG")) { fprintf(stderr, "[groth16] " __VA_ARGS__); fputc(10, stderr); fflush(stderr); } } while (0)
+#define BH_TRACE(...) do { if (getenv("BH_DEBUG")) { fprintf(stderr, "[groth16 %.2f ms] ", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()); fprintf(stderr, __VA_ARGS__); fputc(10, stderr); fflush(stderr); } } while (0)
 
 namespace bellman {
 namespace {
@@ -222,11 +223,24 @@ template <class A> A mul_pt(int group, const A &x, const Fr &k) {
 }  // namespace
 
 // ---- prover.rs:217-360 ----------------------------------------------------------------------------
-Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+namespace {
+// What differs between the two ways of getting the constraint evaluations into HBM
+struct AssignmentSource {
+  const Fr *inputs; size_t n_in;
+  const Fr *aux; size_t n_aux;
+  size_t n_cons;
+  // host path (prove_assignment): evaluations and density bitmaps computed during synthesis
+  const ProvingAssignment *host = nullptr;
+  // device path (prove_witness): matrices and densities already resident
+  const R1cs *r1cs = nullptr;
+};
+}  // namespace
+
+static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   bh_ctx *ctx = params.ctx;
   const double t0 = now_ms();
   const VerifyingKey &vk = params.vk;
-  const size_t n_cons = prover.a.size();
+  const size_t n_cons = src.n_cons;
   // EvaluationDomain::from_coeffs (domain.rs:47-79)
   uint32_t log_m = 0;
   size_t m = 1;
@@ -236,22 +250,34 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
     if (log_m >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
   }
   // assignments: uploaded once, shared by seven multiexps (prover.rs:248-318)
-  const size_t n_in = prover.input_assignment.size(), n_aux = prover.aux_assignment.size();
+  const size_t n_in = src.n_in, n_aux = src.n_aux;
   DevBuf d_in(ctx, n_in * 32 + 32), d_aux(ctx, n_aux * 32 + 32);
   ProofStream ps(ctx);
-  check(bh_dev_upload_on(ctx, d_in.p, prover.input_assignment.data(), n_in * 32, ps.st));
-  if (n_aux) check(bh_dev_upload_on(ctx, d_aux.p, prover.aux_assignment.data(), n_aux * 32, ps.st));
-  auto upload_density = [&](const DensityTracker &d) {
-    const size_t nw = (d.get_query_size() + 63) / 64;
-    std::unique_ptr<DevBuf> buf(new DevBuf(ctx, nw * 8 + 8));
-    if (nw) check(bh_dev_upload_on(ctx, buf->p, d.words(), nw * 8, ps.st));
-    return buf;
-  };
-  auto dens_a_aux = upload_density(prover.a_aux_density);
-  auto dens_b_in = upload_density(prover.b_input_density);
-  auto dens_b_aux = upload_density(prover.b_aux_density);
+  check(bh_dev_upload_on(ctx, d_in.p, src.inputs, n_in * 32, ps.st));
+  if (n_aux) check(bh_dev_upload_on(ctx, d_aux.p, src.aux, n_aux * 32, ps.st));
+  std::unique_ptr<DevBuf> dens_buf[3];
+  const uint64_t *dens_a_aux = nullptr, *dens_b_in = nullptr, *dens_b_aux = nullptr;
+  size_t b_in_total = 0;
+  if (src.host) {
+    auto upload_density = [&](const DensityTracker &d, std::unique_ptr<DevBuf> &buf) {
+      const size_t nw = (d.get_query_size() + 63) / 64;
+      buf.reset(new DevBuf(ctx, nw * 8 + 8));
+      if (nw) check(bh_dev_upload_on(ctx, buf->p, d.words(), nw * 8, ps.st));
+      return (const uint64_t *)buf->p;
+    };
+    dens_a_aux = upload_density(src.host->a_aux_density, dens_buf[0]);
+    dens_b_in = upload_density(src.host->b_input_density, dens_buf[1]);
+    dens_b_aux = upload_density(src.host->b_aux_density, dens_buf[2]);
+    b_in_total = src.host->b_input_density.get_total_density();
+  } else {
+    check(bh_r1cs_density(src.r1cs->handle, 0, &dens_a_aux, nullptr, nullptr));
+    check(bh_r1cs_density(src.r1cs->handle, 1, &dens_b_in, nullptr, &b_in_total));
+    check(bh_r1cs_density(src.r1cs->handle, 2, &dens_b_aux, nullptr, nullptr));
+  }
 
+  BH_TRACE("prove_core start: uploads queued");
   check(bh_stream_synchronize(ctx, ps.st));   // the multiexp jobs run on their own streams
+  BH_TRACE("assignment resident");
   bh_msm_job *l_job = nullptr, *a_in_job = nullptr, *a_aux_job = nullptr, *b1_in_job = nullptr, *b1_aux_job = nullptr,
              *b2_in_job = nullptr, *b2_aux_job = nullptr, *h_job = nullptr;
   // h-block buffers are declared here so that `jobs` (declared after every buffer a job reads) is
@@ -262,15 +288,14 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   check(bh_msm_async_dev(ctx, params.l, 0, d_aux.p, n_aux, BH_SCALARS_MONT, nullptr, 0, &l_job));
   // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
   check(bh_msm_async_dev(ctx, params.a, 0, d_in.p, n_in, BH_SCALARS_MONT, nullptr, 0, &a_in_job));
-  check(bh_msm_async_dev(ctx, params.a, n_in, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_a_aux->p, n_aux,
+  check(bh_msm_async_dev(ctx, params.a, n_in, d_aux.p, n_aux, BH_SCALARS_MONT, dens_a_aux, n_aux,
                          &a_aux_job));
-  const size_t b_in_total = prover.b_input_density.get_total_density();
   // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
-  check(bh_msm_async_dev(ctx, params.b_g1, 0, d_in.p, n_in, BH_SCALARS_MONT, (const uint64_t *)dens_b_in->p, n_in, &b1_in_job));
-  check(bh_msm_async_dev(ctx, params.b_g1, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_b_aux->p, n_aux,
+  check(bh_msm_async_dev(ctx, params.b_g1, 0, d_in.p, n_in, BH_SCALARS_MONT, dens_b_in, n_in, &b1_in_job));
+  check(bh_msm_async_dev(ctx, params.b_g1, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, dens_b_aux, n_aux,
                          &b1_aux_job));
-  check(bh_msm_async_dev(ctx, params.b_g2, 0, d_in.p, n_in, BH_SCALARS_MONT, (const uint64_t *)dens_b_in->p, n_in, &b2_in_job));
-  check(bh_msm_async_dev(ctx, params.b_g2, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, (const uint64_t *)dens_b_aux->p, n_aux,
+  check(bh_msm_async_dev(ctx, params.b_g2, 0, d_in.p, n_in, BH_SCALARS_MONT, dens_b_in, n_in, &b2_in_job));
+  check(bh_msm_async_dev(ctx, params.b_g2, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, dens_b_aux, n_aux,
                          &b2_aux_job));
 
   // The seven multiexps above only need the assignments, so they are already running on their own
@@ -278,16 +303,19 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
   // prover.rs:221-245; the order of issue is unobservable, the order of waits is kept).
   // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
   // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
-  {
+  if (src.host) {
     // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
-    const std::vector<Fr> *src[3] = {&prover.a, &prover.b, &prover.c};
+    const std::vector<Fr> *ev[3] = {&src.host->a, &src.host->b, &src.host->c};
     void *dst[3] = {da.p, db.p, dc.p};
     for (int i = 0; i < 3; i++) {
       if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
-      check(bh_dev_upload_on(ctx, dst[i], src[i]->data(), n_cons * 32, ps.st));
+      check(bh_dev_upload_on(ctx, dst[i], ev[i]->data(), n_cons * 32, ps.st));
     }
+  } else {
+    // a = A.w, b = B.w, c = C.w straight into the FFT buffers (prover.rs:19-55,105-145 on the device)
+    check(bh_r1cs_eval_dev(ctx, src.r1cs->handle, d_in.p, d_aux.p, da.p, db.p, dc.p, log_m, ps.st));
   }
-  BH_TRACE("n_cons=%zu m=%zu uploaded", n_cons, m);
+  BH_TRACE("7 multiexps issued; n_cons=%zu m=%zu a/b/c queued", n_cons, m);
   check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, ps.st));   // synchronises ps.st before returning
   BH_TRACE("h poly done");
   const double t1 = now_ms();
@@ -337,6 +365,132 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
     tm->total_ms = (float)(now_ms() - t0);
   }
   return Proof{g_a, g_b, g_c};
+}
+
+Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  AssignmentSource src;
+  src.inputs = prover.input_assignment.data(); src.n_in = prover.input_assignment.size();
+  src.aux = prover.aux_assignment.data(); src.n_aux = prover.aux_assignment.size();
+  src.n_cons = prover.a.size();
+  src.host = &prover;
+  return prove_core(src, params, r, s, tm);
+}
+
+Proof prove_witness(const R1cs &r1cs, Parameters &params, const Fr *inputs, size_t n_inputs, const Fr *aux, size_t n_aux,
+                    const Fr &r, const Fr &s, ProveTimings *tm) {
+  if (n_inputs != r1cs.num_inputs || n_aux != r1cs.num_aux)
+    throw std::invalid_argument("witness does not have the shape of the captured circuit");
+  AssignmentSource src;
+  src.inputs = inputs; src.n_in = n_inputs;
+  src.aux = aux; src.n_aux = n_aux;
+  src.n_cons = r1cs.num_constraints;
+  src.r1cs = &r1cs;
+  return prove_core(src, params, r, s, tm);
+}
+
+// ---- structure capture (generator.rs:43-131 KeypairAssembly, plus the input rows of prover.rs:208-215)
+namespace {
+struct FrHash {
+  size_t operator()(const Fr &f) const {
+    uint64_t h = f.l[0] * 0x9E3779B97F4A7C15ULL;
+    h ^= f.l[1] + 0xBF58476D1CE4E5B9ULL + (h << 6) + (h >> 2);
+    h ^= f.l[2] + 0x94D049BB133111EBULL + (h << 6) + (h >> 2);
+    h ^= f.l[3] + (h << 6) + (h >> 2);
+    return (size_t)h;
+  }
+};
+class ShapeAssembly : public ConstraintSystem {
+ public:
+  size_t num_inputs = 0, num_aux = 0;
+  struct Term { Index kind; uint32_t idx, coeff; };
+  std::vector<uint32_t> row_ptr[3];
+  std::vector<Term> terms[3];
+  std::vector<Fr> coeffs;
+  std::unordered_map<Fr, uint32_t, FrHash> coeff_index;
+  ShapeAssembly() {
+    coeffs.push_back(Fr::one());
+    coeff_index.emplace(Fr::one(), 0);
+    for (auto &rp : row_ptr) rp.push_back(0);
+  }
+  Variable alloc(ValueFn) override { return Variable::new_unchecked(Index::Aux, num_aux++); }
+  Variable alloc_input(ValueFn) override { return Variable::new_unchecked(Index::Input, num_inputs++); }
+  void enforce(LcFn fa, LcFn fb, LcFn fc) override {
+    const LinearCombination lcs[3] = {fa(LinearCombination::zero()), fb(LinearCombination::zero()),
+                                      fc(LinearCombination::zero())};
+    for (int m = 0; m < 3; m++) {
+      for (size_t i = 0; i < lcs[m].size(); i++) {
+        const Variable &v = lcs[m][i].first;
+        const Fr &k = lcs[m][i].second;
+        if (k.is_zero()) continue;   // prover.rs:31: no value, no density
+        auto it = coeff_index.find(k);
+        uint32_t ci;
+        if (it == coeff_index.end()) {
+          ci = (uint32_t)coeffs.size();
+          coeffs.push_back(k);
+          coeff_index.emplace(k, ci);
+        } else {
+          ci = it->second;
+        }
+        terms[m].push_back(Term{v.kind, (uint32_t)v.idx, ci});
+      }
+      row_ptr[m].push_back((uint32_t)terms[m].size());
+    }
+  }
+};
+}  // namespace
+
+R1cs::R1cs(Circuit &shape_of, bh_ctx *ctx) {
+  ShapeAssembly cs;
+  cs.alloc_input([] { return Fr::one(); });
+  shape_of.synthesize(cs);
+  for (size_t i = 0; i < cs.num_inputs; i++) {
+    cs.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+               [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+  }
+  num_inputs = cs.num_inputs; num_aux = cs.num_aux; num_constraints = cs.row_ptr[0].size() - 1;
+  std::vector<uint32_t> var[3], coeff[3];
+  bh_csr abc[3];
+  for (int m = 0; m < 3; m++) {
+    var[m].reserve(cs.terms[m].size()); coeff[m].reserve(cs.terms[m].size());
+    for (const auto &t : cs.terms[m]) {
+      var[m].push_back(t.kind == Index::Input ? t.idx : (uint32_t)(num_inputs + t.idx));   // inputs first, then aux
+      coeff[m].push_back(t.coeff);
+    }
+    abc[m] = bh_csr{cs.row_ptr[m].data(), var[m].data(), coeff[m].data()};
+  }
+  check(bh_r1cs_create(ctx, num_inputs, num_aux, num_constraints, abc, cs.coeffs.data(), cs.coeffs.size(), &handle));
+}
+R1cs::R1cs(bh_r1cs *existing) : handle(existing) {
+  check(bh_r1cs_shape(existing, &num_inputs, &num_aux, &num_constraints));
+}
+R1cs::~R1cs() { bh_r1cs_release(handle); }
+
+Variable WitnessAssignment::alloc(ValueFn f) {
+  aux_assignment.push_back(f());
+  return Variable::new_unchecked(Index::Aux, aux_assignment.size() - 1);
+}
+Variable WitnessAssignment::alloc_input(ValueFn f) {
+  input_assignment.push_back(f());
+  return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
+}
+
+Proof create_proof(Circuit &circuit, const R1cs &r1cs, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  WitnessAssignment w;
+  w.input_assignment.reserve(r1cs.num_inputs);
+  w.aux_assignment.reserve(r1cs.num_aux);
+  w.alloc_input([] { return Fr::one(); });
+  circuit.synthesize(w);
+  const double t1 = now_ms();
+  ProveTimings local;
+  Proof p = prove_witness(r1cs, params, w.input_assignment.data(), w.input_assignment.size(), w.aux_assignment.data(),
+                          w.aux_assignment.size(), r, s, &local);
+  if (tm) {
+    *tm = local;
+    tm->synthesis_ms = (float)(t1 - t0);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+  return p;
 }
 
 // ---- prover.rs:182-215 ----------------------------------------------------------------------------
@@ -447,6 +601,34 @@ struct bh_params {
   groth16::Parameters *p;
 };
 
+// a non-owning groth16::R1cs over a handle that belongs to the C caller
+struct R1csView {
+  groth16::R1cs r;
+  explicit R1csView(const bh_r1cs *h) : r(const_cast<bh_r1cs *>(h)) {}
+  ~R1csView() { r.handle = nullptr; }
+};
+
+template <class F>
+static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const void *witness, const void *constants, F &&f) {
+  using namespace groth16;
+  if (circuit_kind == 0) {   // MiMC: witness = xl | xr, constants = `size` round constants (Montgomery Fr)
+    MiMCDemo c;
+    c.xl = Fr::zero(); c.xr = Fr::zero();
+    if (witness) { memcpy(&c.xl, witness, 32); memcpy(&c.xr, (const char *)witness + 32, 32); }
+    c.constants = (const Fr *)constants;
+    c.rounds = size;
+    return f(c);
+  }
+  if (circuit_kind == 1) {   // chain: witness = x0, `size` rounds
+    ChainCircuit c;
+    c.seed = seed; c.rounds = size;
+    c.x0 = Fr::zero();
+    if (witness) memcpy(&c.x0, witness, 32);
+    return f(c);
+  }
+  return BH_ERR_INVALID_ARG;
+}
+
 extern "C" {
 
 int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta_g1, const void *beta_g2,
@@ -478,6 +660,7 @@ static int run_guarded(const std::function<groth16::Proof()> &f, void *proof_out
     memcpy((char *)proof_out + 288, &p.c, 96);
     return BH_OK;
   } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
   } catch (...) { return BH_ERR_HIP; }
 }
 
@@ -501,6 +684,53 @@ int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const vo
   memcpy(&rr, r, 32); memcpy(&ss, s, 32);
   ProveTimings tm = {0, 0, 0, 0};
   int rc = run_guarded([&] { return prove_assignment(pa, *params->p, rr, ss, &tm); }, proof_out);
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment, size_t n_inputs,
+                             const void *aux_assignment, size_t n_aux, const void *r, const void *s, void *proof_out,
+                             float *timings4) {
+  using namespace groth16;
+  if (!params || !r1cs) return BH_ERR_INVALID_ARG;
+  R1csView view(r1cs);
+  std::vector<Fr> in(n_inputs), aux(n_aux);   // caller records may be unaligned
+  if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
+  if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = run_guarded([&] { return prove_witness(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, rr, ss, &tm); },
+                       proof_out);
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants, bh_r1cs **out) {
+  if (!ctx || !out) return BH_ERR_INVALID_ARG;
+  return with_demo_circuit(circuit_kind, size, seed, nullptr, constants, [&](bellman::Circuit &c) -> int {
+    try {
+      groth16::R1cs r(c, ctx);
+      *out = r.handle;
+      r.handle = nullptr;   // ownership moves to the caller (bh_r1cs_release)
+      return BH_OK;
+    } catch (const bellman::SynthesisError &e) { return e.code;
+    } catch (...) { return BH_ERR_HIP; }
+  });
+}
+
+int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
+                               const void *witness, const void *constants, const void *r, const void *s, void *proof_out,
+                               float *timings4) {
+  using namespace groth16;
+  if (!params || !r1cs) return BH_ERR_INVALID_ARG;
+  R1csView view(r1cs);
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
+    return run_guarded([&] { return create_proof(c, view.r, *params->p, rr, ss, &tm); }, proof_out);
+  });
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
 }

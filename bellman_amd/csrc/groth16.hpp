@@ -186,11 +186,42 @@ class ProvingAssignment : public bellman::ConstraintSystem {
 
 struct ProveTimings { float synthesis_ms, h_poly_ms, msm_ms, total_ms; };
 
+// The circuit's three constraint matrices, captured once and kept in HBM.  Capture
+// runs `synthesize` against a structure-only ConstraintSystem that never calls the value closures -
+// the same thing generator.rs:43-131 (KeypairAssembly) does to build the CRS for this circuit.
+class R1cs {
+ public:
+  R1cs(bellman::Circuit &shape_of, bh_ctx *ctx);
+  explicit R1cs(bh_r1cs *existing);   // adopt a handle made through the C ABI
+  ~R1cs();
+  R1cs(const R1cs &) = delete;
+  bh_r1cs *handle = nullptr;
+  size_t num_inputs = 0, num_aux = 0, num_constraints = 0;
+};
+
+// prover.rs:57-162 reduced to witness generation: alloc/alloc_input run the value closures,
+// enforce does nothing (the evaluations come from the device-resident matrices).
+class WitnessAssignment : public bellman::ConstraintSystem {
+ public:
+  std::vector<Fr> input_assignment, aux_assignment;
+  bellman::Variable alloc(bellman::ValueFn f) override;
+  bellman::Variable alloc_input(bellman::ValueFn f) override;
+  void enforce(bellman::LcFn, bellman::LcFn, bellman::LcFn) override {}
+};
+
 // prover.rs:182-361.  Throws bellman::SynthesisError.
 Proof create_proof(bellman::Circuit &circuit, Parameters &params, const Fr &r, const Fr &s,
                    ProveTimings *timings = nullptr);
 // prover.rs:217-360 on an already synthesised assignment (input constraints already appended)
 Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s,
                        ProveTimings *timings = nullptr);
+// The same two entry points with the constraint evaluation on the device: only the witness
+// closures of `circuit` run on the host.  The circuit must have the shape `r1cs` was captured from
+// (it does whenever `params` belongs to it); a different variable count throws std::invalid_argument.
+Proof create_proof(bellman::Circuit &circuit, const R1cs &r1cs, Parameters &params, const Fr &r, const Fr &s,
+                   ProveTimings *timings = nullptr);
+Proof prove_witness(const R1cs &r1cs, Parameters &params, const Fr *input_assignment, size_t n_inputs,
+                    const Fr *aux_assignment, size_t n_aux, const Fr &r, const Fr &s,
+                    ProveTimings *timings = nullptr);
 
 }  // namespace groth16

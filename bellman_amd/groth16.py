@@ -206,3 +206,201 @@ def create_proof_demo(params, kind, size, seed, witness, constants, r, s, timing
     if timings is not None:
         timings[:] = list(tm)
     return Proof(out)
+
+
+# ---- constraint matrices resident in HBM -------------------------------------------
+
+
+class ShapeAssembly(ConstraintSystem):
+    """Structure-only ConstraintSystem: records the three matrices, never calls the value closures
+    (what generator.rs:43-131 KeypairAssembly does when the CRS for the circuit is built)."""
+
+    def __init__(self):
+        self.num_inputs = self.num_aux = 0
+        self.rows = ([], [], [])  # per matrix: list of rows, each a list of (kind, idx, coeff)
+
+    def alloc(self, f):
+        self.num_aux += 1
+        return Variable(AUX, self.num_aux - 1)
+
+    def alloc_input(self, f):
+        self.num_inputs += 1
+        return Variable(INPUT, self.num_inputs - 1)
+
+    def enforce(self, a, b, c):
+        z = LinearCombination.zero()
+        for m, lc in enumerate((a(z), b(z), c(z))):
+            self.rows[m].append([(v.kind, v.idx, k) for v, k in lc.terms if k != 0])  # prover.rs:31
+
+    @staticmethod
+    def capture(circuit):
+        cs = ShapeAssembly()
+        cs.alloc_input(lambda: 1)
+        circuit(cs)
+        for i in range(cs.num_inputs):  # prover.rs:208-215
+            cs.enforce(lambda lc, i=i: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
+        return cs
+
+    def csr(self):
+        """-> (row_ptr, var, coeff_index) x3 as uint32 arrays, coefficient table (ints, [0] == 1)."""
+        table, index = [1], {1: 0}
+        out = []
+        for rows in self.rows:
+            row_ptr, var, coeff = [0], [], []
+            for row in rows:
+                for kind, idx, k in row:
+                    if k not in index:
+                        index[k] = len(table)
+                        table.append(k)
+                    var.append(idx if kind == INPUT else self.num_inputs + idx)
+                    coeff.append(index[k])
+                row_ptr.append(len(var))
+            out.append(tuple(np.asarray(x, dtype=np.uint32) for x in (row_ptr, var, coeff)))
+        return out, table
+
+
+class _Csr(ctypes.Structure):
+    _fields_ = [("row_ptr", ctypes.c_void_p), ("var", ctypes.c_void_p), ("coeff", ctypes.c_void_p)]
+
+
+class R1CS:
+    """The circuit's A/B/C matrices registered on the device (bh_r1cs)."""
+
+    def __init__(self, worker, handle):
+        self.worker, self._h = worker, handle
+        lib = _lib.load()
+        n = [ctypes.c_size_t() for _ in range(3)]
+        check(lib.bh_r1cs_shape(self._h, *[ctypes.byref(x) for x in n]), "R1CS")
+        self.num_inputs, self.num_aux, self.num_constraints = (x.value for x in n)
+
+    @staticmethod
+    def from_csr(worker, num_inputs, num_aux, matrices, coeff_table):
+        lib = _lib.load()
+        n_cons = len(matrices[0][0]) - 1
+        keep = [tuple(np.ascontiguousarray(x, dtype=np.uint32) for x in m) for m in matrices]
+        abc = (_Csr * 3)(*[_Csr(*[x.ctypes.data for x in m]) for m in keep])
+        coeffs = fr_to_mont_array(list(coeff_table))
+        h = ctypes.c_void_p()
+        check(lib.bh_r1cs_create(worker.ctx, num_inputs, num_aux, n_cons, ctypes.byref(abc),
+                                 coeffs.ctypes.data_as(ctypes.c_void_p), coeffs.shape[0], ctypes.byref(h)), "R1CS")
+        return R1CS(worker, h)
+
+    @staticmethod
+    def from_circuit(worker, circuit):
+        cs = ShapeAssembly.capture(circuit)
+        matrices, table = cs.csr()
+        return R1CS.from_csr(worker, cs.num_inputs, cs.num_aux, matrices, table)
+
+    @staticmethod
+    def from_demo(worker, kind, size, seed=0, constants=None):
+        lib = _lib.load()
+        con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+        h = ctypes.c_void_p()
+        check(lib.bh_groth16_demo_r1cs(worker.ctx, kind, size, seed, con.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)), "R1CS")
+        return R1CS(worker, h)
+
+    def density(self, which):
+        """which: 0 a_aux, 1 b_input, 2 b_aux -> (bool array, total)"""
+        lib = _lib.load()
+        host, total = ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib.bh_r1cs_density(self._h, which, None, ctypes.byref(host), ctypes.byref(total)), "R1CS")
+        n = self.num_inputs if which == 1 else self.num_aux
+        nw = (n + 63) // 64
+        words = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint64)), shape=(max(nw, 1),)).copy()
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
+        return bits, total.value
+
+    def eval(self, input_assignment, aux_assignment):
+        """a, b, c evaluations ([m,4] uint64 Montgomery, m = next power of two) - parity-test hook."""
+        lib = _lib.load()
+        ctx = self.worker.ctx
+        log_m = 0
+        while (1 << log_m) < self.num_constraints:
+            log_m += 1
+        m = 1 << log_m
+        ia, aa = fr_to_mont_array(list(input_assignment)), fr_to_mont_array(list(aux_assignment))
+        bufs = []
+        for nbytes in (ia.nbytes + 32, aa.nbytes + 32, m * 32, m * 32, m * 32):
+            d = ctypes.c_void_p()
+            check(lib.bh_dev_alloc(ctx, nbytes, ctypes.byref(d)), "R1CS.eval")
+            bufs.append(d)
+        try:
+            check(lib.bh_dev_upload(ctx, bufs[0], ia.ctypes.data_as(ctypes.c_void_p), ia.nbytes), "R1CS.eval")
+            if aa.nbytes:
+                check(lib.bh_dev_upload(ctx, bufs[1], aa.ctypes.data_as(ctypes.c_void_p), aa.nbytes), "R1CS.eval")
+            check(lib.bh_r1cs_eval_dev(ctx, self._h, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], log_m, None), "R1CS.eval")
+            outs = []
+            for d in bufs[2:]:
+                o = np.zeros((m, 4), dtype=np.uint64)
+                check(lib.bh_dev_download(ctx, o.ctypes.data_as(ctypes.c_void_p), d, o.nbytes), "R1CS.eval")
+                outs.append(o)
+        finally:
+            for d in bufs:
+                lib.bh_dev_free(ctx, d)
+        return outs
+
+    def release(self):
+        if self._h:
+            _lib.load().bh_r1cs_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class WitnessAssignment(ConstraintSystem):
+    """prover.rs:57-162 reduced to witness generation (enforce is a no-op)."""
+
+    def __init__(self):
+        self.input_assignment, self.aux_assignment = [], []
+
+    def alloc(self, f):
+        self.aux_assignment.append(f() % Q)
+        return Variable(AUX, len(self.aux_assignment) - 1)
+
+    def alloc_input(self, f):
+        self.input_assignment.append(f() % Q)
+        return Variable(INPUT, len(self.input_assignment) - 1)
+
+    def enforce(self, a, b, c):
+        pass
+
+
+def prove_witness(r1cs, params, input_assignment, aux_assignment, r, s, timings=None):
+    lib = _lib.load()
+    ia, aa = fr_to_mont_array(list(input_assignment)), fr_to_mont_array(list(aux_assignment))
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_witness(params._h, r1cs._h, p(ia), ia.shape[0], p(aa), aa.shape[0], p(rs[0:1]), p(rs[1:2]),
+                                       p(out), tm), "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)
+
+
+def create_proof_r1cs(circuit, r1cs, params, r, s, timings=None):
+    """create_proof with the constraint evaluation on the device: only `circuit`'s value closures run here."""
+    w = WitnessAssignment()
+    w.alloc_input(lambda: 1)
+    circuit(w)
+    return prove_witness(r1cs, params, w.input_assignment, w.aux_assignment, r, s, timings)
+
+
+def create_proof_demo_r1cs(params, r1cs, kind, size, seed, witness, constants, r, s, timings=None):
+    lib = _lib.load()
+    wit = fr_to_mont_array(list(witness))
+    con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_demo_r1cs(params._h, r1cs._h, kind, size, seed, p(wit), p(con), p(rs[0:1]), p(rs[1:2]),
+                                         p(out), tm), "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)

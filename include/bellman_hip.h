@@ -187,6 +187,47 @@ int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint
                           const void *witness, const void *constants, const void *r, const void *s,
                           void *proof_out, float *timings4);
 
+/* ---- R1CS resident in HBM: constraint evaluation as sparse matrix x witness --------
+ * The reference evaluates the A/B/C linear combinations of every constraint on one host thread
+ * during synthesis (groth16/src/prover.rs:19-55 `eval`, :105-145 `enforce`).  The matrices are a
+ * property of the circuit (like the CRS), so they are registered once; per proof only the witness
+ * is uploaded and a = A.w, b = B.w, c = C.w are computed on the device, where the h block consumes
+ * them.  Row i of a matrix holds terms [row_ptr[i], row_ptr[i+1]); a term is (var, coeff): var <
+ * n_inputs addresses input_assignment[var], otherwise aux_assignment[var - n_inputs]; coeff indexes
+ * `coeffs` (n_coeffs Montgomery Fr, coeffs[0] must be 1).  Terms with a zero coefficient contribute
+ * neither to the value nor to the query densities (prover.rs:31).  n_constraints includes the
+ * `input_i * 0 = 0` rows that create_proof appends (prover.rs:208-215). */
+typedef struct bh_r1cs bh_r1cs;
+typedef struct {
+  const uint32_t *row_ptr; /* n_constraints + 1 */
+  const uint32_t *var;     /* nnz */
+  const uint32_t *coeff;   /* nnz */
+} bh_csr;
+int bh_r1cs_create(bh_ctx *ctx, size_t n_inputs, size_t n_aux, size_t n_constraints, const bh_csr abc[3],
+                   const void *coeffs, size_t n_coeffs, bh_r1cs **out);
+void bh_r1cs_release(bh_r1cs *r);
+int bh_r1cs_shape(const bh_r1cs *r, size_t *n_inputs, size_t *n_aux, size_t *n_constraints);
+/* which: 0 a_aux_density, 1 b_input_density, 2 b_aux_density (prover.rs:59-61): LSB0 words on the
+ * device / on the host, and get_total_density() (multiexp.rs:154-156).  Any out pointer may be NULL. */
+int bh_r1cs_density(const bh_r1cs *r, int which, const uint64_t **dev_words, const uint64_t **host_words,
+                    size_t *total);
+/* a/b/c[0 .. 2^log_m) <- constraint evaluations (Montgomery), zero above n_constraints
+ * (EvaluationDomain::from_coeffs padding, domain.rs:68).  Asynchronous on `stream`. */
+int bh_r1cs_eval_dev(bh_ctx *ctx, const bh_r1cs *r, const void *inputs_dev, const void *aux_dev,
+                     void *a_dev, void *b_dev, void *c_dev, uint32_t log_m, void *stream);
+/* create_proof (prover.rs:217-360) from the witness alone: input_assignment (n_inputs, [0] = 1) and
+ * aux_assignment (n_aux) as produced by the circuit's alloc closures; lengths must match the R1CS. */
+int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
+                             size_t n_inputs, const void *aux_assignment, size_t n_aux, const void *r,
+                             const void *s, void *proof_out, float *timings4);
+/* The demo circuits of bh_groth16_prove_demo through that path: capture the matrices once ... */
+int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants,
+                         bh_r1cs **out);
+/* ... then per proof run only the circuit's witness closures on the host (enforce is a no-op). */
+int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
+                               uint64_t seed, const void *witness, const void *constants, const void *r,
+                               const void *s, void *proof_out, float *timings4);
+
 /* ---- self-test hooks used by tests/ (element-wise field / group ops on the device) ---- */
 int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
 int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
