@@ -8,6 +8,9 @@ there is no CPU fallback - importing works without a GPU, creating a `Worker` do
 
 from .errors import (  # noqa: F401
     BellmanHipError,
+    InvalidData,
+    InvalidPoint,
+    PointAtInfinity,
     PolynomialDegreeTooLarge,
     SynthesisError,
     UnexpectedEof,

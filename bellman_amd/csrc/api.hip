@@ -4,6 +4,7 @@
 #include <atomic>
 
 #include "common.hpp"
+#include "msm_types.hpp"
 
 namespace bh {
 // fft.hip
@@ -52,29 +53,56 @@ __global__ void pack_bases_kernel(const unsigned char *raw, size_t stride, long 
 
 // Zcash uncompressed encoding -> device records: one thread per 48-byte big-endian coordinate.
 // coordinate order in: G1 x|y ; G2 x.c1|x.c0|y.c1|y.c0   out: G1 x|y ; G2 x.c0|x.c1|y.c0|y.c1
+// `status` (optional, one word per point, zeroed by the caller) receives the PointStatus bits of the
+// encoding rules of from_uncompressed_unchecked; `bad_flag` (optional) is the legacy any-compressed flag.
 __global__ void decode_uncompressed_kernel(const unsigned char *raw, u32 coords_per_point, fp_t *out, u64 n,
-                                           u32 *bad_flag) {
+                                           u32 *bad_flag, u32 *status) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * coords_per_point) return;
   const u64 pt = t / coords_per_point;
   const u32 ci = (u32)(t % coords_per_point);
   const unsigned char *p0 = raw + pt * coords_per_point * 48;
   const unsigned char flags = p0[0];
-  if (flags & 0x80) atomicOr(bad_flag, 1u);   // compressed form is not this entry point's format
+  if ((flags & 0x80) && bad_flag) atomicOr(bad_flag, 1u);   // compressed form is not this entry point's format
   const bool inf = (flags & 0x40) != 0;
   const unsigned char *src = p0 + (size_t)ci * 48;
   fp_t v;
+  u32 nonzero = 0;
 #pragma unroll
   for (int w = 0; w < 12; w++) {   // limb w (little-endian) = bytes [44-4w, 48-4w) big-endian
     const unsigned char *b = src + 44 - 4 * w;
     u32 x = ((u32)b[0] << 24) | ((u32)b[1] << 16) | ((u32)b[2] << 8) | (u32)b[3];
     if (ci == 0 && w == 11) x &= 0x1fffffffu;   // strip the three flag bits
+    nonzero |= x;
     v.l[w] = inf ? 0u : x;
+  }
+  if (status) {
+    u32 st = 0;
+    if (ci == 0) {
+      if (flags & 0x80) st |= PT_COMPRESSED;
+      if (flags & 0x20) st |= PT_SORT;
+      if (inf) st |= PT_IS_INF;
+    }
+    if (inf && nonzero) st |= PT_INF_NONZERO;
+    // canonical coordinate: value < p  (Fp::from_bytes)
+    u32 borrow = 0;
+#pragma unroll
+    for (int w = 0; w < 12; w++) (void)subb(v.l[w], FpParams::mod(w), borrow, borrow);
+    if (!borrow) st |= PT_RANGE;
+    if (st) atomicOr(status + pt, st);
   }
   if (!inf) fe_to_mont(v, v);
   // G2 stores c1 before c0 on the wire
   const u32 co = (coords_per_point == 4) ? (ci ^ 1u) : ci;
   out[pt * coords_per_point + co] = v;
+}
+
+// smallest index whose status makes Parameters::read fail (lib.rs:300-315)
+__global__ void first_bad_point_kernel(const u32 *status, u64 n, u32 forbid_identity, unsigned long long *min_idx) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    const u32 st = status[i];
+    if ((st & PT_INVALID_MASK) || (forbid_identity && (st & PT_IS_INF))) atomicMin(min_idx, (unsigned long long)i);
+  }
 }
 }  // namespace bh
 
@@ -320,7 +348,7 @@ int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_byte
     BH_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->c.stream));
     const u64 threads = (u64)n * cpp;
     hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, ctx->c.stream,
-                       (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, flag);
+                       (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, flag, (u32 *)nullptr);
     BH_HIP_CHECK(hipGetLastError());
     u32 bad = 0;
     BH_HIP_CHECK(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->c.stream));
@@ -330,6 +358,69 @@ int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_byte
   }
   if (rc != BH_OK) { (void)hipFree(dev); return rc; }
   *out = new bh_bases{group, dev, n, true};
+  return BH_OK;
+}
+int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, unsigned flags,
+                               bh_bases **out, size_t *bad_index) {
+  if (!ctx || !out || (group != BH_G1 && group != BH_G2) || (n && !host_bytes)) return BH_ERR_INVALID_ARG;
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  const u32 cpp = group == BH_G1 ? 2 : 4;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *dev = nullptr;
+  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  if (n) {
+    hipStream_t st = ctx->c.stream;
+    void *raw = nullptr;
+    const size_t status_off = (n * rec + 15) & ~size_t(15);
+    if (hipMalloc(&raw, status_off + n * 4 + 16) != hipSuccess) { (void)hipFree(dev); return BH_ERR_HIP; }
+    u32 *status = (u32 *)((char *)raw + status_off);
+    unsigned long long *min_idx = (unsigned long long *)((char *)status + ((n * 4 + 7) & ~size_t(7)));
+    unsigned long long first = ~0ULL;
+    u32 first_status = 0;
+    int rc = BH_OK;
+    auto run = [&]() -> int {
+      BH_HIP_CHECK(hipMemcpyAsync(raw, host_bytes, n * rec, hipMemcpyHostToDevice, st));
+      BH_HIP_CHECK(hipMemsetAsync(status, 0, n * 4, st));
+      BH_HIP_CHECK(hipMemsetAsync(min_idx, 0xff, 8, st));
+      const u64 threads = (u64)n * cpp;
+      hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st,
+                         (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, (u32 *)nullptr, status);
+      BH_HIP_CHECK(hipGetLastError());
+      if (flags & BH_POINTS_CHECKED) {
+        int r = points_check(group, dev, n, status, st);
+        if (r != BH_OK) return r;
+      }
+      const u64 blocks = (n + 255) / 256;
+      hipLaunchKernelGGL(first_bad_point_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, status,
+                         (u64)n, (flags & BH_POINTS_FORBID_IDENTITY) ? 1u : 0u, min_idx);
+      BH_HIP_CHECK(hipGetLastError());
+      BH_HIP_CHECK(hipMemcpyAsync(&first, min_idx, 8, hipMemcpyDeviceToHost, st));
+      BH_HIP_CHECK(hipStreamSynchronize(st));
+      if (first != ~0ULL) {
+        BH_HIP_CHECK(hipMemcpyAsync(&first_status, status + first, 4, hipMemcpyDeviceToHost, st));
+        BH_HIP_CHECK(hipStreamSynchronize(st));
+      }
+      return BH_OK;
+    };
+    rc = run();
+    (void)hipFree(raw);
+    if (rc == BH_OK && first != ~0ULL) {
+      if (bad_index) *bad_index = (size_t)first;
+      rc = (first_status & PT_INVALID_MASK) ? BH_ERR_INVALID_POINT : BH_ERR_POINT_AT_INFINITY;
+    }
+    if (rc != BH_OK) { (void)hipFree(dev); return rc; }
+  }
+  *out = new bh_bases{group, dev, n, true};
+  return BH_OK;
+}
+int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host) {
+  if (!ctx || !b || first + count > b->n) return BH_ERR_INVALID_ARG;
+  const size_t rec = b->group == BH_G1 ? 96 : 192;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (count) {
+    BH_HIP_CHECK(hipMemcpyAsync(out_host, (const char *)b->dev + first * rec, count * rec, hipMemcpyDeviceToHost, ctx->c.stream));
+    BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  }
   return BH_OK;
 }
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {

@@ -348,6 +348,12 @@ struct FpOps {
   BH_HD static void dbl(T &r, const T &a) { fe_add(r, a, a); }
   BH_HD static void mul(T &r, const T &a, const T &b) { r = fp_mul_call(a, b); }
   BH_HD static void sqr(T &r, const T &a) { r = fp_mul_call(a, a); }
+  BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
+    T one2;
+    fe_one(r);
+    fe_add(one2, r, r);
+    fe_add(r, one2, one2);
+  }
   BH_HD static void inv(T &r, const T &a) {  // a^(p-2)
     u32 e[12];
 #pragma unroll
@@ -395,6 +401,10 @@ struct Fp2Ops {
     p = fp_mul_call(a.c0, a.c1);
     r.c0 = fp_mul_call(s, d);
     fe_add(r.c1, p, p);
+  }
+  BH_HD static void curve_b(T &r) {   // G2: y^2 = x^3 + 4(u + 1)
+    FpOps::curve_b(r.c0);
+    r.c1 = r.c0;
   }
   BH_HD static void inv(T &r, const T &a) {
     fp_t n, t;

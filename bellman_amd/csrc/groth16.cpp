@@ -1,5 +1,6 @@
 // Host side of groth16::create_proof over the C ABI (see groth16.hpp for the reference map).
 #include "groth16.hpp"
+#include "host_fp.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -128,6 +129,125 @@ Parameters::Parameters(bh_ctx *c, const VerifyingKey &k, const G1Affine *hq, siz
   check(bh_bases_register(ctx, BH_G1, b1, nb1, 96, -1, &b_g1));
   check(bh_bases_register(ctx, BH_G2, b2, nb2, 192, -1, &b_g2));
 }
+// ---- groth16/src/lib.rs:159-215 (VerifyingKey::read) + :289-398 (Parameters::read) --------------------
+namespace {
+struct ByteReader {
+  const unsigned char *p;
+  size_t len, pos = 0;
+  size_t remaining() const { return len - pos; }
+};
+[[noreturn]] void throw_io(int rc, int group) {
+  switch (rc) {
+    case BH_ERR_UNEXPECTED_EOF: throw bellman::IoError(rc, "failed to fill whole buffer");
+    case BH_ERR_INVALID_POINT: throw bellman::IoError(rc, group == BH_G1 ? "invalid G1" : "invalid G2");
+    case BH_ERR_POINT_AT_INFINITY: throw bellman::IoError(rc, "point at infinity");
+    default: check(rc); throw std::runtime_error("unreachable");
+  }
+}
+// reads `count` points the way the reference's read loop does: every complete point is validated in
+// stream order first; running out of bytes is reported only if all points before the cut are fine
+bh_bases *read_points(bh_ctx *ctx, ByteReader &rd, int group, size_t count, unsigned flags) {
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  const size_t complete = rd.remaining() / rec < count ? rd.remaining() / rec : count;
+  bh_bases *b = nullptr;
+  const int rc = bh_bases_read_uncompressed(ctx, group, rd.p + rd.pos, complete, flags, &b, nullptr);
+  if (rc != BH_OK) throw_io(rc, group);
+  if (complete < count) { bh_bases_release(ctx, b); throw_io(BH_ERR_UNEXPECTED_EOF, group); }
+  rd.pos += count * rec;
+  return b;
+}
+size_t read_u32_be(ByteReader &rd) {
+  if (rd.remaining() < 4) throw_io(BH_ERR_UNEXPECTED_EOF, BH_G1);
+  const unsigned char *q = rd.p + rd.pos;
+  rd.pos += 4;
+  return ((size_t)q[0] << 24) | ((size_t)q[1] << 16) | ((size_t)q[2] << 8) | (size_t)q[3];
+}
+struct BasesGuard {   // releases what was read so far if a later section throws
+  bh_ctx *ctx;
+  std::vector<bh_bases *> v;
+  ~BasesGuard() { for (bh_bases *b : v) bh_bases_release(ctx, b); }
+  bh_bases *keep(bh_bases *b) { v.push_back(b); return b; }
+};
+}  // namespace
+
+Parameters::Parameters(bh_ctx *c, const void *bytes, size_t len, bool checked) : ctx(c) {
+  ByteReader rd{(const unsigned char *)bytes, len};
+  BasesGuard guard{ctx, {}};
+  // verifying key: always from_uncompressed (lib.rs:160-185); identity allowed except in ic (:199-207)
+  auto vk_point = [&](int group, void *out) {
+    bh_bases *b = guard.keep(read_points(ctx, rd, group, 1, BH_POINTS_CHECKED));
+    check(bh_bases_download(ctx, b, 0, 1, out));
+  };
+  G2Affine gamma_g2;   // verifier-only; validated like the reference does, then dropped
+  vk_point(BH_G1, &vk.alpha_g1); vk_point(BH_G1, &vk.beta_g1); vk_point(BH_G2, &vk.beta_g2);
+  vk_point(BH_G2, &gamma_g2); vk_point(BH_G1, &vk.delta_g1); vk_point(BH_G2, &vk.delta_g2);
+  guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), BH_POINTS_CHECKED | BH_POINTS_FORBID_IDENTITY));   // ic
+  const unsigned qflags = (checked ? BH_POINTS_CHECKED : 0u) | BH_POINTS_FORBID_IDENTITY;   // lib.rs:294-315
+  bh_bases *hq = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
+  bh_bases *lq = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
+  bh_bases *aq = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
+  bh_bases *b1 = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
+  bh_bases *b2 = guard.keep(read_points(ctx, rd, BH_G2, read_u32_be(rd), qflags));
+  h = hq; l = lq; a = aq; b_g1 = b1; b_g2 = b2;
+  // the five query vectors now belong to this object; the verifying-key scratch handles are released
+  std::vector<bh_bases *> scratch;
+  for (bh_bases *b : guard.v)
+    if (b != h && b != l && b != a && b != b_g1 && b != b_g2) scratch.push_back(b);
+  guard.v.swap(scratch);
+}
+
+// ---- groth16/src/lib.rs:38-46 (Proof::write): Zcash compressed encoding ------------------------------
+namespace {
+void fp_to_be48(unsigned char *out, const uint64_t mont[6], bool *lex_largest, bool *is_zero) {
+  bh::hfp_t a, one_raw, c;
+  memcpy(a.l, mont, 48);
+  memset(one_raw.l, 0, 48);
+  one_raw.l[0] = 1;
+  bh::hostfp::mul(c, a, one_raw);   // Montgomery -> canonical
+  for (int i = 0; i < 6; i++)
+    for (int b = 0; b < 8; b++) out[47 - (8 * i + b)] = (unsigned char)(c.l[i] >> (8 * b));
+  // y > (p - 1) / 2   <=>   2y > p - 1   <=>   2y >= p + 1 > p  (p odd)
+  uint64_t d[7];
+  uint64_t carry = 0;
+  for (int i = 0; i < 6; i++) { d[i] = (c.l[i] << 1) | carry; carry = c.l[i] >> 63; }
+  d[6] = carry;
+  bool gt = d[6] != 0;
+  if (!gt) {
+    gt = false;
+    for (int i = 5; i >= 0; i--) {
+      if (d[i] != bh::hostfp::MOD[i]) { gt = d[i] > bh::hostfp::MOD[i]; break; }
+    }
+  }
+  *lex_largest = gt;
+  *is_zero = (c.l[0] | c.l[1] | c.l[2] | c.l[3] | c.l[4] | c.l[5]) == 0;
+}
+}  // namespace
+
+void Proof::write(unsigned char out[192]) const {
+  auto g1 = [](const G1Affine &p, unsigned char *o) {
+    if (p.is_identity()) { memset(o, 0, 48); o[0] = 0xC0; return; }
+    bool ly, zy, lx, zx;
+    unsigned char ybuf[48];
+    fp_to_be48(o, p.v, &lx, &zx);
+    fp_to_be48(ybuf, p.v + 6, &ly, &zy);
+    o[0] |= 0x80 | (ly ? 0x20 : 0);
+  };
+  g1(a, out);
+  if (b.is_identity()) { memset(out + 48, 0, 96); out[48] = 0xC0; }
+  else {
+    // x.c1 | x.c0 ; sort flag from y: compare c1 first, c0 only when c1 = 0
+    bool l0, z0, l1, z1, t0, t1;
+    unsigned char y0[48], y1[48];
+    fp_to_be48(out + 48 + 48, b.v, &t0, &t1);        // x.c0 second
+    fp_to_be48(out + 48, b.v + 6, &t0, &t1);         // x.c1 first
+    fp_to_be48(y0, b.v + 12, &l0, &z0);
+    fp_to_be48(y1, b.v + 18, &l1, &z1);
+    const bool largest = z1 ? l0 : l1;
+    out[48] |= 0x80 | (largest ? 0x20 : 0);
+  }
+  g1(c, out + 144);
+}
+
 Parameters::~Parameters() {
   bh_bases_release(ctx, h); bh_bases_release(ctx, l); bh_bases_release(ctx, a);
   bh_bases_release(ctx, b_g1); bh_bases_release(ctx, b_g2);
@@ -645,6 +765,39 @@ int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta
     return BH_OK;
   } catch (const bellman::SynthesisError &e) { return e.code;
   } catch (...) { return BH_ERR_HIP; }
+}
+int bh_groth16_params_read(bh_ctx *ctx, const void *bytes, size_t len, int checked, bh_params **out) {
+  if (!ctx || !out || (len && !bytes)) return BH_ERR_INVALID_ARG;
+  try {
+    *out = new bh_params{new groth16::Parameters(ctx, bytes, len, checked != 0)};
+    return BH_OK;
+  } catch (const bellman::IoError &e) { return e.code;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (...) { return BH_ERR_HIP; }
+}
+int bh_groth16_params_query(const bh_params *p, int which, const bh_bases **bases, size_t *len) {
+  if (!p || which < 0 || which > 4) return BH_ERR_INVALID_ARG;
+  const bh_bases *q[5] = {p->p->h, p->p->l, p->p->a, p->p->b_g1, p->p->b_g2};
+  if (bases) *bases = q[which];
+  if (len) *len = bh_bases_len(q[which]);
+  return BH_OK;
+}
+int bh_groth16_params_vk(const bh_params *p, void *alpha_g1, void *beta_g1, void *beta_g2, void *delta_g1, void *delta_g2) {
+  if (!p) return BH_ERR_INVALID_ARG;
+  const groth16::VerifyingKey &vk = p->p->vk;
+  if (alpha_g1) memcpy(alpha_g1, &vk.alpha_g1, 96);
+  if (beta_g1) memcpy(beta_g1, &vk.beta_g1, 96);
+  if (beta_g2) memcpy(beta_g2, &vk.beta_g2, 192);
+  if (delta_g1) memcpy(delta_g1, &vk.delta_g1, 96);
+  if (delta_g2) memcpy(delta_g2, &vk.delta_g2, 192);
+  return BH_OK;
+}
+void bh_proof_write(const void *proof_affine, void *out192) {
+  groth16::Proof p;
+  memcpy(&p.a, proof_affine, 96);
+  memcpy(&p.b, (const char *)proof_affine + 96, 192);
+  memcpy(&p.c, (const char *)proof_affine + 288, 96);
+  p.write((unsigned char *)out192);
 }
 void bh_groth16_params_release(bh_params *p) {
   if (!p) return;

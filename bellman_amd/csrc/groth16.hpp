@@ -47,6 +47,12 @@ struct SynthesisError : std::runtime_error {
   SynthesisError(int c, const char *what) : std::runtime_error(what), code(c) {}
 };
 
+// io::Error as raised by Parameters::read / VerifyingKey::read (groth16/src/lib.rs:159-215,289-398)
+struct IoError : std::runtime_error {
+  int code;   // BH_ERR_UNEXPECTED_EOF, BH_ERR_INVALID_POINT ("invalid G1"/"invalid G2"), BH_ERR_POINT_AT_INFINITY
+  IoError(int c, const char *what) : std::runtime_error(what), code(c) {}
+};
+
 // ---- src/lib.rs:163-185 -------------------------------------------------------------------------
 enum class Index { Input, Aux };
 struct Variable {
@@ -152,7 +158,10 @@ using bellman::Fr;
 struct G1Affine { uint64_t v[12]; bool is_identity() const; };   // x | y, Montgomery; all-zero = identity
 struct G2Affine { uint64_t v[24]; bool is_identity() const; };
 
-struct Proof { G1Affine a; G2Affine b; G1Affine c; };             // groth16/src/lib.rs:25-30
+struct Proof {                                                    // groth16/src/lib.rs:25-30
+  G1Affine a; G2Affine b; G1Affine c;
+  void write(unsigned char out[192]) const;                       // :38-46 compressed A | B | C
+};
 
 struct VerifyingKey {                                             // groth16/src/lib.rs:91-117 (prover-relevant part)
   G1Affine alpha_g1, beta_g1;
@@ -166,6 +175,9 @@ class Parameters {
  public:
   Parameters(bh_ctx *ctx, const VerifyingKey &vk, const G1Affine *h, size_t nh, const G1Affine *l, size_t nl,
              const G1Affine *a, size_t na, const G1Affine *b_g1, size_t nb1, const G2Affine *b_g2, size_t nb2);
+  // Parameters::read (groth16/src/lib.rs:289-398): the serialized CRS, decoded (and with
+  // `checked` validated: on the curve, in the prime-order subgroup) on the device.  Throws IoError.
+  Parameters(bh_ctx *ctx, const void *bytes, size_t len, bool checked);
   ~Parameters();
   Parameters(const Parameters &) = delete;
   bh_ctx *ctx;

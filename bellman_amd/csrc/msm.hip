@@ -96,6 +96,9 @@ int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u6
   return group == BH_G1 ? fixed_base_mul_g1(base_host, scalars_dev, n, fmt, out_dev, st)
                         : fixed_base_mul_g2(base_host, scalars_dev, n, fmt, out_dev, st);
 }
+int points_check(int group, const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {
+  return group == BH_G1 ? points_check_g1(pts_dev, n, status_dev, st) : points_check_g2(pts_dev, n, status_dev, st);
+}
 int test_point_add(int group, void *r, const void *a, const void *b, u64 n, hipStream_t st) {
   return group == BH_G1 ? test_point_add_g1(r, a, b, n, st) : test_point_add_g2(r, a, b, n, st);
 }

@@ -312,6 +312,42 @@ __global__ void point_add_kernel(Affine<F> *r, const Affine<F> *a, const Affine<
   xyzz_to_affine(o, z);
   r[i] = o;
 }
+// from_uncompressed's two group-membership tests (bls12_381: is_on_curve & is_torsion_free) for
+// points the decode kernel already accepted: y^2 = x^3 + b, then [q]P = O by plain double-and-add
+// (q is the same for every lane, so the loop does not diverge).  One-time CRS loading work.
+template <class F>
+__global__ void __launch_bounds__(64) point_check_kernel(const Affine<F> *pts, u64 n, u32 *status) {
+  typedef typename F::T T;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 st = status[i];
+  if (st & (PT_INVALID_MASK | PT_IS_INF)) return;
+  const Affine<F> p = pts[i];
+  T lhs, rhs, b;
+  F::sqr(lhs, p.y);
+  F::sqr(rhs, p.x);
+  F::mul(rhs, rhs, p.x);
+  F::curve_b(b);
+  F::add(rhs, rhs, b);
+  if (!F::eq(lhs, rhs)) { status[i] = st | PT_OFF_CURVE; return; }
+  XYZZ<F> acc;
+  xyzz_set_identity(acc);
+  for (int bit = 254; bit >= 0; bit--) {
+    XYZZ<F> t;
+    xyzz_dbl(t, acc);
+    acc = t;
+    if ((FrParams::mod(bit >> 5) >> (bit & 31)) & 1) xyzz_madd(acc, p);
+  }
+  if (!xyzz_is_identity(acc)) status[i] = st | PT_NOT_IN_SUBGROUP;
+}
+template <class F>
+static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {
+  const u32 blocks = (u32)((n + 63) / 64);
+  if (!blocks) return BH_OK;
+  hipLaunchKernelGGL(point_check_kernel<F>, dim3(blocks), dim3(64), 0, st, (const Affine<F> *)pts_dev, n, status_dev);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
 // ============================================================================================
 // host orchestration
 // ============================================================================================
@@ -609,6 +645,9 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
   int fixed_base_mul_##SUFFIX(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,  \
                               hipStream_t st) {                                                               \
     return fixed_base_mul_t<OPS>(base_host, scalars_dev, n, fmt, out_dev, st);                                \
+  }                                                                                                           \
+  int points_check_##SUFFIX(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {                    \
+    return points_check_t<OPS>(pts_dev, n, status_dev, st);                                                   \
   }                                                                                                           \
   int test_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n, hipStream_t st) {                 \
     return test_point_add_t<OPS>(r, a, b, n, st);                                                             \

@@ -80,6 +80,21 @@ int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int
 int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
 int test_point_add_g1(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 int test_point_add_g2(void *r, const void *a, const void *b, u64 n, hipStream_t st);
+// per-point status word of the uncompressed-point loader (api.hip decode kernel + point_check_kernel)
+enum PointStatus : u32 {
+  PT_COMPRESSED = 1,        // compression flag set on an uncompressed point
+  PT_SORT = 2,              // sort flag set on an uncompressed point
+  PT_RANGE = 4,             // a coordinate is not < p
+  PT_INF_NONZERO = 8,       // infinity flag with non-zero coordinate bits
+  PT_IS_INF = 16,           // (valid) identity
+  PT_OFF_CURVE = 32,
+  PT_NOT_IN_SUBGROUP = 64,
+  PT_INVALID_MASK = PT_COMPRESSED | PT_SORT | PT_RANGE | PT_INF_NONZERO | PT_OFF_CURVE | PT_NOT_IN_SUBGROUP,
+};
+// on-curve + prime-order-subgroup test of decoded points (skips entries already invalid / identity)
+int points_check_g1(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);
+int points_check_g2(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);
+int points_check(int group, const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);
 void host_point_add_g1(void *r, const void *a, const void *b, u64 n);
 void host_point_add_g2(void *r, const void *a, const void *b, u64 n);
 void host_point_mul_g1(void *r, const void *a, const void *k);

@@ -17,6 +17,18 @@ class PolynomialDegreeTooLarge(SynthesisError):
     """src/domain.rs:57-59"""
 
 
+class InvalidData(IOError):
+    """io::ErrorKind::InvalidData from Parameters::read / VerifyingKey::read (groth16/src/lib.rs:159-215,289-398)"""
+
+
+class InvalidPoint(InvalidData):
+    """"invalid G1" / "invalid G2": bad encoding, or (checked) not on the curve / not in the subgroup"""
+
+
+class PointAtInfinity(InvalidData):
+    """"point at infinity": a query or ic point is the identity"""
+
+
 class BellmanHipError(RuntimeError):
     """HIP runtime failure / missing device: never silently replaced by a CPU path."""
 
@@ -30,6 +42,10 @@ def check(rc, what="bellman_hip call"):
         raise UnexpectedEof("expected more bases from source")
     if rc == 3:
         raise PolynomialDegreeTooLarge()
+    if rc == 6:
+        raise InvalidPoint("invalid G1/G2")
+    if rc == 7:
+        raise PointAtInfinity("point at infinity")
     if rc == -2:
         # the reference panics here (assert!), e.g. src/multiexp.rs:324-329, src/domain.rs:155,174
         raise AssertionError("%s: invalid argument (the reference panics)" % what)

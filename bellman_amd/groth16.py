@@ -137,6 +137,13 @@ class Proof:
     def __init__(self, raw):
         self.a, self.b, self.c = raw[:12].copy(), raw[12:36].copy(), raw[36:48].copy()
 
+    def write(self):
+        """Proof::write (groth16/src/lib.rs:38-46): compressed A (48) | B (96) | C (48)"""
+        raw = np.concatenate([self.a, self.b, self.c]).astype(np.uint64)
+        out = np.zeros(192, dtype=np.uint8)
+        _lib.load().bh_proof_write(raw.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        return out.tobytes()
+
 
 class Parameters:
     """`&Parameters` as ParameterSource (groth16/src/lib.rs:435-473); query vectors live in HBM."""
@@ -152,6 +159,38 @@ class Parameters:
                                            qs[1].shape[0], p(qs[2]), qs[2].shape[0], p(qs[3]), qs[3].shape[0],
                                            p(qs[4]), qs[4].shape[0], ctypes.byref(h_)), "Parameters")
         self._h = h_
+
+    @classmethod
+    def read(cls, worker, data, checked):
+        """Parameters::read(reader, checked) (groth16/src/lib.rs:289-398): serialized CRS bytes ->
+        device-resident parameters; decoding and validation run on the GPU.  Raises UnexpectedEof,
+        InvalidPoint or PointAtInfinity - whichever the reference's sequential reader hits first."""
+        lib = _lib.load()
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        self = cls.__new__(cls)
+        self.worker = worker
+        h_ = ctypes.c_void_p()
+        self._h = None
+        check(lib.bh_groth16_params_read(worker.ctx, buf.ctypes.data_as(ctypes.c_void_p), buf.size, 1 if checked else 0,
+                                         ctypes.byref(h_)), "Parameters.read")
+        self._h = h_
+        return self
+
+    def query(self, which):
+        """which in h, l, a, b_g1, b_g2 -> affine Montgomery records of that query, read back from HBM"""
+        lib = _lib.load()
+        idx = ("h", "l", "a", "b_g1", "b_g2").index(which)
+        b, n = ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib.bh_groth16_params_query(self._h, idx, ctypes.byref(b), ctypes.byref(n)), "Parameters.query")
+        out = np.zeros((n.value, 24 if idx == 4 else 12), dtype=np.uint64)
+        check(lib.bh_bases_download(self.worker.ctx, b, 0, n.value, out.ctypes.data_as(ctypes.c_void_p)), "Parameters.query")
+        return out
+
+    def vk(self):
+        """alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2 as affine Montgomery records"""
+        outs = [np.zeros(w, dtype=np.uint64) for w in (12, 12, 24, 12, 24)]
+        check(_lib.load().bh_groth16_params_vk(self._h, *[o.ctypes.data_as(ctypes.c_void_p) for o in outs]), "Parameters.vk")
+        return outs
 
     def release(self):
         if self._h:

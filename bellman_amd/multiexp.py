@@ -89,6 +89,36 @@ class Bases:
         return self
 
     @classmethod
+    def read_uncompressed(cls, worker, group, data, checked=True, forbid_identity=True):
+        """The per-point part of `Parameters::read(reader, checked)` (groth16/src/lib.rs:289-341):
+        `from_uncompressed` (checked: on the curve and in the prime-order subgroup) or
+        `from_uncompressed_unchecked`, plus the "point at infinity" rule; all on the device.
+        Raises InvalidPoint / PointAtInfinity carrying `.index` = first offending point."""
+        rec = _WORDS[group] * 8
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        assert buf.size % rec == 0
+        self = cls.__new__(cls)
+        self.worker, self.group, self.n = worker, group, buf.size // rec
+        h, bad = ctypes.c_void_p(), ctypes.c_size_t(0)
+        flags = (1 if checked else 0) | (2 if forbid_identity else 0)
+        try:
+            check(_lib.load().bh_bases_read_uncompressed(worker.ctx, group, buf.ctypes.data_as(ctypes.c_void_p), self.n, flags,
+                                                         ctypes.byref(h), ctypes.byref(bad)), "bases_read_uncompressed")
+        except IOError as e:
+            e.index = bad.value
+            raise
+        self._h = h
+        return self
+
+    def download(self, first=0, count=None):
+        """affine Montgomery records [count, 12|24] uint64 back from HBM"""
+        count = self.n - first if count is None else count
+        out = np.zeros((count, _WORDS[self.group]), dtype=np.uint64)
+        check(_lib.load().bh_bases_download(self.worker.ctx, self._h, first, count, out.ctypes.data_as(ctypes.c_void_p)),
+              "bases_download")
+        return out
+
+    @classmethod
     def wrap_device(cls, worker, group, dev_ptr, n):
         self = cls.__new__(cls)
         self.worker, self.group, self.n = worker, group, n

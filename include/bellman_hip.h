@@ -32,6 +32,8 @@ extern "C" {
 #define BH_ERR_UNEXPECTED_IDENTITY 1 /* SynthesisError::UnexpectedIdentity   src/multiexp.rs:63-65   */
 #define BH_ERR_UNEXPECTED_EOF 2      /* SynthesisError::IoError(UnexpectedEof) src/multiexp.rs:55-61,74-80 */
 #define BH_ERR_DEGREE_TOO_LARGE 3    /* SynthesisError::PolynomialDegreeTooLarge src/domain.rs:57-59 */
+#define BH_ERR_INVALID_POINT 6       /* io::ErrorKind::InvalidData "invalid G1" / "invalid G2" groth16/src/lib.rs:300-304,326-330 */
+#define BH_ERR_POINT_AT_INFINITY 7   /* io::ErrorKind::InvalidData "point at infinity"         groth16/src/lib.rs:306-315,332-341 */
 #define BH_ERR_HIP (-1)              /* HIP runtime failure (message on stderr) */
 #define BH_ERR_INVALID_ARG (-2)      /* the reference would panic (e.g. density length mismatch,
                                         src/multiexp.rs:324-329; length mismatch src/domain.rs:155,174) */
@@ -111,6 +113,18 @@ int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n,
  * subgroup check is made; a compressed-form flag returns BH_ERR_INVALID_ARG. */
 int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n,
                                    bh_bases **out);
+/* `from_uncompressed` / `from_uncompressed_unchecked` + the identity test of Parameters::read
+ * (groth16/src/lib.rs:289-341) for `n` uncompressed points, all on the device.  Without flags only
+ * the encoding rules are enforced (flag bits, coordinates < p, a clean infinity encoding);
+ * BH_POINTS_CHECKED adds the on-curve and prime-order-subgroup tests, BH_POINTS_FORBID_IDENTITY the
+ * "point at infinity" rule.  On BH_ERR_INVALID_POINT / BH_ERR_POINT_AT_INFINITY *bad_index (optional)
+ * is the first offending point in stream order, which is the one the reference reports. */
+#define BH_POINTS_CHECKED 1u
+#define BH_POINTS_FORBID_IDENTITY 2u
+int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, unsigned flags,
+                               bh_bases **out, size_t *bad_index);
+/* copies `count` device-resident affine records (Montgomery) starting at `first` back to the host */
+int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host);
 /* wrap an existing device array of packed 96/192-byte records (not owned) */
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 void bh_bases_release(bh_ctx *ctx, bh_bases *b);
@@ -169,6 +183,20 @@ int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta
                              const void *delta_g1, const void *delta_g2, const void *h, size_t nh,
                              const void *l, size_t nl, const void *a, size_t na, const void *b_g1,
                              size_t nb1, const void *b_g2, size_t nb2, bh_params **out);
+/* Parameters::read(reader, checked) (groth16/src/lib.rs:289-398, with VerifyingKey::read :159-215) on
+ * the serialized CRS (`Parameters::write`, :258-287): decoding, and with checked != 0 the on-curve /
+ * subgroup validation of the query points, run on the device; the verifying key is always validated.
+ * The first failure in stream order is returned, as the reference's sequential reader would:
+ * BH_ERR_INVALID_POINT, BH_ERR_POINT_AT_INFINITY (query and ic points must not be the identity) or
+ * BH_ERR_UNEXPECTED_EOF (input ends inside the structure). Trailing bytes are ignored. */
+int bh_groth16_params_read(bh_ctx *ctx, const void *bytes, size_t len, int checked, bh_params **out);
+/* which: 0 h, 1 l, 2 a, 3 b_g1, 4 b_g2 - the device-resident query (owned by the params) and its length */
+int bh_groth16_params_query(const bh_params *p, int which, const bh_bases **bases, size_t *len);
+/* the prover-side verifying-key elements as affine Montgomery records (any pointer may be NULL) */
+int bh_groth16_params_vk(const bh_params *p, void *alpha_g1, void *beta_g1, void *beta_g2, void *delta_g1,
+                         void *delta_g2);
+/* Proof::write (groth16/src/lib.rs:38-46): affine a | b | c (384 B) -> compressed A (48) | B (96) | C (48) */
+void bh_proof_write(const void *proof_affine, void *out192);
 void bh_groth16_params_release(bh_params *p);
 /* prover.rs:217-360 on the fields of a synthesised ProvingAssignment (prover.rs:57-71): a/b/c
  * evaluations (n_constraints, input constraints of :208-215 already appended), input/aux
