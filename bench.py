@@ -68,7 +68,7 @@ G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1
 )
 
 
-def bench_create_proof(worker, lib, log_n, proofs=3):
+def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     """BASELINE config C4: groth16::create_proof on a synthetic 2^log_n-constraint R1CS (the C++
     chain circuit of groth16.cpp), synthetic CRS generated on the device by the product's
     fixed-base kernel (distinct prime-order points; not a trusted setup - timing only)."""
@@ -100,7 +100,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3):
     for i in range(proofs + 1):
         tm = [0, 0, 0, 0]
         t0 = time.perf_counter()
-        pg.create_proof_demo(params, 1, rounds, 2020 + i, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
+        last = pg.create_proof_demo(params, 1, rounds, 2020 + i, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
         wall = (time.perf_counter() - t0) * 1e3
         if i:
             tms.append(tm + [wall])
@@ -141,6 +141,31 @@ def bench_create_proof(worker, lib, log_n, proofs=3):
     conc_r = threads * per_thread / (time.perf_counter() - t0)
     r1cs.release()
     params.release()
+    cpu = None
+    if cpu_baseline:
+        # CPU baseline for this metric: the C restatement of prover.rs:217-360 (oracle/cprover.py: bellman's
+        # parallel_fft split, its window rule, the eight multiexps issued together so that their window
+        # tasks share all host cores), one proof, same inputs as the last GPU proof - which it must equal.
+        from oracle import cprover, cref
+        from tests import circuits
+
+        i = proofs
+        f = circuits.chain_assignment_fast(rounds, 2020 + i, 987654321 + i)
+        vk = dict(alpha_g1=vk1[0], beta_g1=vk1[1], beta_g2=vk2[0], delta_g1=vk1[2], delta_g2=vk2[1])
+        cpu_threads = cref.lib().orc_max_threads()
+        tcpu = {}
+        want = cprover.prove_assignment(f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"],
+                                        f["b_input_density"], f["b_aux_density"], vk, h, l, a, b1, b2, 0xABCDEF0123 + i,
+                                        0x123456789AB, threads=cpu_threads, concurrent=True, timing=tcpu)
+        assert last.a.tobytes() == want[0].tobytes() and last.b.tobytes() == want[1].tobytes() and \
+            last.c.tobytes() == want[2].tobytes(), "GPU proof differs from the CPU oracle's"
+        cpu = {
+            "value": round(1.0 / tcpu["total_s"], 4), "unit": "proofs/s", "cores": cpu_threads, "kind": "port",
+            "sample": "1 proof, same 2^%d-constraint instance (proof bit-identical to the GPU's): C restatement of "
+                      "prover.rs:217-360 on evaluations synthesised beforehand, the 8 multiexps issued together; host "
+                      "synthesis excluded (it would add to the CPU side only)" % log_n,
+            "seconds": round(tcpu["total_s"], 3),
+        }
     m = np.mean(np.array(tms), axis=0)
     mr = np.mean(np.array(tms_r), axis=0)
     return {
@@ -155,6 +180,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3):
         "proofs_per_s_concurrent": round(conc, 3),
         "concurrent_host_threads": threads,
         "samples": proofs,
+        "cpu_baseline": cpu,
         "with_r1cs_resident_in_hbm": {
             "note": "constraint matrices captured once per circuit (%.0f ms, untimed, like the CRS upload); per proof: "
                     "witness closures on the host, A.w/B.w/C.w + everything else on the device; identical proofs" % capture_ms,
@@ -372,7 +398,7 @@ def main():
             }
         if not args.no_proof and not distributed:
             out["fft"] = bench_fft(worker, lib)
-            out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n)
+            out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of
         # this same command (profiles/r1_pmc_accumulate.json), if it matches this workload
         try:

@@ -10,36 +10,53 @@ Q = cref.Q
 
 
 def prove_assignment(a_ev, b_ev, c_ev, input_assignment, aux_assignment, a_aux_density, b_input_density,
-                     b_aux_density, vk, h, l, a, b_g1, b_g2, r, s, threads=0):
+                     b_aux_density, vk, h, l, a, b_g1, b_g2, r, s, threads=0, concurrent=False, timing=None):
     """vk: dict of numpy records alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2.
-    Returns (a, b, c) affine records, or raises RuntimeError(code)."""
+    Returns (a, b, c) affine records, or raises RuntimeError(code).
+    concurrent: issue the eight multiexps together, as prover.rs:244-318 does on the rayon pool
+    (their window tasks then share all host cores).  timing (dict, optional) receives the seconds
+    spent in the C restatement only (h block + multiexps + assembly), excluding the Python-side
+    conversion of the inputs."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
     n = len(a_ev)
     m = 1
     while m < n:
         m *= 2
     pad = lambda v: cref.fr_to_mont(cref.ints_to_arr(list(v) + [0] * (m - n), 4))  # noqa: E731
-    hco = cref.fr_from_mont(cref.h_coeffs(pad(a_ev), pad(b_ev), pad(c_ev), threads=threads or 8))  # canonical
+    pa, pb, pc = pad(a_ev), pad(b_ev), pad(c_ev)
     ia = cref.ints_to_arr(list(input_assignment), 4)
     aa = cref.ints_to_arr(list(aux_assignment), 4) if len(aux_assignment) else np.zeros((0, 4), dtype=np.uint64)
     n_in = len(input_assignment)
     b_in_total = int(sum(b_input_density))
+    dens = {id(d): cref.density_bitmap(d) for d in (a_aux_density, b_input_density, b_aux_density)}
+    t0 = time.perf_counter()
+    hco = cref.fr_from_mont(cref.h_coeffs(pa, pb, pc, threads=threads or 8))  # canonical
 
     def me(group, bases, offset, density, scalars):
-        rc, pt = cref.multiexp(group, bases, offset, None if density is None else cref.density_bitmap(density), scalars,
+        rc, pt = cref.multiexp(group, bases, offset, None if density is None else dens[id(density)], scalars,
                                threads=threads)
         return rc, pt
 
     # wait order of prover.rs:339-354
-    jobs = [
-        me(1, a, 0, None, ia),
-        me(1, a, n_in, a_aux_density, aa),
-        me(1, b_g1, 0, b_input_density, ia),
-        me(1, b_g1, b_in_total, b_aux_density, aa),
-        me(2, b_g2, 0, b_input_density, ia),
-        me(2, b_g2, b_in_total, b_aux_density, aa),
-        me(1, h, 0, None, hco),
-        me(1, l, 0, None, aa),
+    calls = [
+        (1, a, 0, None, ia),
+        (1, a, n_in, a_aux_density, aa),
+        (1, b_g1, 0, b_input_density, ia),
+        (1, b_g1, b_in_total, b_aux_density, aa),
+        (2, b_g2, 0, b_input_density, ia),
+        (2, b_g2, b_in_total, b_aux_density, aa),
+        (1, h, 0, None, hco),
+        (1, l, 0, None, aa),
     ]
+    if concurrent:
+        with ThreadPoolExecutor(max_workers=len(calls)) as ex:
+            jobs = list(ex.map(lambda c: me(*c), calls))
+    else:
+        jobs = [me(*c) for c in calls]
+    if timing is not None:
+        timing["multiexp_and_h_s"] = time.perf_counter() - t0
     if not vk["delta_g1"].any() or not vk["delta_g2"].any():
         raise RuntimeError(1)
     for rc, _ in jobs:
@@ -61,4 +78,6 @@ def prove_assignment(a_ev, b_ev, c_ev, input_assignment, aux_assignment, a_aux_d
     g_c = add(1, g_c, mul(1, b1_answer, r))
     g_c = add(1, g_c, h_res)
     g_c = add(1, g_c, l_res)
+    if timing is not None:
+        timing["total_s"] = time.perf_counter() - t0
     return g_a, g_b, g_c

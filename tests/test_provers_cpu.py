@@ -78,3 +78,24 @@ def test_oracle_provers_agree_on_small_mimc():
                                    pa.b_input_density.bv, pa.b_aux_density.bv, vk, G1.to_array(p_c.h), G1.to_array(p_c.l),
                                    G1.to_array(p_c.a), G1.to_array(p_c.b_g1), G2.to_array(p_c.b_g2), r, s)
     assert got[0].tobytes() == proof_c.a and got[1].tobytes() == proof_c.b and got[2].tobytes() == proof_c.c
+
+
+def test_cprover_concurrent_issue_gives_the_same_proof():
+    """oracle/cprover.py: issuing the eight multiexps together (prover.rs:244-318) is unobservable."""
+    from oracle import cprover, cref
+    from tests import circuits
+
+    rounds, seed, x0 = 70, 5, 424242
+    f = circuits.chain_assignment_fast(rounds, seed, x0)
+    m = 128
+    h, l = cref.gen_bases(1, m - 1, a=11, b=3), cref.gen_bases(1, rounds + 1, a=5, b=7)
+    a, b1, b2 = cref.gen_bases(1, rounds + 3, a=2, b=9), cref.gen_bases(1, 40, a=13, b=4), cref.gen_bases(2, 40, a=17, b=6)
+    g1, g2 = cref.g1_generator(), cref.g2_generator()
+    vk = dict(alpha_g1=cref.point_mul(1, g1, 101), beta_g1=cref.point_mul(1, g1, 102), beta_g2=cref.point_mul(2, g2, 102),
+              delta_g1=cref.point_mul(1, g1, 103), delta_g2=cref.point_mul(2, g2, 103))
+    args = (f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"], f["b_input_density"],
+            f["b_aux_density"], vk, h, l, a, b1, b2, 77, 88)
+    tm = {}
+    p1 = cprover.prove_assignment(*args)
+    p2 = cprover.prove_assignment(*args, threads=4, concurrent=True, timing=tm)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(p1, p2)) and tm["total_s"] >= tm["multiexp_and_h_s"] > 0
