@@ -13,6 +13,7 @@ from .errors import (  # noqa: F401
     PointAtInfinity,
     PolynomialDegreeTooLarge,
     SynthesisError,
+    UnconstrainedVariable,
     UnexpectedEof,
     UnexpectedIdentity,
 )

@@ -14,6 +14,7 @@ int fr_sub_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st);
 int fr_divide_by_z(Context &c, fr_t *a, uint32_t log_n, hipStream_t st);
 int fr_distribute_powers(Context &c, fr_t *a, u64 n, const fr_t &g, hipStream_t st);
 int h_poly_dev(Context &c, fr_t *a, fr_t *b, fr_t *cc, fr_t *scratch, uint32_t log_n, hipStream_t st);
+int fr_gen_powers(Context &c, fr_t *out, u64 n, const fr_t &g, const fr_t &scale, hipStream_t st);
 // msm.hip
 struct MsmJobImpl;
 MsmJobImpl *msm_job_new(Context *ctx, int group);
@@ -267,6 +268,13 @@ int bh_fr_distribute_powers_dev(bh_ctx *ctx, void *a, size_t n, const void *g_ho
   memcpy(&g, g_host, sizeof g);
   return fr_distribute_powers(ctx->c, (fr_t *)a, n, g, pick_stream(ctx, stream));
 }
+int bh_fr_powers_dev(bh_ctx *ctx, void *out, size_t n, const void *g_host, const void *scale_host, void *stream) {
+  fr_t g, sc;
+  memcpy(&g, g_host, sizeof g);
+  memcpy(&sc, scale_host, sizeof sc);
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return fr_gen_powers(ctx->c, (fr_t *)out, n, g, sc, pick_stream(ctx, stream));
+}
 int bh_h_poly_fr_dev(bh_ctx *ctx, void *a, void *b, void *c, uint32_t log_n, void *stream) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
@@ -421,6 +429,19 @@ int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count
     BH_HIP_CHECK(hipMemcpyAsync(out_host, (const char *)b->dev + first * rec, count * rec, hipMemcpyDeviceToHost, ctx->c.stream));
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
+  return BH_OK;
+}
+int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {
+  if (!ctx || !out || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *dev = nullptr;
+  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  if (n) {
+    BH_HIP_CHECK(hipMemcpyAsync(dev, dev_points, n * rec, hipMemcpyDeviceToDevice, ctx->c.stream));
+    BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  }
+  *out = new bh_bases{group, dev, n, true};
   return BH_OK;
 }
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {

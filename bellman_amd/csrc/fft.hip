@@ -382,6 +382,12 @@ int fr_distribute_powers(Context &c, fr_t *a, u64 n, const fr_t &g, hipStream_t 
   fe_one(one);
   return launch_gen_powers(a, n, g, one, 1, st);
 }
+// out[i] = scale * g^i (generator.rs:249-263 powers of tau, with the h-query factor folded in)
+int fr_gen_powers(Context &c, fr_t *out, u64 n, const fr_t &g, const fr_t &scale, hipStream_t st) {
+  (void)c;
+  if (!n) return BH_OK;
+  return launch_gen_powers(out, n, g, scale, 0, st);
+}
 // prover.rs:221-240 on device-resident, already padded a,b,c; result (m entries) in a
 int h_poly_dev(Context &c, fr_t *a, fr_t *b, fr_t *cc, fr_t *scratch, uint32_t log_n, hipStream_t st) {
   int rc;

@@ -102,6 +102,23 @@ void Fr::to_canonical(uint64_t out[4]) const {
   const uint64_t one[4] = {1, 0, 0, 0};
   mont_mul(out, l, one);
 }
+Fr Fr::pow_vartime(uint64_t e) const {
+  Fr acc = Fr::one();
+  for (int i = 63; i >= 0; i--) {
+    acc = acc * acc;
+    if ((e >> i) & 1) acc = acc * *this;
+  }
+  return acc;
+}
+Fr Fr::invert() const {   // a^(q-2)
+  uint64_t e[4] = {FR_MOD[0] - 2, FR_MOD[1], FR_MOD[2], FR_MOD[3]};   // no borrow: the low limb ends in ...00000001 + 0xffffffff00000000
+  Fr acc = Fr::one();
+  for (int i = 255; i >= 0; i--) {
+    acc = acc * acc;
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = acc * *this;
+  }
+  return acc;
+}
 }  // namespace bellman
 
 namespace groth16 {
@@ -119,6 +136,16 @@ static void check(int rc) {
     default: throw std::runtime_error("bellman_hip: HIP/runtime failure (no CPU fallback)");
   }
 }
+
+namespace {
+struct DevBuf {
+  bh_ctx *ctx;
+  void *p = nullptr;
+  DevBuf(bh_ctx *c, size_t bytes) : ctx(c) { check(bh_dev_alloc(ctx, bytes, &p)); }
+  ~DevBuf() { if (p) bh_dev_free(ctx, p); }
+  DevBuf(const DevBuf &) = delete;
+};
+}  // namespace
 
 Parameters::Parameters(bh_ctx *c, const VerifyingKey &k, const G1Affine *hq, size_t nh, const G1Affine *lq, size_t nl,
                        const G1Affine *aq, size_t na, const G1Affine *b1, size_t nb1, const G2Affine *b2, size_t nb2)
@@ -178,10 +205,14 @@ Parameters::Parameters(bh_ctx *c, const void *bytes, size_t len, bool checked) :
     bh_bases *b = guard.keep(read_points(ctx, rd, group, 1, BH_POINTS_CHECKED));
     check(bh_bases_download(ctx, b, 0, 1, out));
   };
-  G2Affine gamma_g2;   // verifier-only; validated like the reference does, then dropped
   vk_point(BH_G1, &vk.alpha_g1); vk_point(BH_G1, &vk.beta_g1); vk_point(BH_G2, &vk.beta_g2);
-  vk_point(BH_G2, &gamma_g2); vk_point(BH_G1, &vk.delta_g1); vk_point(BH_G2, &vk.delta_g2);
-  guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), BH_POINTS_CHECKED | BH_POINTS_FORBID_IDENTITY));   // ic
+  vk_point(BH_G2, &vk.gamma_g2); vk_point(BH_G1, &vk.delta_g1); vk_point(BH_G2, &vk.delta_g2);
+  {
+    const size_t n_ic = read_u32_be(rd);
+    bh_bases *ic = guard.keep(read_points(ctx, rd, BH_G1, n_ic, BH_POINTS_CHECKED | BH_POINTS_FORBID_IDENTITY));
+    vk.ic.resize(n_ic);
+    check(bh_bases_download(ctx, ic, 0, n_ic, vk.ic.data()));
+  }
   const unsigned qflags = (checked ? BH_POINTS_CHECKED : 0u) | BH_POINTS_FORBID_IDENTITY;   // lib.rs:294-315
   bh_bases *hq = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
   bh_bases *lq = guard.keep(read_points(ctx, rd, BH_G1, read_u32_be(rd), qflags));
@@ -194,6 +225,129 @@ Parameters::Parameters(bh_ctx *c, const void *bytes, size_t len, bool checked) :
   for (bh_bases *b : guard.v)
     if (b != h && b != l && b != a && b != b_g1 && b != b_g2) scratch.push_back(b);
   guard.v.swap(scratch);
+}
+
+// ---- groth16/src/generator.rs:163-510 ------------------------------------------------------------------
+namespace {
+template <class A>
+std::vector<A> download_points(bh_ctx *ctx, const void *dev, size_t n) {
+  std::vector<A> v(n);
+  if (n) check(bh_dev_download(ctx, v.data(), dev, n * sizeof(A)));
+  return v;
+}
+template <class A>
+void drop_identities(std::vector<A> &v) {   // generator.rs:491-505
+  size_t k = 0;
+  for (size_t i = 0; i < v.size(); i++)
+    if (!v[i].is_identity()) v[k++] = v[i];
+  v.resize(k);
+}
+}  // namespace
+
+Parameters::Parameters(bh_ctx *c, R1cs &r1cs, const G1Affine &g1, const G2Affine &g2, const Fr &alpha, const Fr &beta,
+                       const Fr &gamma, const Fr &delta, const Fr &tau)
+    : ctx(c) {
+  if (gamma.is_zero() || delta.is_zero())   // generator.rs:227-243
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
+  const Fr gamma_inv = gamma.invert(), delta_inv = delta.invert();
+  const size_t n_cons = r1cs.num_constraints, n_in = r1cs.num_inputs, n_vars = r1cs.num_inputs + r1cs.num_aux;
+  uint32_t log_m = 0;
+  size_t m = 1;
+  while (m < n_cons) {   // EvaluationDomain::from_coeffs, generator.rs:204-205
+    m *= 2;
+    log_m++;
+    if (log_m >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
+  }
+  const Fr one = Fr::one();
+  // h query: g1^(tau^i * t(tau) / delta), i < m - 1                                      generator.rs:247-296
+  const Fr coeff = (tau.pow_vartime(m) - one) * delta_inv;
+  DevBuf d_tau(ctx, m * 32), d_hs(ctx, m * 32), d_h(ctx, m * 96);
+  check(bh_fr_powers_dev(ctx, d_tau.p, m, &tau, &one, nullptr));
+  check(bh_fr_powers_dev(ctx, d_hs.p, m - 1, &tau, &coeff, nullptr));
+  check(bh_fixed_base_mul_dev(ctx, BH_G1, &g1, d_hs.p, m - 1, BH_SCALARS_MONT, d_h.p, nullptr));
+  // Lagrange coefficients of tau, then the QAP polynomials of every variable at tau       :299-387
+  check(bh_fft_fr_dev(ctx, d_tau.p, log_m, BH_IFFT, nullptr));
+  DevBuf d_at(ctx, n_vars * 32 + 32), d_bt(ctx, n_vars * 32 + 32), d_ct(ctx, n_vars * 32 + 32), d_e(ctx, n_vars * 32 + 32);
+  check(bh_r1cs_eval_transposed_dev(ctx, r1cs.handle, d_tau.p, d_at.p, d_bt.p, d_ct.p, nullptr));
+  check(bh_fr_qap_ext_dev(ctx, d_e.p, d_at.p, d_bt.p, d_ct.p, n_in, n_vars, &alpha, &beta, &gamma_inv, &delta_inv, nullptr));
+  // a = g1^at, b = g1^bt / g2^bt, ext = g1^e (a zero scalar gives the identity, :389-397)   :389-409
+  DevBuf d_a(ctx, n_vars * 96 + 96), d_b1(ctx, n_vars * 96 + 96), d_b2(ctx, n_vars * 192 + 192), d_ext(ctx, n_vars * 96 + 96);
+  check(bh_fixed_base_mul_dev(ctx, BH_G1, &g1, d_at.p, n_vars, BH_SCALARS_MONT, d_a.p, nullptr));
+  check(bh_fixed_base_mul_dev(ctx, BH_G1, &g1, d_bt.p, n_vars, BH_SCALARS_MONT, d_b1.p, nullptr));
+  check(bh_fixed_base_mul_dev(ctx, BH_G2, &g2, d_bt.p, n_vars, BH_SCALARS_MONT, d_b2.p, nullptr));
+  check(bh_fixed_base_mul_dev(ctx, BH_G1, &g1, d_e.p, n_vars, BH_SCALARS_MONT, d_ext.p, nullptr));
+  check(bh_ctx_synchronize(ctx));
+  std::vector<G1Affine> av = download_points<G1Affine>(ctx, d_a.p, n_vars), b1v = download_points<G1Affine>(ctx, d_b1.p, n_vars),
+                        ext = download_points<G1Affine>(ctx, d_ext.p, n_vars);
+  std::vector<G2Affine> b2v = download_points<G2Affine>(ctx, d_b2.p, n_vars);
+  for (size_t i = n_in; i < n_vars; i++)                       // :464-470
+    if (ext[i].is_identity()) throw SynthesisError(BH_ERR_UNCONSTRAINED_VARIABLE, "UnconstrainedVariable");
+  vk.ic.assign(ext.begin(), ext.begin() + n_in);
+  auto scalar_mul1 = [](const G1Affine &p, const Fr &k) { uint64_t kc[4]; k.to_canonical(kc); G1Affine r; bh_point_mul(BH_G1, &r, &p, kc); return r; };
+  auto scalar_mul2 = [](const G2Affine &p, const Fr &k) { uint64_t kc[4]; k.to_canonical(kc); G2Affine r; bh_point_mul(BH_G2, &r, &p, kc); return r; };
+  vk.alpha_g1 = scalar_mul1(g1, alpha); vk.beta_g1 = scalar_mul1(g1, beta); vk.beta_g2 = scalar_mul2(g2, beta);   // :475-484
+  vk.gamma_g2 = scalar_mul2(g2, gamma); vk.delta_g1 = scalar_mul1(g1, delta); vk.delta_g2 = scalar_mul2(g2, delta);
+  drop_identities(av); drop_identities(b1v); drop_identities(b2v);
+  BasesGuard guard{ctx, {}};
+  bh_bases *hq = nullptr, *lq = nullptr, *aq = nullptr, *b1q = nullptr, *b2q = nullptr;
+  check(bh_bases_copy_dev(ctx, BH_G1, d_h.p, m - 1, &hq)); guard.keep(hq);
+  check(bh_bases_register(ctx, BH_G1, ext.data() + n_in, n_vars - n_in, 96, -1, &lq)); guard.keep(lq);
+  check(bh_bases_register(ctx, BH_G1, av.data(), av.size(), 96, -1, &aq)); guard.keep(aq);
+  check(bh_bases_register(ctx, BH_G1, b1v.data(), b1v.size(), 96, -1, &b1q)); guard.keep(b1q);
+  check(bh_bases_register(ctx, BH_G2, b2v.data(), b2v.size(), 192, -1, &b2q)); guard.keep(b2q);
+  h = hq; l = lq; a = aq; b_g1 = b1q; b_g2 = b2q;
+  guard.v.clear();
+}
+
+// ---- groth16/src/lib.rs:143-156 + :258-287 (VerifyingKey::write, Parameters::write) -------------------
+namespace {
+void fp_to_be48(unsigned char *out, const uint64_t mont[6], bool *lex_largest, bool *is_zero);
+void put_g1(std::vector<unsigned char> &o, const G1Affine &p) {
+  const size_t at = o.size();
+  o.resize(at + 96, 0);
+  if (p.is_identity()) { o[at] = 0x40; return; }
+  bool x, y;
+  fp_to_be48(&o[at], p.v, &x, &y);
+  fp_to_be48(&o[at + 48], p.v + 6, &x, &y);
+}
+void put_g2(std::vector<unsigned char> &o, const G2Affine &p) {
+  const size_t at = o.size();
+  o.resize(at + 192, 0);
+  if (p.is_identity()) { o[at] = 0x40; return; }
+  bool x, y;
+  fp_to_be48(&o[at], p.v + 6, &x, &y);          // x.c1
+  fp_to_be48(&o[at + 48], p.v, &x, &y);         // x.c0
+  fp_to_be48(&o[at + 96], p.v + 18, &x, &y);    // y.c1
+  fp_to_be48(&o[at + 144], p.v + 12, &x, &y);   // y.c0
+}
+void put_u32(std::vector<unsigned char> &o, size_t v) {
+  for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s));
+}
+}  // namespace
+
+std::vector<unsigned char> Parameters::write() const {
+  std::vector<unsigned char> o;
+  put_g1(o, vk.alpha_g1); put_g1(o, vk.beta_g1); put_g2(o, vk.beta_g2); put_g2(o, vk.gamma_g2);
+  put_g1(o, vk.delta_g1); put_g2(o, vk.delta_g2);
+  put_u32(o, vk.ic.size());
+  for (const G1Affine &p : vk.ic) put_g1(o, p);
+  const bh_bases *qs[5] = {h, l, a, b_g1, b_g2};
+  for (int q = 0; q < 5; q++) {
+    const size_t n = bh_bases_len(qs[q]);
+    put_u32(o, n);
+    if (q < 4) {
+      std::vector<G1Affine> v(n);
+      check(bh_bases_download(ctx, qs[q], 0, n, v.data()));
+      o.reserve(o.size() + n * 96);
+      for (const G1Affine &p : v) put_g1(o, p);
+    } else {
+      std::vector<G2Affine> v(n);
+      check(bh_bases_download(ctx, qs[q], 0, n, v.data()));
+      o.reserve(o.size() + n * 192);
+      for (const G2Affine &p : v) put_g2(o, p);
+    }
+  }
+  return o;
 }
 
 // ---- groth16/src/lib.rs:38-46 (Proof::write): Zcash compressed encoding ------------------------------
@@ -299,13 +453,6 @@ void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
 }
 
 namespace {
-struct DevBuf {
-  bh_ctx *ctx;
-  void *p = nullptr;
-  DevBuf(bh_ctx *c, size_t bytes) : ctx(c) { check(bh_dev_alloc(ctx, bytes, &p)); }
-  ~DevBuf() { if (p) bh_dev_free(ctx, p); }
-  DevBuf(const DevBuf &) = delete;
-};
 struct ProofStream {   // uploads + h block of one proof; independent of other proofs in flight
   bh_ctx *ctx;
   void *st = nullptr;
@@ -774,6 +921,48 @@ int bh_groth16_params_read(bh_ctx *ctx, const void *bytes, size_t len, int check
   } catch (const bellman::IoError &e) { return e.code;
   } catch (const bellman::SynthesisError &e) { return e.code;
   } catch (...) { return BH_ERR_HIP; }
+}
+int bh_groth16_generate(bh_ctx *ctx, bh_r1cs *r1cs, const void *g1, const void *g2, const void *alpha, const void *beta,
+                        const void *gamma, const void *delta, const void *tau, bh_params **out) {
+  if (!ctx || !r1cs || !out) return BH_ERR_INVALID_ARG;
+  using namespace groth16;
+  try {
+    R1csView view(r1cs);
+    G1Affine p1; G2Affine p2;
+    Fr f[5];
+    memcpy(&p1, g1, 96); memcpy(&p2, g2, 192);
+    const void *src[5] = {alpha, beta, gamma, delta, tau};
+    for (int i = 0; i < 5; i++) memcpy(&f[i], src[i], 32);
+    *out = new bh_params{new Parameters(ctx, view.r, p1, p2, f[0], f[1], f[2], f[3], f[4])};
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (...) { return BH_ERR_HIP; }
+}
+int bh_groth16_params_write(const bh_params *p, void *buf, size_t cap, size_t *len) {
+  if (!p || !len) return BH_ERR_INVALID_ARG;
+  try {
+    const groth16::Parameters &P = *p->p;
+    size_t need = 864 + 4 + P.vk.ic.size() * 96 + 5 * 4;
+    const bh_bases *qs[5] = {P.h, P.l, P.a, P.b_g1, P.b_g2};
+    for (int q = 0; q < 5; q++) need += bh_bases_len(qs[q]) * (q < 4 ? 96 : 192);
+    *len = need;
+    if (!buf || cap < need) return buf ? BH_ERR_INVALID_ARG : BH_OK;   // size query when buf == NULL
+    std::vector<unsigned char> o = P.write();
+    memcpy(buf, o.data(), o.size());
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (...) { return BH_ERR_HIP; }
+}
+int bh_groth16_params_vk_ext(const bh_params *p, void *gamma_g2, void *ic_out, size_t ic_cap, size_t *n_ic) {
+  if (!p) return BH_ERR_INVALID_ARG;
+  const groth16::VerifyingKey &vk = p->p->vk;
+  if (gamma_g2) memcpy(gamma_g2, &vk.gamma_g2, 192);
+  if (n_ic) *n_ic = vk.ic.size();
+  if (ic_out) {
+    if (ic_cap < vk.ic.size()) return BH_ERR_INVALID_ARG;
+    if (!vk.ic.empty()) memcpy(ic_out, vk.ic.data(), vk.ic.size() * 96);
+  }
+  return BH_OK;
 }
 int bh_groth16_params_query(const bh_params *p, int which, const bh_bases **bases, size_t *len) {
   if (!p || which < 0 || which > 4) return BH_ERR_INVALID_ARG;

@@ -39,6 +39,8 @@ struct Fr {
   Fr operator*(const Fr &o) const;
   Fr neg() const;
   void to_canonical(uint64_t out[4]) const;   // the bits of Exponent::Bits (multiexp.rs:179)
+  Fr pow_vartime(uint64_t e) const;
+  Fr invert() const;                          // *this must not be zero
 };
 
 // ---- src/lib.rs:303-319 -------------------------------------------------------------------------
@@ -163,12 +165,17 @@ struct Proof {                                                    // groth16/src
   void write(unsigned char out[192]) const;                       // :38-46 compressed A | B | C
 };
 
-struct VerifyingKey {                                             // groth16/src/lib.rs:91-117 (prover-relevant part)
+struct VerifyingKey {                                             // groth16/src/lib.rs:91-128
   G1Affine alpha_g1, beta_g1;
   G2Affine beta_g2;
   G1Affine delta_g1;
   G2Affine delta_g2;
+  // verifier-side elements: not used by create_proof; filled by Parameters::read and the generator
+  G2Affine gamma_g2 = G2Affine{};
+  std::vector<G1Affine> ic;
 };
+
+class R1cs;
 
 // `&Parameters` as ParameterSource (groth16/src/lib.rs:435-473): the five query vectors live in HBM.
 class Parameters {
@@ -178,6 +185,14 @@ class Parameters {
   // Parameters::read (groth16/src/lib.rs:289-398): the serialized CRS, decoded (and with
   // `checked` validated: on the curve, in the prime-order subgroup) on the device.  Throws IoError.
   Parameters(bh_ctx *ctx, const void *bytes, size_t len, bool checked);
+  // generate_parameters (groth16/src/generator.rs:163-510) for the circuit whose matrices are `r1cs`:
+  // powers of tau, ifft to the Lagrange basis, the QAP polynomials at tau and every fixed-base
+  // multiplication run on the device.  Throws SynthesisError (UnexpectedIdentity for a zero gamma or
+  // delta, UnconstrainedVariable, PolynomialDegreeTooLarge).
+  Parameters(bh_ctx *ctx, R1cs &r1cs, const G1Affine &g1, const G2Affine &g2, const Fr &alpha, const Fr &beta,
+             const Fr &gamma, const Fr &delta, const Fr &tau);
+  // Parameters::write (groth16/src/lib.rs:258-287)
+  std::vector<unsigned char> write() const;
   ~Parameters();
   Parameters(const Parameters &) = delete;
   bh_ctx *ctx;

@@ -9,6 +9,7 @@
 // function of the matrices alone and are computed here once.
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -24,6 +25,14 @@ struct bh_r1cs {
   u64 *dens[3] = {nullptr, nullptr, nullptr};       // a_aux, b_input, b_aux (LSB0 words, device)
   size_t dens_total[3] = {0, 0, 0};
   std::vector<u64> dens_host[3];
+  // host copy of the matrices + the transposed (variable-major) device copy the parameter generator
+  // uses (generator.rs:43-131 stores exactly that: per variable, (coeff, constraint) lists); built on
+  // first use
+  std::vector<u32> h_row_ptr[3], h_var[3], h_coeff[3];
+  std::mutex t_mu;
+  bool t_ready = false;
+  u32 *t_row_ptr[3] = {nullptr, nullptr, nullptr};   // [n_inputs + n_aux + 1]
+  uint2 *t_terms[3] = {nullptr, nullptr, nullptr};   // (constraint, coefficient index)
 };
 
 namespace {
@@ -71,6 +80,19 @@ __global__ void __launch_bounds__(256) r1cs_eval_kernel(R1csEvalArgs a) {
       }
     }
     st_fr16(a.out[mat] + row, acc);
+  }
+}
+
+__global__ void __launch_bounds__(256) qap_ext_kernel(fr_t *e, const fr_t *at, const fr_t *bt, const fr_t *ct, u64 n_inputs,
+                                                      u64 n, fr_t alpha, fr_t beta, fr_t gamma_inv, fr_t delta_inv) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    fr_t a = ld_fr16(at + i), b = ld_fr16(bt + i), c = ld_fr16(ct + i);
+    fe_mul(a, a, beta);
+    fe_mul(b, b, alpha);
+    fe_add(a, a, b);
+    fe_add(a, a, c);
+    if (i < n_inputs) fe_mul(a, a, gamma_inv); else fe_mul(a, a, delta_inv);
+    st_fr16(e + i, a);
   }
 }
 
@@ -138,6 +160,9 @@ int bh_r1cs_create(bh_ctx *ctx, size_t n_inputs, size_t n_aux, size_t n_constrai
     const u32 nnz = abc[m].row_ptr[n_constraints];
     std::vector<uint2> terms(nnz);
     for (u32 t = 0; t < nnz; t++) terms[t] = make_uint2(abc[m].var[t], abc[m].coeff[t]);
+    r->h_row_ptr[m].assign(abc[m].row_ptr, abc[m].row_ptr + n_constraints + 1);
+    r->h_var[m].assign(abc[m].var, abc[m].var + nnz);
+    r->h_coeff[m].assign(abc[m].coeff, abc[m].coeff + nnz);
     rc = upload_vec(ctx, &r->row_ptr[m], abc[m].row_ptr, n_constraints + 1);
     if (rc == BH_OK) rc = upload_vec(ctx, &r->terms[m], terms.data(), (size_t)nnz);
     if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;   // `terms` is a local
@@ -155,6 +180,8 @@ void bh_r1cs_release(bh_r1cs *r) {
     r->ctx->c.pool.release(r->row_ptr[m]);
     r->ctx->c.pool.release(r->terms[m]);
     r->ctx->c.pool.release(r->dens[m]);
+    r->ctx->c.pool.release(r->t_row_ptr[m]);
+    r->ctx->c.pool.release(r->t_terms[m]);
   }
   r->ctx->c.pool.release(r->coeffs);
   delete r;
@@ -191,6 +218,69 @@ int bh_r1cs_eval_dev(bh_ctx *ctx, const bh_r1cs *r, const void *inputs_dev, cons
   const u64 blocks = (3 * a.m + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->c.stream;
   hipLaunchKernelGGL(r1cs_eval_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, a);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
+
+// QAP polynomials at tau (generator.rs:369-387 eval_at_tau for every variable): at[v] = sum over the
+// constraints j that use v in A of coeff * L_j(tau); the same sparse product as bh_r1cs_eval_dev on
+// the transposed matrices, with the Lagrange coefficients in the role of the witness.
+int bh_r1cs_eval_transposed_dev(bh_ctx *ctx, bh_r1cs *r, const void *lagrange_dev, void *at_dev, void *bt_dev,
+                                void *ct_dev, void *stream) {
+  if (!ctx || !r) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  const size_t n_vars = r->n_inputs + r->n_aux;
+  {
+    std::lock_guard<std::mutex> g(r->t_mu);
+    if (!r->t_ready) {
+      for (int m = 0; m < 3; m++) {
+        const size_t nnz = r->h_var[m].size();
+        std::vector<u32> rp(n_vars + 1, 0);
+        for (size_t t = 0; t < nnz; t++) rp[r->h_var[m][t] + 1]++;
+        for (size_t v = 0; v < n_vars; v++) rp[v + 1] += rp[v];
+        std::vector<uint2> terms(nnz);
+        std::vector<u32> cursor(rp.begin(), rp.end() - 1);
+        for (size_t row = 0; row < r->n_constraints; row++)
+          for (u32 t = r->h_row_ptr[m][row]; t < r->h_row_ptr[m][row + 1]; t++)
+            terms[cursor[r->h_var[m][t]]++] = make_uint2((u32)row, r->h_coeff[m][t]);
+        int rc = upload_vec(ctx, &r->t_row_ptr[m], rp.data(), rp.size());
+        if (rc == BH_OK) rc = upload_vec(ctx, &r->t_terms[m], terms.data(), nnz);
+        if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
+        if (rc != BH_OK) return rc;
+      }
+      r->t_ready = true;
+    }
+  }
+  R1csEvalArgs a;
+  for (int m = 0; m < 3; m++) { a.row_ptr[m] = r->t_row_ptr[m]; a.terms[m] = r->t_terms[m]; }
+  a.out[0] = (fr_t *)at_dev; a.out[1] = (fr_t *)bt_dev; a.out[2] = (fr_t *)ct_dev;
+  a.coeffs = r->coeffs; a.inputs = (const fr_t *)lagrange_dev; a.aux = (const fr_t *)lagrange_dev;
+  a.n_inputs = 0;                       // every "variable" of the product is a constraint index
+  a.n_constraints = n_vars;
+  a.m = n_vars;
+  if (!n_vars) return BH_OK;
+  const u64 blocks = (3 * a.m + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->c.stream;
+  hipLaunchKernelGGL(r1cs_eval_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, a);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
+
+// generator.rs:400-407: e[v] = (at[v]*beta + bt[v]*alpha + ct[v]) * inv, inv = 1/gamma for the public
+// inputs (ic) and 1/delta for the auxiliary variables (l)
+int bh_fr_qap_ext_dev(bh_ctx *ctx, void *e_dev, const void *at_dev, const void *bt_dev, const void *ct_dev,
+                      size_t n_inputs, size_t n_vars, const void *alpha, const void *beta, const void *gamma_inv,
+                      const void *delta_inv, void *stream) {
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (!n_vars) return BH_OK;
+  fr_t al, be, gi, di;
+  memcpy(&al, alpha, 32); memcpy(&be, beta, 32); memcpy(&gi, gamma_inv, 32); memcpy(&di, delta_inv, 32);
+  const u64 blocks = (n_vars + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->c.stream;
+  hipLaunchKernelGGL(qap_ext_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, (fr_t *)e_dev,
+                     (const fr_t *)at_dev, (const fr_t *)bt_dev, (const fr_t *)ct_dev, (u64)n_inputs, (u64)n_vars, al, be,
+                     gi, di);
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }

@@ -17,6 +17,10 @@ class PolynomialDegreeTooLarge(SynthesisError):
     """src/domain.rs:57-59"""
 
 
+class UnconstrainedVariable(SynthesisError):
+    """groth16/src/generator.rs:464-470"""
+
+
 class InvalidData(IOError):
     """io::ErrorKind::InvalidData from Parameters::read / VerifyingKey::read (groth16/src/lib.rs:159-215,289-398)"""
 
@@ -42,6 +46,8 @@ def check(rc, what="bellman_hip call"):
         raise UnexpectedEof("expected more bases from source")
     if rc == 3:
         raise PolynomialDegreeTooLarge()
+    if rc == 5:
+        raise UnconstrainedVariable()
     if rc == 6:
         raise InvalidPoint("invalid G1/G2")
     if rc == 7:

@@ -176,6 +176,44 @@ class Parameters:
         self._h = h_
         return self
 
+    @classmethod
+    def generate(cls, worker, r1cs, g1, g2, alpha, beta, gamma, delta, tau):
+        """generate_parameters (groth16/src/generator.rs:163-510) on the device for the circuit whose
+        matrices are `r1cs` (R1CS.from_circuit / from_demo).  g1, g2: affine Montgomery records (numpy
+        uint64 [12] / [24]); alpha..tau: ints.  Raises UnexpectedIdentity (gamma or delta = 0),
+        UnconstrainedVariable, PolynomialDegreeTooLarge."""
+        lib = _lib.load()
+        g1 = np.ascontiguousarray(g1, dtype=np.uint64)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint64)
+        sc = fr_to_mont_array([alpha, beta, gamma, delta, tau])
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self = cls.__new__(cls)
+        self.worker, self._h = worker, None
+        h_ = ctypes.c_void_p()
+        check(lib.bh_groth16_generate(worker.ctx, r1cs._h, p(g1), p(g2), *[p(sc[i:i + 1]) for i in range(5)], ctypes.byref(h_)),
+              "generate_parameters")
+        self._h = h_
+        return self
+
+    def write(self):
+        """Parameters::write (groth16/src/lib.rs:258-287) -> bytes"""
+        lib = _lib.load()
+        n = ctypes.c_size_t()
+        check(lib.bh_groth16_params_write(self._h, None, 0, ctypes.byref(n)), "Parameters.write")
+        buf = np.zeros(n.value, dtype=np.uint8)
+        check(lib.bh_groth16_params_write(self._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n)), "Parameters.write")
+        return buf.tobytes()
+
+    def vk_ext(self):
+        """gamma_g2 ([24] uint64) and ic ([n,12] uint64): the verifier-side key elements"""
+        lib = _lib.load()
+        n = ctypes.c_size_t()
+        gamma = np.zeros(24, dtype=np.uint64)
+        check(lib.bh_groth16_params_vk_ext(self._h, gamma.ctypes.data_as(ctypes.c_void_p), None, 0, ctypes.byref(n)), "vk_ext")
+        ic = np.zeros((n.value, 12), dtype=np.uint64)
+        check(lib.bh_groth16_params_vk_ext(self._h, None, ic.ctypes.data_as(ctypes.c_void_p), n.value, None), "vk_ext")
+        return gamma, ic
+
     def query(self, which):
         """which in h, l, a, b_g1, b_g2 -> affine Montgomery records of that query, read back from HBM"""
         lib = _lib.load()

@@ -70,37 +70,25 @@ G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1
 
 def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     """BASELINE config C4: groth16::create_proof on a synthetic 2^log_n-constraint R1CS (the C++
-    chain circuit of groth16.cpp), synthetic CRS generated on the device by the product's
-    fixed-base kernel (distinct prime-order points; not a trusted setup - timing only)."""
+    chain circuit of groth16.cpp).  The CRS is a real one for this circuit, made by the product's
+    device generator (generate_parameters, generator.rs:163-510) from fixed toxic waste - as the
+    reference's own tests do (groth16/src/tests/mod.rs:93-99); not a secure setup."""
     from bellman_amd import groth16 as pg
 
     rounds = (1 << log_n) - 3
-    n_aux = rounds + 1
-    nb = (rounds + 1) // 2 + 2
-
-    def gen(group, n, seed):
-        words = 12 if group == 1 else 24
-        t = splitmix_scalars(n, seed)
-        dt, dout = worker.alloc(n * 32), worker.alloc(n * 8 * words)
-        worker.upload(dt, t)
-        g = G1_GEN_MONT if group == 1 else G2_GEN_MONT
-        assert lib.bh_fixed_base_mul_dev(worker.ctx, group, g.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
-        worker.synchronize()
-        out = np.empty((n, words), dtype=np.uint64)
-        worker.download(out, dout)
-        worker.free(dt)
-        worker.free(dout)
-        return out
-
-    h, l = gen(1, (1 << log_n) - 1, 11), gen(1, n_aux, 12)
-    a, b1, b2 = gen(1, n_aux + 2, 13), gen(1, nb, 14), gen(2, nb, 15)
-    vk1, vk2 = gen(1, 3, 16), gen(2, 2, 17)
-    params = pg.Parameters(worker, vk1[0], vk1[1], vk2[0], vk1[2], vk2[1], h, l, a, b1, b2)
+    CIRCUIT_SEED = 2020
+    t0 = time.perf_counter()
+    r1cs = pg.R1CS.from_demo(worker, 1, rounds, CIRCUIT_SEED)
+    capture_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481,
+                                    tau=3673)
+    generate_ms = (time.perf_counter() - t0) * 1e3
     tms = []
     for i in range(proofs + 1):
         tm = [0, 0, 0, 0]
         t0 = time.perf_counter()
-        last = pg.create_proof_demo(params, 1, rounds, 2020 + i, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
+        last = pg.create_proof_demo(params, 1, rounds, CIRCUIT_SEED, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
         wall = (time.perf_counter() - t0) * 1e3
         if i:
             tms.append(tm + [wall])
@@ -110,7 +98,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     from concurrent.futures import ThreadPoolExecutor
 
     def one(i):
-        pg.create_proof_demo(params, 1, rounds, 3030 + i, [1234567 + i], None, 0x55AA + i, 0x77, None)
+        pg.create_proof_demo(params, 1, rounds, CIRCUIT_SEED, [1234567 + i], None, 0x55AA + i, 0x77, None)
 
     threads, per_thread = int(os.environ.get("BENCH_PROOF_THREADS", "12")), 2
     t0 = time.perf_counter()
@@ -120,29 +108,28 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     # the same proofs with the constraint matrices resident in HBM: the matrices are
     # captured ONCE per circuit (outside the timed region, like the CRS); a proof then runs only the
     # circuit's witness closures on the host and evaluates a = A.w, b = B.w, c = C.w on the device
-    t0 = time.perf_counter()
-    r1cs = pg.R1CS.from_demo(worker, 1, rounds, 0)
-    capture_ms = (time.perf_counter() - t0) * 1e3
     tms_r = []
     for i in range(proofs + 1):
         tm = [0, 0, 0, 0]
         t0 = time.perf_counter()
-        pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, 2020 + i, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
+        last_r = pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, CIRCUIT_SEED, [987654321 + i], None, 0xABCDEF0123 + i, 0x123456789AB, tm)
         wall = (time.perf_counter() - t0) * 1e3
         if i:
             tms_r.append(tm + [wall])
 
     def one_r(i):
-        pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, 3030 + i, [1234567 + i], None, 0x55AA + i, 0x77, None)
+        pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, CIRCUIT_SEED, [1234567 + i], None, 0x55AA + i, 0x77, None)
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(one_r, range(threads * per_thread)))
     conc_r = threads * per_thread / (time.perf_counter() - t0)
-    r1cs.release()
-    params.release()
+    assert last_r.a.tobytes() == last.a.tobytes() and last_r.b.tobytes() == last.b.tobytes() and \
+        last_r.c.tobytes() == last.c.tobytes(), "device-evaluated constraints gave a different proof"
     cpu = None
     if cpu_baseline:
+        h, l, a, b1, b2 = (params.query(q) for q in ("h", "l", "a", "b_g1", "b_g2"))
+        vkr = params.vk()
         # CPU baseline for this metric: the C restatement of prover.rs:217-360 (oracle/cprover.py: bellman's
         # parallel_fft split, its window rule, the eight multiexps issued together so that their window
         # tasks share all host cores), one proof, same inputs as the last GPU proof - which it must equal.
@@ -150,8 +137,8 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         from tests import circuits
 
         i = proofs
-        f = circuits.chain_assignment_fast(rounds, 2020 + i, 987654321 + i)
-        vk = dict(alpha_g1=vk1[0], beta_g1=vk1[1], beta_g2=vk2[0], delta_g1=vk1[2], delta_g2=vk2[1])
+        f = circuits.chain_assignment_fast(rounds, CIRCUIT_SEED, 987654321 + i)
+        vk = dict(alpha_g1=vkr[0], beta_g1=vkr[1], beta_g2=vkr[2], delta_g1=vkr[3], delta_g2=vkr[4])
         cpu_threads = cref.lib().orc_max_threads()
         tcpu = {}
         want = cprover.prove_assignment(f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"],
@@ -166,6 +153,8 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
                       "synthesis excluded (it would add to the CPU side only)" % log_n,
             "seconds": round(tcpu["total_s"], 3),
         }
+    r1cs.release()
+    params.release()
     m = np.mean(np.array(tms), axis=0)
     mr = np.mean(np.array(tms_r), axis=0)
     return {
@@ -181,6 +170,8 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "concurrent_host_threads": threads,
         "samples": proofs,
         "cpu_baseline": cpu,
+        "crs": "generate_parameters on the device from fixed toxic waste: %.0f ms (h, l, a, b_g1, b_g2 = %d G1 + %d G2 "
+               "fixed-base multiplications, 1 iFFT, transposed sparse product); untimed set-up" % (generate_ms, 4 * (1 << log_n), 1 << log_n),
         "with_r1cs_resident_in_hbm": {
             "note": "constraint matrices captured once per circuit (%.0f ms, untimed, like the CRS upload); per proof: "
                     "witness closures on the host, A.w/B.w/C.w + everything else on the device; identical proofs" % capture_ms,

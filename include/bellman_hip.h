@@ -32,6 +32,7 @@ extern "C" {
 #define BH_ERR_UNEXPECTED_IDENTITY 1 /* SynthesisError::UnexpectedIdentity   src/multiexp.rs:63-65   */
 #define BH_ERR_UNEXPECTED_EOF 2      /* SynthesisError::IoError(UnexpectedEof) src/multiexp.rs:55-61,74-80 */
 #define BH_ERR_DEGREE_TOO_LARGE 3    /* SynthesisError::PolynomialDegreeTooLarge src/domain.rs:57-59 */
+#define BH_ERR_UNCONSTRAINED_VARIABLE 5 /* SynthesisError::UnconstrainedVariable  groth16/src/generator.rs:464-470 */
 #define BH_ERR_INVALID_POINT 6       /* io::ErrorKind::InvalidData "invalid G1" / "invalid G2" groth16/src/lib.rs:300-304,326-330 */
 #define BH_ERR_POINT_AT_INFINITY 7   /* io::ErrorKind::InvalidData "point at infinity"         groth16/src/lib.rs:306-315,332-341 */
 #define BH_ERR_HIP (-1)              /* HIP runtime failure (message on stderr) */
@@ -125,6 +126,8 @@ int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, s
                                bh_bases **out, size_t *bad_index);
 /* copies `count` device-resident affine records (Montgomery) starting at `first` back to the host */
 int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host);
+/* a new owned handle holding a device-to-device copy of `n` packed records */
+int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 /* wrap an existing device array of packed 96/192-byte records (not owned) */
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 void bh_bases_release(bh_ctx *ctx, bh_bases *b);
@@ -179,6 +182,7 @@ int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host,
  * The C++ mirror of Circuit / ConstraintSystem / LinearCombination / ProvingAssignment lives in
  * bellman_amd/csrc/groth16.hpp; these entry points expose it to other host languages. */
 typedef struct bh_params bh_params;
+typedef struct bh_r1cs bh_r1cs; /* constraint matrices on the device, see the R1CS section below */
 int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta_g1, const void *beta_g2,
                              const void *delta_g1, const void *delta_g2, const void *h, size_t nh,
                              const void *l, size_t nl, const void *a, size_t na, const void *b_g1,
@@ -190,6 +194,19 @@ int bh_groth16_params_create(bh_ctx *ctx, const void *alpha_g1, const void *beta
  * BH_ERR_INVALID_POINT, BH_ERR_POINT_AT_INFINITY (query and ic points must not be the identity) or
  * BH_ERR_UNEXPECTED_EOF (input ends inside the structure). Trailing bytes are ignored. */
 int bh_groth16_params_read(bh_ctx *ctx, const void *bytes, size_t len, int checked, bh_params **out);
+/* generate_parameters (groth16/src/generator.rs:163-510) for the circuit whose matrices are `r1cs`
+ * (bh_r1cs_create; the matrices include the `input_i * 0 = 0` rows, generator.rs:195-202): g1 / g2 =
+ * affine generators (96 / 192 B), alpha..tau = Montgomery Fr.  Everything per-variable or
+ * per-constraint runs on the device.  BH_ERR_UNEXPECTED_IDENTITY for gamma = 0 or delta = 0 (:227-243),
+ * BH_ERR_UNCONSTRAINED_VARIABLE (:464-470), BH_ERR_DEGREE_TOO_LARGE. */
+int bh_groth16_generate(bh_ctx *ctx, bh_r1cs *r1cs, const void *g1, const void *g2, const void *alpha,
+                        const void *beta, const void *gamma, const void *delta, const void *tau,
+                        bh_params **out);
+/* Parameters::write (groth16/src/lib.rs:258-287).  buf == NULL: *len = bytes needed.  Parameters made by
+ * bh_groth16_params_create carry no gamma_g2 / ic and write them as the identity / an empty list. */
+int bh_groth16_params_write(const bh_params *p, void *buf, size_t cap, size_t *len);
+/* verifier-side key elements kept by params_read / generate: gamma_g2 (192 B), ic (n_ic x 96 B) */
+int bh_groth16_params_vk_ext(const bh_params *p, void *gamma_g2, void *ic_out, size_t ic_cap, size_t *n_ic);
 /* which: 0 h, 1 l, 2 a, 3 b_g1, 4 b_g2 - the device-resident query (owned by the params) and its length */
 int bh_groth16_params_query(const bh_params *p, int which, const bh_bases **bases, size_t *len);
 /* the prover-side verifying-key elements as affine Montgomery records (any pointer may be NULL) */
@@ -225,7 +242,6 @@ int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint
  * `coeffs` (n_coeffs Montgomery Fr, coeffs[0] must be 1).  Terms with a zero coefficient contribute
  * neither to the value nor to the query densities (prover.rs:31).  n_constraints includes the
  * `input_i * 0 = 0` rows that create_proof appends (prover.rs:208-215). */
-typedef struct bh_r1cs bh_r1cs;
 typedef struct {
   const uint32_t *row_ptr; /* n_constraints + 1 */
   const uint32_t *var;     /* nnz */
@@ -243,6 +259,18 @@ int bh_r1cs_density(const bh_r1cs *r, int which, const uint64_t **dev_words, con
  * (EvaluationDomain::from_coeffs padding, domain.rs:68).  Asynchronous on `stream`. */
 int bh_r1cs_eval_dev(bh_ctx *ctx, const bh_r1cs *r, const void *inputs_dev, const void *aux_dev,
                      void *a_dev, void *b_dev, void *c_dev, uint32_t log_m, void *stream);
+/* Parameter generation (groth16/src/generator.rs:247-462) - device building blocks:
+ *   bh_fr_powers_dev             out[i] = scale * g^i           (:249-263 powers of tau; :266-296 with t(tau)/delta folded in)
+ *   bh_r1cs_eval_transposed_dev  at/bt/ct[v] = QAP polynomial of variable v at tau (:369-387) from the
+ *                                Lagrange coefficients (ifft of the powers of tau, :299-300); n_inputs + n_aux entries each
+ *   bh_fr_qap_ext_dev            e[v] = (at*beta + bt*alpha + ct) * (v < n_inputs ? 1/gamma : 1/delta)   (:400-407)
+ * followed by bh_fixed_base_mul_dev for the h, a, b_g1, b_g2, ic/l points.  Scalars are Montgomery Fr. */
+int bh_fr_powers_dev(bh_ctx *ctx, void *out_dev, size_t n, const void *g_host, const void *scale_host, void *stream);
+int bh_r1cs_eval_transposed_dev(bh_ctx *ctx, bh_r1cs *r, const void *lagrange_dev, void *at_dev, void *bt_dev,
+                                void *ct_dev, void *stream);
+int bh_fr_qap_ext_dev(bh_ctx *ctx, void *e_dev, const void *at_dev, const void *bt_dev, const void *ct_dev,
+                      size_t n_inputs, size_t n_vars, const void *alpha, const void *beta, const void *gamma_inv,
+                      const void *delta_inv, void *stream);
 /* create_proof (prover.rs:217-360) from the witness alone: input_assignment (n_inputs, [0] = 1) and
  * aux_assignment (n_aux) as produced by the circuit's alloc closures; lengths must match the R1CS. */
 int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
