@@ -503,10 +503,31 @@ struct AssignmentSource {
 };
 }  // namespace
 
-static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+namespace {
+// The slice of an n-term multiexp that part `k` of `parts` computes when one proof is spread over
+// several GPUs: contiguous in the scalar index, cut at multiples of 64 so that the
+// density bitmap of the slice starts on a word.  parts = 1 gives [0, n).
+struct Slice { size_t lo, hi; };
+Slice slice_of(size_t n, size_t part, size_t parts) {
+  auto cut = [&](size_t k) {
+    if (k >= parts) return n;
+    const size_t c = (size_t)((unsigned __int128)n * k / parts) & ~size_t(63);
+    return c < n ? c : n;
+  };
+  return Slice{cut(part), cut(part + 1)};
+}
+size_t popcount_prefix(const uint64_t *words, size_t bits) {   // bits is a multiple of 64
+  size_t t = 0;
+  for (size_t w = 0; w < bits / 64; w++) t += (size_t)__builtin_popcountll(words[w]);
+  return t;
+}
+}  // namespace
+
+// prover.rs:217-318 + the waits of :339-354: the eight multiexp results (of this part's slices)
+static void msm_sums(const AssignmentSource &src, Parameters &params, size_t part, size_t parts, MsmSums &out,
+                     ProveTimings *tm) {
   bh_ctx *ctx = params.ctx;
   const double t0 = now_ms();
-  const VerifyingKey &vk = params.vk;
   const size_t n_cons = src.n_cons;
   // EvaluationDomain::from_coeffs (domain.rs:47-79)
   uint32_t log_m = 0;
@@ -524,6 +545,7 @@ static Proof prove_core(const AssignmentSource &src, Parameters &params, const F
   if (n_aux) check(bh_dev_upload_on(ctx, d_aux.p, src.aux, n_aux * 32, ps.st));
   std::unique_ptr<DevBuf> dens_buf[3];
   const uint64_t *dens_a_aux = nullptr, *dens_b_in = nullptr, *dens_b_aux = nullptr;
+  const uint64_t *hw_a_aux = nullptr, *hw_b_in = nullptr, *hw_b_aux = nullptr;   // the same bitmaps on the host
   size_t b_in_total = 0;
   if (src.host) {
     auto upload_density = [&](const DensityTracker &d, std::unique_ptr<DevBuf> &buf) {
@@ -536,10 +558,12 @@ static Proof prove_core(const AssignmentSource &src, Parameters &params, const F
     dens_b_in = upload_density(src.host->b_input_density, dens_buf[1]);
     dens_b_aux = upload_density(src.host->b_aux_density, dens_buf[2]);
     b_in_total = src.host->b_input_density.get_total_density();
+    hw_a_aux = src.host->a_aux_density.words(); hw_b_in = src.host->b_input_density.words();
+    hw_b_aux = src.host->b_aux_density.words();
   } else {
-    check(bh_r1cs_density(src.r1cs->handle, 0, &dens_a_aux, nullptr, nullptr));
-    check(bh_r1cs_density(src.r1cs->handle, 1, &dens_b_in, nullptr, &b_in_total));
-    check(bh_r1cs_density(src.r1cs->handle, 2, &dens_b_aux, nullptr, nullptr));
+    check(bh_r1cs_density(src.r1cs->handle, 0, &dens_a_aux, &hw_a_aux, nullptr));
+    check(bh_r1cs_density(src.r1cs->handle, 1, &dens_b_in, &hw_b_in, &b_in_total));
+    check(bh_r1cs_density(src.r1cs->handle, 2, &dens_b_aux, &hw_b_aux, nullptr));
   }
 
   BH_TRACE("prove_core start: uploads queued");
@@ -552,18 +576,24 @@ static Proof prove_core(const AssignmentSource &src, Parameters &params, const F
   DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
   JobSet jobs;
   for (bh_msm_job **j : {&l_job, &a_in_job, &a_aux_job, &b1_in_job, &b1_aux_job, &b2_in_job, &b2_aux_job, &h_job}) jobs.track(j);
-  check(bh_msm_async_dev(ctx, params.l, 0, d_aux.p, n_aux, BH_SCALARS_MONT, nullptr, 0, &l_job));
+  // one multiexp over this part's slice of the scalars: `skip` advances by the number of bases the
+  // skipped scalars would have consumed (all of them without a density map, the set bits with one)
+  auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
+                   const uint64_t *dens_host, bh_msm_job **job) {
+    const Slice sl = slice_of(n, part, parts);
+    const size_t base_skip = skip + (dens_dev ? popcount_prefix(dens_host, sl.lo) : sl.lo);
+    check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
+                           dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
+  };
+  issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
   // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
-  check(bh_msm_async_dev(ctx, params.a, 0, d_in.p, n_in, BH_SCALARS_MONT, nullptr, 0, &a_in_job));
-  check(bh_msm_async_dev(ctx, params.a, n_in, d_aux.p, n_aux, BH_SCALARS_MONT, dens_a_aux, n_aux,
-                         &a_aux_job));
+  issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job);
+  issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
   // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
-  check(bh_msm_async_dev(ctx, params.b_g1, 0, d_in.p, n_in, BH_SCALARS_MONT, dens_b_in, n_in, &b1_in_job));
-  check(bh_msm_async_dev(ctx, params.b_g1, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, dens_b_aux, n_aux,
-                         &b1_aux_job));
-  check(bh_msm_async_dev(ctx, params.b_g2, 0, d_in.p, n_in, BH_SCALARS_MONT, dens_b_in, n_in, &b2_in_job));
-  check(bh_msm_async_dev(ctx, params.b_g2, b_in_total, d_aux.p, n_aux, BH_SCALARS_MONT, dens_b_aux, n_aux,
-                         &b2_aux_job));
+  issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job);
+  issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
+  issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job);
+  issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
 
   // The seven multiexps above only need the assignments, so they are already running on their own
   // streams while the h block below uploads a/b/c and runs its FFTs (the reference issues h first,
@@ -586,52 +616,87 @@ static Proof prove_core(const AssignmentSource &src, Parameters &params, const F
   check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, ps.st));   // synchronises ps.st before returning
   BH_TRACE("h poly done");
   const double t1 = now_ms();
-  check(bh_msm_async_dev(ctx, params.h, 0, da.p, m - 1, BH_SCALARS_MONT, nullptr, 0, &h_job));   // a.len() - 1, :238-244
+  issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
   // every job must be waited on (it owns device resources), even when an earlier one fails
   int rcs[8];
-  G1Affine h_res, l_res, a_in, a_aux, b1_in, b1_aux;
-  G2Affine b2_in, b2_aux;
   // prover.rs:339-354 waits in this order: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
-  rcs[0] = jobs.wait(a_in_job, &a_in);
-  rcs[1] = jobs.wait(a_aux_job, &a_aux);
-  rcs[2] = jobs.wait(b1_in_job, &b1_in);
-  rcs[3] = jobs.wait(b1_aux_job, &b1_aux);
-  rcs[4] = jobs.wait(b2_in_job, &b2_in);
-  rcs[5] = jobs.wait(b2_aux_job, &b2_aux);
-  rcs[6] = jobs.wait(h_job, &h_res);
-  rcs[7] = jobs.wait(l_job, &l_res);
+  rcs[0] = jobs.wait(a_in_job, &out.a_in);
+  rcs[1] = jobs.wait(a_aux_job, &out.a_aux);
+  rcs[2] = jobs.wait(b1_in_job, &out.b1_in);
+  rcs[3] = jobs.wait(b1_aux_job, &out.b1_aux);
+  rcs[4] = jobs.wait(b2_in_job, &out.b2_in);
+  rcs[5] = jobs.wait(b2_aux_job, &out.b2_aux);
+  rcs[6] = jobs.wait(h_job, &out.h);
+  rcs[7] = jobs.wait(l_job, &out.l);
   const double t2 = now_ms();
   BH_TRACE("waits done rc=%d %d %d %d %d %d %d %d", rcs[0], rcs[1], rcs[2], rcs[3], rcs[4], rcs[5], rcs[6], rcs[7]);
-
-  if (vk.delta_g1.is_identity() || vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
+  if (params.vk.delta_g1.is_identity() || params.vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
     throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
   for (int i = 0; i < 8; i++) check(rcs[i]);                      // first failing `?` in wait order
+  if (tm) {
+    tm->h_poly_ms = (float)(t1 - t0);
+    tm->msm_ms = (float)(t2 - t1);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+}
 
+// prover.rs:326-360 from the eight multiexp results
+Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, const Fr &s) {
+  const VerifyingKey &vk = params.vk;
+  if (vk.delta_g1.is_identity() || vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
   G1Affine g_a = add_pts(BH_G1, mul_pt(BH_G1, vk.delta_g1, r), vk.alpha_g1);   // :326-327
   G2Affine g_b = add_pts(BH_G2, mul_pt(BH_G2, vk.delta_g2, s), vk.beta_g2);    // :328-329
   const Fr rs = r * s;
   G1Affine g_c = mul_pt(BH_G1, vk.delta_g1, rs);                                // :331-338
   g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.alpha_g1, s));
   g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.beta_g1, r));
-  G1Affine a_answer = add_pts(BH_G1, a_in, a_aux);                              // :339-343
+  G1Affine a_answer = add_pts(BH_G1, m.a_in, m.a_aux);                          // :339-343
   g_a = add_pts(BH_G1, g_a, a_answer);
   a_answer = mul_pt(BH_G1, a_answer, s);
   g_c = add_pts(BH_G1, g_c, a_answer);
-  G1Affine b1_answer = add_pts(BH_G1, b1_in, b1_aux);                           // :345-354
-  G2Affine b2_answer = add_pts(BH_G2, b2_in, b2_aux);
+  G1Affine b1_answer = add_pts(BH_G1, m.b1_in, m.b1_aux);                       // :345-354
+  G2Affine b2_answer = add_pts(BH_G2, m.b2_in, m.b2_aux);
   g_b = add_pts(BH_G2, g_b, b2_answer);
   b1_answer = mul_pt(BH_G1, b1_answer, r);
   g_c = add_pts(BH_G1, g_c, b1_answer);
-  g_c = add_pts(BH_G1, g_c, h_res);
-  g_c = add_pts(BH_G1, g_c, l_res);
-  if (tm) {
-    tm->h_poly_ms = (float)(t1 - t0);
-    tm->msm_ms = (float)(t2 - t1);
-    tm->total_ms = (float)(now_ms() - t0);
-  }
-  return Proof{g_a, g_b, g_c};
+  g_c = add_pts(BH_G1, g_c, m.h);
+  g_c = add_pts(BH_G1, g_c, m.l);
+  Proof p;
+  p.a = g_a; p.b = g_b; p.c = g_c;
+  return p;
+}
+
+void MsmSums::add(const MsmSums &o) {
+  a_in = add_pts(BH_G1, a_in, o.a_in); a_aux = add_pts(BH_G1, a_aux, o.a_aux);
+  b1_in = add_pts(BH_G1, b1_in, o.b1_in); b1_aux = add_pts(BH_G1, b1_aux, o.b1_aux);
+  b2_in = add_pts(BH_G2, b2_in, o.b2_in); b2_aux = add_pts(BH_G2, b2_aux, o.b2_aux);
+  h = add_pts(BH_G1, h, o.h); l = add_pts(BH_G1, l, o.l);
+}
+
+static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  MsmSums sums;
+  msm_sums(src, params, 0, 1, sums, tm);
+  Proof p = assemble_proof(params, sums, r, s);
+  if (tm) tm->total_ms = (float)(now_ms() - t0);
+  return p;
+}
+
+MsmSums prove_witness_part(const R1cs &r1cs, Parameters &params, const Fr *inputs, size_t n_inputs, const Fr *aux, size_t n_aux,
+                           size_t part, size_t parts, ProveTimings *tm) {
+  if (n_inputs != r1cs.num_inputs || n_aux != r1cs.num_aux || parts == 0 || part >= parts)
+    throw std::invalid_argument("witness does not have the shape of the captured circuit / bad part");
+  AssignmentSource src;
+  src.inputs = inputs; src.n_in = n_inputs;
+  src.aux = aux; src.n_aux = n_aux;
+  src.n_cons = r1cs.num_constraints;
+  src.r1cs = &r1cs;
+  MsmSums sums;
+  msm_sums(src, params, part, parts, sums, tm);
+  return sums;
 }
 
 Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
@@ -868,6 +933,16 @@ struct bh_params {
   groth16::Parameters *p;
 };
 
+static int run_guarded_sums(const std::function<groth16::MsmSums()> &f, void *sums_out) {
+  try {
+    groth16::MsmSums m = f();
+    memcpy(sums_out, &m, sizeof m);
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
+  } catch (...) { return BH_ERR_HIP; }
+}
+
 // a non-owning groth16::R1cs over a handle that belongs to the C caller
 struct R1csView {
   groth16::R1cs r;
@@ -1075,6 +1150,67 @@ int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circu
   });
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
+}
+
+int bh_groth16_prove_witness_part(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment, size_t n_inputs,
+                                  const void *aux_assignment, size_t n_aux, size_t part, size_t parts, void *sums_out,
+                                  float *timings4) {
+  using namespace groth16;
+  if (!params || !r1cs || !sums_out) return BH_ERR_INVALID_ARG;
+  R1csView view(r1cs);
+  std::vector<Fr> in(n_inputs), aux(n_aux);
+  if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
+  if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = run_guarded_sums([&] { return prove_witness_part(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, part, parts, &tm); },
+                            sums_out);
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+int bh_groth16_prove_demo_r1cs_part(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
+                                    const void *witness, const void *constants, size_t part, size_t parts, void *sums_out,
+                                    float *timings4) {
+  using namespace groth16;
+  if (!params || !r1cs || !sums_out) return BH_ERR_INVALID_ARG;
+  R1csView view(r1cs);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
+    return run_guarded_sums([&] {
+      const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      WitnessAssignment w;
+      w.input_assignment.reserve(view.r.num_inputs);
+      w.aux_assignment.reserve(view.r.num_aux);
+      w.alloc_input([] { return Fr::one(); });
+      c.synthesize(w);
+      const double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      MsmSums m = prove_witness_part(view.r, *params->p, w.input_assignment.data(), w.input_assignment.size(),
+                                     w.aux_assignment.data(), w.aux_assignment.size(), part, parts, &tm);
+      tm.synthesis_ms = (float)(t1 - t0);
+      tm.total_ms += tm.synthesis_ms;
+      return m;
+    }, sums_out);
+  });
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+void bh_groth16_sums_add(void *acc, const void *other) {
+  groth16::MsmSums a, b;
+  memcpy(&a, acc, sizeof a);
+  memcpy(&b, other, sizeof b);
+  a.add(b);
+  memcpy(acc, &a, sizeof a);
+}
+
+int bh_groth16_assemble(bh_params *params, const void *sums, const void *r, const void *s, void *proof_out) {
+  using namespace groth16;
+  if (!params || !sums) return BH_ERR_INVALID_ARG;
+  MsmSums m;
+  memcpy(&m, sums, sizeof m);
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  return run_guarded([&] { return assemble_proof(*params->p, m, rr, ss); }, proof_out);
 }
 
 int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed, const void *witness,

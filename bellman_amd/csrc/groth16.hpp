@@ -213,6 +213,17 @@ class ProvingAssignment : public bellman::ConstraintSystem {
 
 struct ProveTimings { float synthesis_ms, h_poly_ms, msm_ms, total_ms; };
 
+// The eight multiexp results of create_proof in the order the reference waits for them
+// (prover.rs:339-354).  With the proof spread over several GPUs every rank produces the sums over its
+// slice of the scalars; the per-slot group sums over all ranks are what assemble_proof needs.
+struct MsmSums {
+  G1Affine a_in, a_aux, b1_in, b1_aux;
+  G2Affine b2_in, b2_aux;
+  G1Affine h, l;
+  void add(const MsmSums &other);   // slot-wise group addition
+};
+static_assert(sizeof(MsmSums) == 6 * 96 + 2 * 192, "packed: the C ABI hands it over as 960 bytes");
+
 // The circuit's three constraint matrices, captured once and kept in HBM.  Capture
 // runs `synthesize` against a structure-only ConstraintSystem that never calls the value closures -
 // the same thing generator.rs:43-131 (KeypairAssembly) does to build the CRS for this circuit.
@@ -247,6 +258,14 @@ Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &
 // (it does whenever `params` belongs to it); a different variable count throws std::invalid_argument.
 Proof create_proof(bellman::Circuit &circuit, const R1cs &r1cs, Parameters &params, const Fr &r, const Fr &s,
                    ProveTimings *timings = nullptr);
+// One proof over `parts` GPUs: every rank holds the CRS and the matrices, generates
+// the witness and runs the h block (replicated, small), but computes each multiexp only over part
+// `part` of the scalar indices; the ranks exchange their MsmSums (960 B), add them slot-wise and
+// assemble the identical proof.
+MsmSums prove_witness_part(const R1cs &r1cs, Parameters &params, const Fr *input_assignment, size_t n_inputs,
+                           const Fr *aux_assignment, size_t n_aux, size_t part, size_t parts,
+                           ProveTimings *timings = nullptr);
+Proof assemble_proof(const Parameters &params, const MsmSums &sums, const Fr &r, const Fr &s);
 Proof prove_witness(const R1cs &r1cs, Parameters &params, const Fr *input_assignment, size_t n_inputs,
                     const Fr *aux_assignment, size_t n_aux, const Fr &r, const Fr &s,
                     ProveTimings *timings = nullptr);

@@ -481,3 +481,54 @@ def create_proof_demo_r1cs(params, r1cs, kind, size, seed, witness, constants, r
     if timings is not None:
         timings[:] = list(tm)
     return Proof(out)
+
+
+# ---- one proof over several GPUs ------------------------------------------------------
+SUMS_WORDS = 120  # BH_MSM_SUMS_BYTES / 8
+
+
+def prove_witness_part(r1cs, params, input_assignment, aux_assignment, part, parts, timings=None):
+    """The eight multiexp results of create_proof over part `part` of `parts` of the scalar indices
+    -> uint64[120] (a_inputs, a_aux, b_g1_inputs, b_g1_aux | b_g2_inputs, b_g2_aux | h, l)."""
+    lib = _lib.load()
+    ia, aa = fr_to_mont_array(list(input_assignment)), fr_to_mont_array(list(aux_assignment))
+    out = np.zeros(SUMS_WORDS, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_witness_part(params._h, r1cs._h, p(ia), ia.shape[0], p(aa), aa.shape[0], part, parts, p(out), tm),
+          "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return out
+
+
+def prove_demo_part(params, r1cs, kind, size, seed, witness, constants, part, parts, timings=None):
+    lib = _lib.load()
+    wit = fr_to_mont_array(list(witness))
+    con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+    out = np.zeros(SUMS_WORDS, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_demo_r1cs_part(params._h, r1cs._h, kind, size, seed, p(wit), p(con), part, parts, p(out), tm),
+          "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return out
+
+
+def sums_add(acc, other):
+    """slot-wise group addition of two multiexp-result records (host code)"""
+    acc = np.ascontiguousarray(acc, dtype=np.uint64).copy()
+    other = np.ascontiguousarray(other, dtype=np.uint64)
+    _lib.load().bh_groth16_sums_add(acc.ctypes.data_as(ctypes.c_void_p), other.ctypes.data_as(ctypes.c_void_p))
+    return acc
+
+
+def assemble(params, sums, r, s):
+    """prover.rs:326-360 from the (summed) multiexp results"""
+    rs = fr_to_mont_array([r, s])
+    sums = np.ascontiguousarray(sums, dtype=np.uint64)
+    out = np.zeros(48, dtype=np.uint64)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(_lib.load().bh_groth16_assemble(params._h, p(sums), p(rs[0:1]), p(rs[1:2]), p(out)), "create_proof")
+    return Proof(out)

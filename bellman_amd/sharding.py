@@ -44,3 +44,35 @@ def sharded_multiexp(worker, bases_shard, density_map, scalars_shard, group, dev
 
     part = multiexp(worker, bases_shard, density_map, scalars_shard, **kw).wait()
     return fold_partials(part, group, device=device, process_group=process_group)
+
+
+def fold_sums(sums, process_group=None, device=None):
+    """all-gather every rank's multiexp-result record (960 B) and add them slot-wise."""
+    import torch
+    import torch.distributed as dist
+
+    from .groth16 import sums_add
+
+    world = dist.get_world_size(process_group)
+    mine = torch.from_numpy(np.ascontiguousarray(sums, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=process_group)
+    total = parts[0].cpu().numpy().view(np.uint64)
+    for p in parts[1:]:
+        total = sums_add(total, p.cpu().numpy().view(np.uint64))
+    return total
+
+
+def create_proof_sharded(part_fn, params, r, s, process_group=None, device=None):
+    """One Groth16 proof over all ranks of `process_group`: `part_fn(rank, world)` returns this rank's
+    multiexp sums (groth16.prove_witness_part / prove_demo_part over its slice of the scalars); one
+    all-gather of 960 bytes, slot-wise fold, and every rank assembles the same proof."""
+    import torch.distributed as dist
+
+    from .groth16 import assemble
+
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    total = fold_sums(part_fn(rank, world), process_group=process_group, device=device)
+    return assemble(params, total, r, s)

@@ -276,6 +276,22 @@ int bh_fr_qap_ext_dev(bh_ctx *ctx, void *e_dev, const void *at_dev, const void *
 int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
                              size_t n_inputs, const void *aux_assignment, size_t n_aux, const void *r,
                              const void *s, void *proof_out, float *timings4);
+/* ---- one proof over several GPUs: every rank holds the CRS and the matrices, builds the
+ * witness and runs the (small) h block, but computes each of the eight multiexps of prover.rs:244-318
+ * only over part `part` of `parts` of the scalar indices (contiguous, cut at multiples of 64).  The
+ * result is BH_MSM_SUMS_BYTES = 6 x 96 + 2 x 192 bytes: affine a_inputs, a_aux, b_g1_inputs, b_g1_aux
+ * (G1), b_g2_inputs, b_g2_aux (G2), h, l (G1) - the wait order of prover.rs:339-354.  The ranks
+ * all-gather these records, add them slot-wise (bh_groth16_sums_add) and every rank assembles the same
+ * proof (prover.rs:326-360, bh_groth16_assemble).  parts = 1 is bh_groth16_prove_witness. */
+#define BH_MSM_SUMS_BYTES 960
+int bh_groth16_prove_witness_part(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
+                                  size_t n_inputs, const void *aux_assignment, size_t n_aux, size_t part,
+                                  size_t parts, void *sums_out, float *timings4);
+void bh_groth16_sums_add(void *acc, const void *other);
+int bh_groth16_assemble(bh_params *params, const void *sums, const void *r, const void *s, void *proof_out);
+int bh_groth16_prove_demo_r1cs_part(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
+                                    uint64_t seed, const void *witness, const void *constants, size_t part,
+                                    size_t parts, void *sums_out, float *timings4);
 /* The demo circuits of bh_groth16_prove_demo through that path: capture the matrices once ... */
 int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants,
                          bh_r1cs **out);
