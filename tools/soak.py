@@ -42,6 +42,50 @@ def main():
     marks.append(round(free_mb()))
     print("free MiB over time:", marks, "elapsed %.1fs" % (time.time() - t0))
     assert marks[-1] >= marks[1] - 64, "device memory keeps shrinking"
-    print("soak ok")
+    print("soak ok (multiexp / fft)")
+    soak_proofs(w)
+
+
+def soak_proofs(w):
+    """create / prove / release cycles of every handle type of the proof path, from four host threads"""
+    from concurrent.futures import ThreadPoolExecutor
+    from bellman_amd import groth16 as pg
+    from bench import G2_GEN_MONT
+
+    rounds, seed = (1 << 14) - 3, 9
+    marks = []
+    t0 = time.time()
+    ref = {}
+    for cycle in range(12):
+        r1cs = pg.R1CS.from_demo(w, 1, rounds, seed)
+        params = pg.Parameters.generate(w, r1cs, G1_GEN_MONT, G2_GEN_MONT, 48577, 22580, 53332, 5481, 3673)
+        if cycle % 3 == 0:   # through the serialized form as well
+            blob = params.write()
+            params.release()
+            params = pg.Parameters.read(w, blob, cycle % 2 == 0)
+
+        def one(i):
+            if i % 3 == 2:   # a proof assembled from three slices
+                tot = None
+                for part in range(3):
+                    sm = pg.prove_demo_part(params, r1cs, 1, rounds, seed, [1000 + i % 5], None, part, 3)
+                    tot = sm if tot is None else pg.sums_add(tot, sm)
+                p = pg.assemble(params, tot, 77, 88)
+            elif i % 3 == 1:
+                p = pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, seed, [1000 + i % 5], None, 77, 88)
+            else:
+                p = pg.create_proof_demo(params, 1, rounds, seed, [1000 + i % 5], None, 77, 88)
+            return i % 5, p.a.tobytes() + p.b.tobytes() + p.c.tobytes()
+
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for k, proof in ex.map(one, range(20)):
+                assert ref.setdefault(k, proof) == proof, "proof changed between paths / cycles"
+        r1cs.release()
+        params.release()
+        w.synchronize()
+        marks.append(round(free_mb()))
+    print("free MiB after each proof cycle:", marks, "elapsed %.1fs" % (time.time() - t0))
+    assert marks[-1] >= marks[2] - 64, "device memory keeps shrinking"
+    print("soak ok (proof path)")
 
 main()
