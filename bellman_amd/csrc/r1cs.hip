@@ -28,6 +28,10 @@ struct bh_r1cs {
   // host copy of the matrices + the transposed (variable-major) device copy the parameter generator
   // uses (generator.rs:43-131 stores exactly that: per variable, (coeff, constraint) lists); built on
   // first use
+  uint2 *long_rows = nullptr;                        // (matrix, row) of rows with more than LONG_ROW terms
+  u32 n_long = 0;
+  uint2 *t_long_rows = nullptr;                      // the same for the transposed matrices
+  u32 t_n_long = 0;
   std::vector<u32> h_row_ptr[3], h_var[3], h_coeff[3];
   std::mutex t_mu;
   bool t_ready = false;
@@ -44,7 +48,11 @@ struct R1csEvalArgs {
   const fr_t *coeffs, *inputs, *aux;
   u32 n_inputs;
   u64 n_constraints, m;   // rows >= n_constraints are the zero padding of from_coeffs (domain.rs:68)
+  const uint2 *long_rows; // rows the lane-per-row kernel leaves to r1cs_long_rows_kernel
 };
+// A row with more terms than this is summed by a whole workgroup instead of one lane: the constant
+// ONE typically appears in every constraint, so its row of a transposed matrix has ~n terms.
+constexpr u32 LONG_ROW = 1024;
 
 __device__ __forceinline__ fr_t ld_fr16(const fr_t *p) {
   const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -69,6 +77,7 @@ __global__ void __launch_bounds__(256) r1cs_eval_kernel(R1csEvalArgs a) {
     fe_zero(acc);
     if (row < a.n_constraints) {
       const u32 lo = a.row_ptr[mat][row], hi = a.row_ptr[mat][row + 1];
+      if (hi - lo > LONG_ROW) continue;   // written by r1cs_long_rows_kernel
       for (u32 t = lo; t < hi; t++) {
         const uint2 term = a.terms[mat][t];
         fr_t w = ld_fr16(term.x < a.n_inputs ? a.inputs + term.x : a.aux + (term.x - a.n_inputs));
@@ -94,6 +103,53 @@ __global__ void __launch_bounds__(256) qap_ext_kernel(fr_t *e, const fr_t *at, c
     if (i < n_inputs) fe_mul(a, a, gamma_inv); else fe_mul(a, a, delta_inv);
     st_fr16(e + i, a);
   }
+}
+
+__global__ void __launch_bounds__(256) r1cs_long_rows_kernel(R1csEvalArgs a) {
+  __shared__ fr_t part[256];
+  const uint2 job = a.long_rows[blockIdx.x];
+  const u32 mat = job.x, row = job.y;
+  const u32 lo = a.row_ptr[mat][row], hi = a.row_ptr[mat][row + 1];
+  fr_t acc;
+  fe_zero(acc);
+  for (u32 t = lo + threadIdx.x; t < hi; t += 256) {
+    const uint2 term = a.terms[mat][t];
+    fr_t w = ld_fr16(term.x < a.n_inputs ? a.inputs + term.x : a.aux + (term.x - a.n_inputs));
+    if (term.y != 0) {
+      const fr_t k = ld_fr16(a.coeffs + term.y);
+      fe_mul(w, w, k);
+    }
+    fe_add(acc, acc, w);
+  }
+  part[threadIdx.x] = acc;
+  for (u32 off = 128; off >= 1; off >>= 1) {
+    __syncthreads();
+    if (threadIdx.x < off) {
+      fr_t x = part[threadIdx.x], y = part[threadIdx.x + off];
+      fe_add(x, x, y);
+      part[threadIdx.x] = x;
+    }
+  }
+  if (threadIdx.x == 0) st_fr16(a.out[mat] + row, part[0]);
+}
+
+static std::vector<uint2> find_long_rows(const std::vector<u32> *row_ptr_of_3) {
+  std::vector<uint2> v;
+  for (u32 m = 0; m < 3; m++)
+    for (size_t r = 0; r + 1 < row_ptr_of_3[m].size(); r++)
+      if (row_ptr_of_3[m][r + 1] - row_ptr_of_3[m][r] > LONG_ROW) v.push_back(make_uint2(m, (u32)r));
+  return v;
+}
+
+static int launch_eval(bh_ctx *ctx, R1csEvalArgs &a, u32 n_long, hipStream_t st) {
+  const u64 blocks = (3 * a.m + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
+  hipLaunchKernelGGL(r1cs_eval_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, a);
+  BH_HIP_CHECK(hipGetLastError());
+  if (n_long) {
+    hipLaunchKernelGGL(r1cs_long_rows_kernel, dim3(n_long), dim3(256), 0, st, a);
+    BH_HIP_CHECK(hipGetLastError());
+  }
+  return BH_OK;
 }
 
 template <class T>
@@ -167,6 +223,12 @@ int bh_r1cs_create(bh_ctx *ctx, size_t n_inputs, size_t n_aux, size_t n_constrai
     if (rc == BH_OK) rc = upload_vec(ctx, &r->terms[m], terms.data(), (size_t)nnz);
     if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;   // `terms` is a local
   }
+  if (rc == BH_OK) {
+    const std::vector<uint2> lr = find_long_rows(r->h_row_ptr);
+    r->n_long = (u32)lr.size();
+    rc = upload_vec(ctx, &r->long_rows, lr.data(), lr.size());
+    if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;   // `lr` is a local
+  }
   if (rc == BH_OK) rc = upload_vec(ctx, &r->coeffs, cf, n_coeffs);
   if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
   if (rc != BH_OK) { bh_r1cs_release(r); return rc; }
@@ -183,6 +245,8 @@ void bh_r1cs_release(bh_r1cs *r) {
     r->ctx->c.pool.release(r->t_row_ptr[m]);
     r->ctx->c.pool.release(r->t_terms[m]);
   }
+  r->ctx->c.pool.release(r->long_rows);
+  r->ctx->c.pool.release(r->t_long_rows);
   r->ctx->c.pool.release(r->coeffs);
   delete r;
 }
@@ -215,11 +279,8 @@ int bh_r1cs_eval_dev(bh_ctx *ctx, const bh_r1cs *r, const void *inputs_dev, cons
   a.n_inputs = (u32)r->n_inputs;
   a.n_constraints = r->n_constraints;
   a.m = u64(1) << log_m;
-  const u64 blocks = (3 * a.m + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->c.stream;
-  hipLaunchKernelGGL(r1cs_eval_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, a);
-  BH_HIP_CHECK(hipGetLastError());
-  return BH_OK;
+  a.long_rows = r->long_rows;
+  return launch_eval(ctx, a, r->n_long, stream ? (hipStream_t)stream : ctx->c.stream);
 }
 
 // QAP polynomials at tau (generator.rs:369-387 eval_at_tau for every variable): at[v] = sum over the
@@ -233,9 +294,11 @@ int bh_r1cs_eval_transposed_dev(bh_ctx *ctx, bh_r1cs *r, const void *lagrange_de
   {
     std::lock_guard<std::mutex> g(r->t_mu);
     if (!r->t_ready) {
+      std::vector<u32> t_rp[3];
       for (int m = 0; m < 3; m++) {
         const size_t nnz = r->h_var[m].size();
-        std::vector<u32> rp(n_vars + 1, 0);
+        std::vector<u32> &rp = t_rp[m];
+        rp.assign(n_vars + 1, 0);
         for (size_t t = 0; t < nnz; t++) rp[r->h_var[m][t] + 1]++;
         for (size_t v = 0; v < n_vars; v++) rp[v + 1] += rp[v];
         std::vector<uint2> terms(nnz);
@@ -248,6 +311,11 @@ int bh_r1cs_eval_transposed_dev(bh_ctx *ctx, bh_r1cs *r, const void *lagrange_de
         if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
         if (rc != BH_OK) return rc;
       }
+      const std::vector<uint2> lr = find_long_rows(t_rp);
+      r->t_n_long = (u32)lr.size();
+      int rc = upload_vec(ctx, &r->t_long_rows, lr.data(), lr.size());
+      if (rc == BH_OK && hipStreamSynchronize(ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
+      if (rc != BH_OK) return rc;
       r->t_ready = true;
     }
   }
@@ -259,11 +327,8 @@ int bh_r1cs_eval_transposed_dev(bh_ctx *ctx, bh_r1cs *r, const void *lagrange_de
   a.n_constraints = n_vars;
   a.m = n_vars;
   if (!n_vars) return BH_OK;
-  const u64 blocks = (3 * a.m + 255) / 256, cap = (u64)ctx->c.num_cus * 16;
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->c.stream;
-  hipLaunchKernelGGL(r1cs_eval_kernel, dim3((u32)(blocks < cap ? blocks : cap)), dim3(256), 0, st, a);
-  BH_HIP_CHECK(hipGetLastError());
-  return BH_OK;
+  a.long_rows = r->t_long_rows;
+  return launch_eval(ctx, a, r->t_n_long, stream ? (hipStream_t)stream : ctx->c.stream);
 }
 
 // generator.rs:400-407: e[v] = (at[v]*beta + bt[v]*alpha + ct[v]) * inv, inv = 1/gamma for the public

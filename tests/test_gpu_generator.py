@@ -69,7 +69,7 @@ def test_generate_mimc_then_write_read_prove(worker):
         assert _same(pg.create_proof_r1cs(circ, r1cs, params, r, s), proof_want.a, proof_want.b, proof_want.c)
 
 
-@pytest.mark.parametrize("rounds", [1, 2, 9, 130])
+@pytest.mark.parametrize("rounds", [1, 2, 9, 130, 1300])
 def test_generate_chain_circuit(worker, rounds):
     """zero-coefficient terms, variables absent from B (identities filtered out of the B queries),
     a domain that is not full (n_cons < m)"""

@@ -38,6 +38,8 @@ def test_r1cs_eval_random_matrices(worker, n_in, n_aux, n_cons, seed):
         row_ptr, var, coeff = [0], [], []
         for i in range(n_cons):
             k = rnd.choice([0, 0, 1, 1, 2, 3, 5, 40 if i % 97 == 0 else 2])
+            if n_cons > 4000 and i in (7, 4000):
+                k = 1025 + 2000 * (i == 7)   # rows above the lane-per-row limit: summed by a workgroup
             for _ in range(k):
                 var.append(rnd.randrange(nv))
                 coeff.append(rnd.choice([0, 0, 0, 1, 2] + list(range(len(table)))))
