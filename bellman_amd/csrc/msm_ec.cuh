@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
 // fixed-base scalar multiplication (fixture generation) and test hooks
 // ============================================================================================
 template <class F>
-__global__ void fixed_base_mul_kernel(Affine<F> base, const void *scalars, int fmt, u64 n, Affine<F> *out) {
+__global__ void __launch_bounds__(128) fixed_base_mul_kernel(Affine<F> base, const void *scalars, int fmt, u64 n, Affine<F> *out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fr_t s;
@@ -301,7 +301,7 @@ __global__ void fixed_base_mul_kernel(Affine<F> base, const void *scalars, int f
   out[i] = r;
 }
 template <class F>
-__global__ void point_add_kernel(Affine<F> *r, const Affine<F> *a, const Affine<F> *b, u64 n) {
+__global__ void __launch_bounds__(128) point_add_kernel(Affine<F> *r, const Affine<F> *a, const Affine<F> *b, u64 n) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   XYZZ<F> x, y, z;
