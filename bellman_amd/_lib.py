@@ -19,7 +19,7 @@ EXPORTS = [
     "bh_dev_zero_on", "bh_ctx_synchronize",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
-    "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
+    "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
@@ -104,6 +104,8 @@ def load():
     lib.bh_groth16_params_write.argtypes = [vp, vp, sz, c.POINTER(sz)]
     lib.bh_groth16_params_vk_ext.argtypes = [vp, vp, vp, sz, c.POINTER(sz)]
     lib.bh_bases_copy_dev.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]
+    lib.bh_bases_precompute.argtypes = [vp, vp, c.c_uint]
+    lib.bh_bases_table_info.argtypes = [vp, c.POINTER(c.c_uint), c.POINTER(c.c_uint), c.POINTER(sz)]
     lib.bh_r1cs_eval_transposed_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.bh_fr_powers_dev.argtypes = [vp, vp, sz, vp, vp, vp]
     lib.bh_fr_qap_ext_dev.argtypes = [vp, vp, vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]

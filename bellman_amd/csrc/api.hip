@@ -20,7 +20,7 @@ struct MsmJobImpl;
 MsmJobImpl *msm_job_new(Context *ctx, int group);
 void msm_job_delete(MsmJobImpl *j);
 int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                    int fmt, const u64 *density_dev, unsigned forced_c);
+                    int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
 hipStream_t msm_job_stream(MsmJobImpl &job);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
@@ -114,6 +114,9 @@ struct bh_bases {
   void *dev;
   size_t n;
   bool owned;
+  // optional window table (bh_bases_precompute): [W][n] affine records, row 0 = a copy of the bases
+  void *table = nullptr;
+  WindowTable tab = {0, 0, 0};
 };
 struct bh_msm_job {
   MsmJobImpl *impl;
@@ -450,9 +453,42 @@ int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, 
   *out = new bh_bases{group, const_cast<void *>(dev_points), n, false};
   return BH_OK;
 }
+int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits) {
+  if (!ctx || !b) return BH_ERR_INVALID_ARG;
+  if (b->table) { (void)hipFree(b->table); b->table = nullptr; }
+  if (b->n == 0) return BH_OK;
+  const u32 c = window_bits ? window_bits : table_window_bits(b->n, b->group == BH_G2);
+  if (c < 2 || c > 24) return BH_ERR_INVALID_ARG;
+  const u32 W = (256 + c - 1) / c;
+  const size_t rec = b->group == BH_G1 ? 96 : 192;
+  if ((u64)W * b->n >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;   // table rows must fit the 31-bit base field
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *t = nullptr;
+  if (hipMalloc(&t, (size_t)W * b->n * rec) != hipSuccess) {
+    (void)hipGetLastError();
+    return BH_ERR_HIP;   // not enough HBM for the table: the caller keeps using the plain bases
+  }
+  hipStream_t st = ctx->c.stream;
+  int rc = BH_OK;
+  if (hipMemcpyAsync(t, b->dev, b->n * rec, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK) rc = window_table(b->group, t, b->n, c, W, st);
+  if (rc == BH_OK && hipStreamSynchronize(st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc != BH_OK) { (void)hipFree(t); return rc; }
+  b->table = t;
+  b->tab = WindowTable{c, W, (u64)b->n};
+  return BH_OK;
+}
+int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows, size_t *bytes) {
+  if (!b) return BH_ERR_INVALID_ARG;
+  if (window_bits) *window_bits = b->table ? b->tab.c : 0;
+  if (rows) *rows = b->table ? b->tab.W : 0;
+  if (bytes) *bytes = b->table ? (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192) : 0;
+  return BH_OK;
+}
 void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
   (void)ctx;
   if (!b) return;
+  if (b->table) (void)hipFree(b->table);
   if (b->owned && b->dev) (void)hipFree(b->dev);
   delete b;
 }
@@ -503,7 +539,8 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     }
   }
   if (rc == BH_OK)
-    rc = msm_job_enqueue(*impl, bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev, g_forced_c.load());
+    rc = msm_job_enqueue(*impl, bases->table ? bases->table : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
+                         g_forced_c.load(), bases->table ? &bases->tab : nullptr);
   if (rc != BH_OK) {
     float ms[4];
     unsigned char dummy[192];

@@ -340,6 +340,32 @@ __global__ void __launch_bounds__(64) point_check_kernel(const Affine<F> *pts, u
   }
   if (!xyzz_is_identity(acc)) status[i] = st | PT_NOT_IN_SUBGROUP;
 }
+// Window table of a registered base vector: row j holds 2^(c*j) P_i in affine form, so that digit j of
+// a scalar can go to the same bucket set as digit 0 (one bucket reduction instead of W, no Horner
+// over windows).  One lane per base walks the rows: c doublings and one inversion per row.
+template <class F>
+__global__ void __launch_bounds__(128) window_table_kernel(Affine<F> *table, u64 n, u32 c, u32 W) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = table[i];
+  for (u32 j = 1; j < W; j++) {
+    if (!aff_is_identity(p)) {
+      XYZZ<F> acc, t;
+      xyzz_dbl_affine(acc, p);
+      for (u32 k = 1; k < c; k++) { xyzz_dbl(t, acc); acc = t; }
+      xyzz_to_affine(p, acc);
+    }
+    table[(u64)j * n + i] = p;
+  }
+}
+template <class F>
+static int window_table_t(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {
+  const u32 blocks = (u32)((n + 127) / 128);
+  if (!blocks) return BH_OK;
+  hipLaunchKernelGGL(window_table_kernel<F>, dim3(blocks), dim3(128), 0, st, (Affine<F> *)table_dev, n, c, W);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
 template <class F>
 static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {
   const u32 blocks = (u32)((n + 63) / 64);
@@ -353,21 +379,26 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // ============================================================================================
 template <class F>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
-                       u64 n, int fmt, const u64 *density_dev, unsigned forced_c) {
+                       u64 n, int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table) {
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
-  const MsmPlan p = make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu, F::WORDS == 24);
+  // a window table is used when it exists, nobody forces another window size, and its row indices
+  // fit the 31-bit base field of a pair
+  const bool use_table = table && ((forced_c & 0xffu) == 0 || (forced_c & 0xffu) == table->c) &&
+                         (u64)table->W * table->stride < ((u64)1 << 31) && (u64)table->W * n < ((u64)1 << 32);
+  const MsmPlan p = use_table ? make_table_plan(n, *table, (forced_c >> 8) & 0xffffu, F::WORDS == 24, c.num_cus)
+                              : make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu, F::WORDS == 24);
   // accumulator placement: bit 24 of the tuning word forces registers, bit 25 forces LDS
   const bool lds_acc = (forced_c & (1u << 25)) ? true : (forced_c & (1u << 24)) ? false : (F::WORDS == 24);
   job.plan = p;
-  if ((u64)p.W * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
+  if ((u64)p.Wd * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
   if (n_bases >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;        // base index shares its word with the sign bit
   auto alloc = [&](size_t bytes) -> void * {
     void *ptr = c.pool.acquire(bytes);
     if (ptr) job.dev_allocs.push_back(ptr);
     return ptr;
   };
-  const u64 npairs = (u64)p.W * n;
+  const u64 npairs = (u64)p.Wd * n;
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   MsmBuffers b;
   b.pairs_a = (u64 *)alloc(npairs * 8);
@@ -543,10 +574,10 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     }
     if (ef.eof && ef.ident) {
       // both kinds of failure exist: the reference reports the top window's first failure
-      const double cref = (p.n < 32) ? 3.0 : std::ceil(std::log((double)p.n));   // multiexp.rs:318-322
+      const double cref = (p.nd < 32) ? 3.0 : std::ceil(std::log((double)p.nd));   // multiexp.rs:318-322
       const u32 c_ref = (u32)cref, w_ref = (255 + c_ref - 1) / c_ref, lo_ref = c_ref * (w_ref - 1);
-      hipLaunchKernelGGL(msm_err_resolve_kernel<F>, dim3((p.n + 255) / 256), dim3(256), 0, job.stream,
-                         job.scalars_dev, job.fmt, p.n, job.density_dev, job.word_prefix, job.skip, job.n_bases,
+      hipLaunchKernelGGL(msm_err_resolve_kernel<F>, dim3((p.nd + 255) / 256), dim3(256), 0, job.stream,
+                         job.scalars_dev, job.fmt, p.nd, job.density_dev, job.word_prefix, job.skip, job.n_bases,
                          (const Affine<F> *)job.bases_dev, lo_ref, job.err_dev);
       if (hipMemcpyAsync(&ef, job.err_dev, sizeof ef, hipMemcpyDeviceToHost, job.stream) != hipSuccess ||
           hipStreamSynchronize(job.stream) != hipSuccess)
@@ -636,8 +667,12 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
 
 #define BH_INSTANTIATE_MSM(SUFFIX, OPS)                                                                       \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
-                           const void *scalars_dev, u64 n, int fmt, const u64 *density_dev, unsigned fc) {   \
-    return msm_enqueue<OPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, fc);             \
+                           const void *scalars_dev, u64 n, int fmt, const u64 *density_dev, unsigned fc,     \
+                           const WindowTable *table) {                                                       \
+    return msm_enqueue<OPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, fc, table);      \
+  }                                                                                                           \
+  int window_table_##SUFFIX(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {                           \
+    return window_table_t<OPS>(table_dev, n, c, W, st);                                                       \
   }                                                                                                           \
   int msm_finish_##SUFFIX(MsmJobImpl &job, void *out_affine, float *ms) {                                     \
     return msm_finish<OPS>(job, out_affine, ms);                                                              \

@@ -109,7 +109,7 @@ __global__ void density_popc_kernel(const u64 *words, u32 *out, u64 nwords) {
 
 __global__ void msm_digits_kernel(const void *scalars, int fmt, u32 n, const u64 *density,
                                   const u32 *word_prefix, u64 skip, u64 n_bases, u32 c, u32 W,
-                                  u64 *pairs, ErrFlags *err) {
+                                  u64 base_stride, u64 *pairs, ErrFlags *err) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool dense = true;
@@ -134,7 +134,8 @@ __global__ void msm_digits_kernel(const void *scalars, int fmt, u32 n, const u64
     u32 neg = 0;
     carry = 0;
     if (v > half) { v = (1u << c) - v; neg = (v != 0); carry = 1; }
-    pairs[(u64)w * n + i] = ((u64)v << 32) | ((u64)neg << 31) | ((u32)k & 0x7fffffffu);
+    // with a window table digit w of base k adds row w of the table: 2^(c*w) P_k
+    pairs[(u64)w * n + i] = ((u64)v << 32) | ((u64)neg << 31) | ((u32)(k + w * base_stride) & 0x7fffffffu);
   }
 }
 
@@ -245,13 +246,48 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, n >> (p.c - 1));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
+  p.nd = p.n; p.Wd = p.W; p.base_stride = 0;
+  return p;
+}
+
+// Window bits a table is built for (MI355X sweep, profiles/r1_tune_window_table.txt)
+unsigned table_window_bits(u64 n_bases, bool g2) {
+  (void)g2;
+  const u32 lg = ilog2(n_bases ? n_bases : 1);
+  return lg <= 12 ? 8 : lg <= 16 ? 13 : 16;
+}
+
+MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
+  MsmPlan p;
+  p.c = t.c;
+  p.Wd = (256 + p.c - 1) / p.c;            // == t.W
+  p.nd = (u32)n;
+  p.base_stride = t.stride;
+  p.n = (u32)((u64)p.Wd * n);              // every digit of every scalar is an entry of the one window
+  p.W = 1;
+  p.nb = 1u << (p.c - 1);
+  p.NB = p.nb;
+  p.lo_bits = (p.c - 1) / 2;
+  p.hi_bits = (p.c - 1) - p.lo_bits;
+  p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
+  // K: a quarter of the average bucket (so a bucket spans a handful of chunks, folded by its owner lane
+  // in the merge), at least the classic value, but never so large that the chip runs out of lanes
+  const u32 lg = ilog2(p.n ? p.n : 1);
+  const u32 base_k = lg <= 11 ? 8 : lg <= 17 ? 16 : g2 ? 64 : 32;
+  const u64 avg = (u64)p.n >> (p.c - 1);
+  const u64 lanes_wanted = (u64)num_cus * 4 * 64 * 2;   // two wavefronts per SIMD
+  u64 k = std::max<u64>(base_k, avg / 4);
+  k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_wanted));
+  p.chunk = forced_chunk ? forced_chunk : (u32)k;
+  p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
+  p.sort_passes = (p.c + 7) / 8;
   return p;
 }
 
 
 int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
                    u64 skip, u64 n_bases, hipStream_t st, const u64 **sorted_out) {
-  const u64 n = p.n;
+  const u64 n = p.nd;   // scalars (the density bitmap is indexed by scalar)
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nwords = (n + 63) / 64;
   if (density_dev) {
@@ -262,8 +298,8 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
     if (rc) return rc;
   }
   // 1. digits
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.n,
-                     density_dev, b.word_prefix, skip, n_bases, p.c, p.W, b.pairs_a, b.err);
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((p.nd + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.nd,
+                     density_dev, b.word_prefix, skip, n_bases, p.c, p.Wd, p.base_stride, b.pairs_a, b.err);
   BH_HIP_CHECK(hipGetLastError());
   // 2. sort by digit, 8 bits per pass
   u64 *src = b.pairs_a, *dst = b.pairs_b;

@@ -31,6 +31,17 @@ struct MsmPlan {
   u32 n, c, W, nb, NB, lo_bits, hi_bits, num_tiles, sort_passes;
   u32 chunk;             // K: sorted entries per accumulation lane
   u32 chunks_per_window; // ceil(n / K)
+  // digit stage: nd scalars x Wd digits.  Classic plan: nd == n, Wd == W, base_stride == 0.
+  // Window-table plan (bases registered with their multiples 2^(c*j) P): all Wd digit columns feed
+  // ONE bucket set, so the stages after the digits see a single window of n = nd*Wd entries (W == 1)
+  // and a pair's base field addresses table row j: j*base_stride + base index.
+  u32 nd, Wd;
+  u64 base_stride;
+};
+// multiples 2^(c*j) P_i, j < W, stored row-major [j][i] (row 0 = the bases themselves)
+struct WindowTable {
+  u32 c, W;
+  u64 stride;   // number of bases per row
 };
 
 struct MsmJobImpl {
@@ -64,6 +75,8 @@ struct MsmBuffers {
   ErrFlags *err;
 };
 MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2);
+MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus);
+unsigned table_window_bits(u64 n_bases, bool g2);   // the c a window table is built for by default
 size_t scan_tmp_elems(u64 n);
 // runs stages 1-2 (+ per-window first non-zero position) on `st`; *sorted_out = sorted pairs
 int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
@@ -71,9 +84,9 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
 
 // msm_g1.hip / msm_g2.hip
 int msm_enqueue_g1(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                   int fmt, const u64 *density_dev, unsigned forced_c);
+                   int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
 int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                   int fmt, const u64 *density_dev, unsigned forced_c);
+                   int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
 int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);   // ms: float[4] or null
 int msm_finish_g2(MsmJobImpl &job, void *out_affine, float *ms);
 int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
@@ -92,6 +105,10 @@ enum PointStatus : u32 {
   PT_INVALID_MASK = PT_COMPRESSED | PT_SORT | PT_RANGE | PT_INF_NONZERO | PT_OFF_CURVE | PT_NOT_IN_SUBGROUP,
 };
 // on-curve + prime-order-subgroup test of decoded points (skips entries already invalid / identity)
+// fills rows 1 .. W-1 of a window table whose row 0 holds the n bases
+int window_table_g1(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st);
+int window_table_g2(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st);
+int window_table(int group, void *table_dev, u64 n, u32 c, u32 W, hipStream_t st);
 int points_check_g1(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);
 int points_check_g2(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);
 int points_check(int group, const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st);

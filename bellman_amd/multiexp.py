@@ -5,6 +5,7 @@ all-zero = identity); scalars are [n,4] uint64 little-endian, canonical unless `
 """
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -72,6 +73,7 @@ class Bases:
         )
         self._h = h
         self.n = n
+        self._auto_precompute()
 
     @classmethod
     def from_uncompressed(cls, worker, group, data):
@@ -86,6 +88,7 @@ class Bases:
         check(_lib.load().bh_bases_register_uncompressed(worker.ctx, group, buf.ctypes.data_as(ctypes.c_void_p), self.n,
                                                          ctypes.byref(h)), "bases_register_uncompressed")
         self._h = h
+        self._auto_precompute()
         return self
 
     @classmethod
@@ -108,7 +111,26 @@ class Bases:
             e.index = bad.value
             raise
         self._h = h
+        self._auto_precompute()
         return self
+
+    def _auto_precompute(self):
+        # BELLMAN_HIP_PRECOMPUTE=1 (or =<window bits>): build the window table at registration
+        v = os.environ.get("BELLMAN_HIP_PRECOMPUTE", "")
+        if v and v != "0" and self.n:
+            self.precompute(0 if v == "1" else int(v))
+
+    def precompute(self, window_bits=0):
+        """Build the window table 2^(c*j) P_i next to the bases (W x the memory): multiexps over this
+        vector then use one bucket set for all windows.  Same results, faster reduction."""
+        check(_lib.load().bh_bases_precompute(self.worker.ctx, self._h, window_bits), "bases_precompute")
+        return self
+
+    def table_info(self):
+        """(window bits, rows, bytes) of the window table; zeros without one"""
+        c_, w_, b_ = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_size_t()
+        check(_lib.load().bh_bases_table_info(self._h, ctypes.byref(c_), ctypes.byref(w_), ctypes.byref(b_)))
+        return c_.value, w_.value, b_.value
 
     def download(self, first=0, count=None):
         """affine Montgomery records [count, 12|24] uint64 back from HBM"""
@@ -125,6 +147,7 @@ class Bases:
         h = ctypes.c_void_p()
         check(_lib.load().bh_bases_wrap_dev(worker.ctx, group, dev_ptr, n, ctypes.byref(h)))
         self._h = h
+        self._auto_precompute()
         return self
 
     def __len__(self):

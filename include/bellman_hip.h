@@ -126,6 +126,15 @@ int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, s
                                bh_bases **out, size_t *bad_index);
 /* copies `count` device-resident affine records (Montgomery) starting at `first` back to the host */
 int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host);
+/* Window table for a registered base vector (optional; the CRS is fixed across proofs, groth16/src/lib.rs
+ * :443-473 hands out the same Arc<Vec<Affine>> every time): stores 2^(c*j) P_i for every window j next to
+ * the bases (W = ceil(256/c) rows, W x the memory).  Multiexps over such bases send every digit of a
+ * scalar to ONE bucket set - one bucket reduction instead of W and no doubling chain over windows.
+ * The result of a multiexp is the same group element either way.  window_bits = 0 picks the tuned
+ * value for the vector length.  BH_ERR_HIP when the table does not fit in HBM (the handle stays usable
+ * without it); BH_ERR_INVALID_ARG when W x n >= 2^31. */
+int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits);
+int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows, size_t *bytes);
 /* a new owned handle holding a device-to-device copy of `n` packed records */
 int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 /* wrap an existing device array of packed 96/192-byte records (not owned) */

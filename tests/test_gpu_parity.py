@@ -551,3 +551,51 @@ def test_msm_fuzz_random_shapes(worker, seed):
     finally:
         lib.bh_msm_set_window_bits(worker.ctx, 0)
         lib.bh_msm_set_chunk(worker.ctx, 0)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n,cbits", [(1, 0), (2, 3), (37, 0), (1000, 5), (1000, 0), (5000, 11), (1 << 14, 0), (1 << 14, 16)])
+def test_multiexp_with_window_table(worker, group, n, cbits):
+    """bh_bases_precompute: all windows into one bucket set via the stored multiples 2^(c*j) P -
+    the same group element as without the table and as the oracle, with skip and a density map."""
+    import bellman_amd
+
+    bases = cref.gen_bases(group, n + 3, a=5, b=11)
+    sc = cref.random_fr(n, 77 + n)
+    if n > 4:
+        sc[0] = 0
+        sc[1] = 0
+        sc[1, 0] = 1                                       # scalar 1
+        sc[2] = cref.ints_to_arr([bls.Q - 1], 4)[0]         # q - 1: top window + carries
+    hb = bellman_amd.Bases(worker, group, bases)
+    plain = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, skip=2).wait()
+    hb.precompute(cbits)
+    c_used, rows, nbytes = hb.table_info()
+    assert rows == (256 + c_used - 1) // c_used and nbytes == rows * (n + 3) * (96 if group == 1 else 192)
+    rc, want = cref.multiexp(group, bases, 2, None, sc)
+    assert rc == 0
+    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, skip=2).wait()
+    assert np.array_equal(got, want) and np.array_equal(plain, want)
+    rnd = random.Random(n)
+    bits = [rnd.random() < 0.6 for _ in range(n)]
+    rc, want = cref.multiexp(group, bases, 1, cref.density_bitmap(bits), sc)
+    assert rc == 0
+    assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.DensityTracker(bits), sc, skip=1).wait(), want)
+
+
+def test_window_table_error_semantics(worker):
+    """identity bases and short base vectors behave the same with a table (Appendix A item 6)"""
+    import bellman_amd
+
+    n = 300
+    bases = cref.gen_bases(1, n, a=3, b=7)
+    bases[17] = 0
+    sc = cref.random_fr(n, 9)
+    hb = bellman_amd.Bases(worker, 1, bases).precompute()
+    with pytest.raises(bellman_amd.UnexpectedIdentity):
+        bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait()
+    sc[17] = 0   # an identity under a zero scalar is skipped silently
+    rc, want = cref.multiexp(1, bases, 0, None, sc)
+    assert rc == 0 and np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want)
+    with pytest.raises(bellman_amd.UnexpectedEof):
+        bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, skip=1).wait()

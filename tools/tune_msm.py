@@ -31,7 +31,13 @@ def main():
     ds = w.alloc(n * 32)
     w.upload(ds, s)
     ref = None
+    table = os.environ.get("BH_TABLE", "0") == "1"   # BH_TABLE=1: sweep with a window table built for each c
     for c in cs:
+        if table:
+            import time
+            t0 = time.time()
+            bases.precompute(c)
+            print("  window table c=%d: %s built in %.2f s" % (c, bases.table_info(), time.time() - t0), flush=True)
         for k in ks:
             lib.bh_msm_set_window_bits(w.ctx, c)
             lib.bh_msm_set_chunk(w.ctx, k | (int(os.environ.get('BH_ACC', '0')) << 16))
