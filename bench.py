@@ -84,6 +84,20 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481,
                                     tau=3673)
     generate_ms = (time.perf_counter() - t0) * 1e3
+    # the serialized form and back (Parameters::write / Parameters::read, groth16/src/lib.rs:258-398): the proofs
+    # below use the parameters that came through the reader with `checked = true`
+    t0 = time.perf_counter()
+    blob = params.write()
+    write_ms = (time.perf_counter() - t0) * 1e3
+    params.release()
+    t0 = time.perf_counter()
+    params = pg.Parameters.read(worker, blob, True)
+    read_checked_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    pg.Parameters.read(worker, blob, False).release()
+    read_unchecked_ms = (time.perf_counter() - t0) * 1e3
+    crs_bytes = len(blob)
+    del blob
     tms = []
     for i in range(proofs + 1):
         tm = [0, 0, 0, 0]
@@ -171,7 +185,10 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "samples": proofs,
         "cpu_baseline": cpu,
         "crs": "generate_parameters on the device from fixed toxic waste: %.0f ms (h, l, a, b_g1, b_g2 = %d G1 + %d G2 "
-               "fixed-base multiplications, 1 iFFT, transposed sparse product); untimed set-up" % (generate_ms, 4 * (1 << log_n), 1 << log_n),
+               "fixed-base multiplications, 1 iFFT, transposed sparse product); Parameters::write %.0f ms (%.0f MB, host "
+               "encoding); Parameters::read(checked) %.0f ms / (unchecked) %.0f ms incl. the host-to-device copy - decoding, "
+               "on-curve and subgroup tests on the device; untimed set-up"
+               % (generate_ms, 4 * (1 << log_n), 1 << log_n, write_ms, crs_bytes / 1e6, read_checked_ms, read_unchecked_ms),
         "with_r1cs_resident_in_hbm": {
             "note": "constraint matrices captured once per circuit (%.0f ms, untimed, like the CRS upload); per proof: "
                     "witness closures on the host, A.w/B.w/C.w + everything else on the device; identical proofs" % capture_ms,
