@@ -140,6 +140,24 @@ int bh_ctx_create(int device, bh_ctx **out) {
   *out = ctx;
   return BH_OK;
 }
+int bh_ctx_trim(bh_ctx *ctx) {
+  // Workspaces of finished jobs are kept in a size-bucketed cache (a 2^26-term multiexp leaves ~30 GB
+  // there): hand the idle blocks and the cached FFT tables back to the driver.  Blocks in use stay.
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  BH_HIP_CHECK(hipDeviceSynchronize());
+  ctx->c.pool.release_all();
+  {
+    std::lock_guard<std::mutex> g(ctx->c.fft_mu);
+    for (auto &kv : ctx->c.fft_tables) {
+      if (kv.second.tw) (void)hipFree(kv.second.tw);
+      if (kv.second.coset) (void)hipFree(kv.second.coset);
+      if (kv.second.icoset) (void)hipFree(kv.second.icoset);
+    }
+    ctx->c.fft_tables.clear();
+  }
+  return BH_OK;
+}
 void bh_ctx_destroy(bh_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->c.device);

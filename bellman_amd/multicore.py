@@ -29,6 +29,10 @@ class Worker:
     def synchronize(self):
         check(self._lib.bh_ctx_synchronize(self._ctx))
 
+    def trim(self):
+        """give idle cached device memory (job workspaces, FFT tables) back to the driver"""
+        check(self._lib.bh_ctx_trim(self._ctx))
+
     def close(self):
         if self._ctx:
             self._lib.bh_ctx_destroy(self._ctx)

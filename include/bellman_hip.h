@@ -71,6 +71,10 @@ int bh_stream_synchronize(bh_ctx *ctx, void *stream);
 int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int bh_dev_zero_on(bh_ctx *ctx, void *dev_ptr, size_t bytes, void *stream);
 int bh_ctx_synchronize(bh_ctx *ctx);
+/* returns the context's idle cached device memory (recycled job workspaces, FFT twiddle tables) to the
+ * driver; waits for the device to be idle first.  Purely a memory-footprint control; call it while no
+ * other thread is inside a call on this context. */
+int bh_ctx_trim(bh_ctx *ctx);
 
 /* ---- EvaluationDomain (src/domain.rs) ------------------------------------------------
  * mode: 0 fft (:81-83)  1 ifft (:85-99)  2 coset_fft (:115-118)  3 icoset_fft (:120-125).

@@ -87,5 +87,9 @@ def soak_proofs(w):
     print("free MiB after each proof cycle:", marks, "elapsed %.1fs" % (time.time() - t0))
     assert marks[-1] >= marks[2] - 64, "device memory keeps shrinking"
     print("soak ok (proof path)")
+    before = free_mb()
+    w.trim()
+    print("trim: free MiB %d -> %d" % (before, free_mb()))
+    assert free_mb() >= before
 
 main()
