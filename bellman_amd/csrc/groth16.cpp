@@ -102,6 +102,16 @@ void Fr::to_canonical(uint64_t out[4]) const {
   const uint64_t one[4] = {1, 0, 0, 0};
   mont_mul(out, l, one);
 }
+// little-endian 512-bit integer -> Fr (ff's wide reduction behind Field::random): lo + hi * 2^256 mod q
+Fr Fr::from_u512(const uint64_t limbs[8]) {
+  Fr lo, hi, r2;
+  memcpy(lo.l, limbs, 32);
+  memcpy(hi.l, limbs + 4, 32);
+  memcpy(r2.l, FR_R2, 32);
+  // mont_mul(x, R^2) = x * R mod q for any 256-bit x: the Montgomery form of x mod q
+  const Fr lo_m = lo * r2, hi_m = hi * r2;
+  return lo_m + hi_m * r2;   // Montgomery form of 2^256 is R * R = R^2
+}
 Fr Fr::pow_vartime(uint64_t e) const {
   Fr acc = Fr::one();
   for (int i = 63; i >= 0; i--) {
@@ -123,6 +133,7 @@ Fr Fr::invert() const {   // a^(q-2)
 
 namespace groth16 {
 using namespace bellman;
+
 
 bool G1Affine::is_identity() const { uint64_t o = 0; for (uint64_t x : v) o |= x; return o == 0; }
 bool G2Affine::is_identity() const { uint64_t o = 0; for (uint64_t x : v) o |= x; return o == 0; }
@@ -1055,6 +1066,12 @@ int bh_groth16_params_vk(const bh_params *p, void *alpha_g1, void *beta_g1, void
   if (delta_g1) memcpy(delta_g1, &vk.delta_g1, 96);
   if (delta_g2) memcpy(delta_g2, &vk.delta_g2, 192);
   return BH_OK;
+}
+void bh_test_fr_from_u512_host(void *r, const void *limbs8) {
+  uint64_t w[8];
+  memcpy(w, limbs8, 64);
+  const bellman::Fr f = bellman::Fr::from_u512(w);
+  memcpy(r, &f, 32);
 }
 void bh_proof_write(const void *proof_affine, void *out192) {
   groth16::Proof p;

@@ -31,6 +31,7 @@ struct Fr {
   static Fr zero();
   static Fr one();
   static Fr from_u64(uint64_t v);
+  static Fr from_u512(const uint64_t limbs_le[8]);   // wide reduction, as ff's Field::random does
   bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
   bool operator==(const Fr &o) const { return memcmp(l, o.l, sizeof l) == 0; }
   bool operator!=(const Fr &o) const { return !(*this == o); }
@@ -250,6 +251,17 @@ class WitnessAssignment : public bellman::ConstraintSystem {
 // prover.rs:182-361.  Throws bellman::SynthesisError.
 Proof create_proof(bellman::Circuit &circuit, Parameters &params, const Fr &r, const Fr &s,
                    ProveTimings *timings = nullptr);
+// prover.rs:164-180: r and s drawn from `rng` (any callable returning uint64_t; 512 bits each, reduced
+// mod q like ff's Field::random), then create_proof.
+template <class Rng>
+Proof create_random_proof(bellman::Circuit &circuit, Parameters &params, Rng &&rng) {
+  uint64_t w[8];
+  for (uint64_t &x : w) x = rng();
+  const Fr r = Fr::from_u512(w);
+  for (uint64_t &x : w) x = rng();
+  const Fr s = Fr::from_u512(w);
+  return create_proof(circuit, params, r, s);
+}
 // prover.rs:217-360 on an already synthesised assignment (input constraints already appended)
 Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s,
                        ProveTimings *timings = nullptr);

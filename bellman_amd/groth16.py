@@ -269,6 +269,19 @@ def create_proof(circuit, params, r, s, timings=None):
     return prove_assignment(prover, params, r, s, timings)
 
 
+def create_random_proof(circuit, params, rng=None, r1cs=None):
+    """prover.rs:164-180: r and s drawn uniformly from Fr, then create_proof.  `rng` is any object with
+    randrange (random.Random, random.SystemRandom); default: the operating system's CSPRNG.  With
+    `r1cs` the constraint evaluation runs on the device (create_proof_r1cs)."""
+    import random
+
+    rng = rng or random.SystemRandom()
+    r, s = rng.randrange(Q), rng.randrange(Q)
+    if r1cs is not None:
+        return create_proof_r1cs(circuit, r1cs, params, r, s)
+    return create_proof(circuit, params, r, s)
+
+
 def create_proof_demo(params, kind, size, seed, witness, constants, r, s, timings=None):
     """create_proof on one of the C++ demo circuits (groth16.cpp): 0 = MiMCDemo, 1 = chain."""
     lib = _lib.load()

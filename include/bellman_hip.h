@@ -328,6 +328,7 @@ void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
 void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
+void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,11 @@ int main(int argc, char **argv) {
     groth16::R1cs r1cs(shape, ctx);
     groth16::Proof p2 = groth16::create_proof(circuit, r1cs, params, r, s);
     if (memcmp(&p, &p2, sizeof p) != 0) { fprintf(stderr, "R1cs path produced a different proof\n"); rc = 5; }
+    // create_random_proof (prover.rs:164-180): r, s from the caller's generator; two calls differ
+    uint64_t state = 88172645463325252ULL;
+    auto rng = [&state] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+    groth16::Proof q1 = groth16::create_random_proof(circuit, params, rng), q2 = groth16::create_random_proof(circuit, params, rng);
+    if (memcmp(&q1, &q2, sizeof q1) == 0 || memcmp(&q1, &p, sizeof p) == 0) { fprintf(stderr, "create_random_proof is not random\n"); rc = 6; }
   } catch (const SynthesisError &e) {
     fprintf(stderr, "SynthesisError %d: %s\n", e.code, e.what());
     rc = 10 + e.code;

@@ -151,3 +151,23 @@ def test_host_group_ops_accept_unaligned_buffers(lib):
     k = np.array(cref.int_to_limbs(12345, 4), dtype=np.uint64)
     lib.bh_point_mul(1, _p(r), _p(a), _p(k))
     assert np.array_equal(r, cref.point_mul(1, A[0], 12345))
+
+
+def test_fr_wide_reduction_host():
+    """Fr::from_u512 of the C++ mirror (create_random_proof's sampling, prover.rs:176-177): host code"""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    rnd = random.Random(3)
+    for v in [0, 1, q - 1, q, q + 1, (1 << 256) - 1, 1 << 256, (1 << 512) - 1] + [rnd.getrandbits(512) for _ in range(50)]:
+        limbs = np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(8)], dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        lib.bh_test_fr_from_u512_host(out.ctypes.data_as(ctypes.c_void_p), limbs.ctypes.data_as(ctypes.c_void_p))
+        got = sum(int(x) << (64 * i) for i, x in enumerate(out))
+        assert got == (v % q) * (1 << 256) % q
