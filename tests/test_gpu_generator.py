@@ -113,3 +113,29 @@ def test_generate_errors(worker):
 
     with pytest.raises(bellman_amd.UnconstrainedVariable):
         pg.Parameters.generate(worker, pg.R1CS.from_circuit(worker, unconstrained), g1, g2, *[TOXIC[k] for k in ("alpha", "beta", "gamma", "delta", "tau")])
+
+
+def test_mimc_322_generate_prove_verify_like_the_reference_test(worker):
+    """groth16/tests/mimc.rs:38-101 end to end on the product: random trapdoors -> generate_parameters
+    (device), create_random_proof (device, R1CS resident), Proof::write = 192 bytes, and the proof
+    satisfies the verification equation (oracle/pyref/pairing.py restates verify_proof) for the right
+    image only."""
+    from bellman_amd import groth16 as pg
+    from oracle.pyref import pairing
+
+    rnd = random.Random(31415)
+    cons = [rnd.randrange(Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr = rnd.randrange(Q), rnd.randrange(Q)
+    image = circuits.mimc_hash(xl, xr, cons)
+    r1cs = pg.R1CS.from_demo(worker, 0, circuits.MIMC_ROUNDS, 0, cons)
+    g1, g2 = _recs(1, [CBls12.G1.gen])[0], _recs(2, [CBls12.G2.gen])[0]
+    params = pg.Parameters.generate(worker, r1cs, g1, g2, *[rnd.randrange(1, Q) for _ in range(5)])
+    proof = pg.create_random_proof(circuits.mimc_circuit(xl, xr, cons), params, rng=rnd, r1cs=r1cs)
+    assert len(proof.write()) == 192
+    alpha_g1, _, beta_g2, _, delta_g2 = params.vk()
+    gamma_g2, ic = params.vk_ext()
+    vk = dict(alpha_g1=cref.g1_to_py(alpha_g1)[0], beta_g2=cref.g2_to_py(beta_g2)[0], gamma_g2=cref.g2_to_py(gamma_g2)[0],
+              delta_g2=cref.g2_to_py(delta_g2)[0], ic=cref.g1_to_py(ic))
+    pr = (cref.g1_to_py(proof.a)[0], cref.g2_to_py(proof.b)[0], cref.g1_to_py(proof.c)[0])
+    assert pairing.verify_proof(vk, pr, [image])
+    assert not pairing.verify_proof(vk, pr, [(image + 1) % Q])
