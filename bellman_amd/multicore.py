@@ -29,6 +29,39 @@ class Worker:
     def synchronize(self):
         check(self._lib.bh_ctx_synchronize(self._ctx))
 
+    # ---- host-side task helpers (multicore.rs:33-91): device work goes through multiexp /
+    # EvaluationDomain; these exist for caller code that used the pool for its own host tasks ----
+    _pool = None
+
+    @classmethod
+    def _host_pool(cls):
+        if cls._pool is None:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+
+            cls._host_threads = os.cpu_count() or 1
+            cls._pool = ThreadPoolExecutor(max_workers=cls._host_threads)
+        return cls._pool
+
+    def compute(self, f):
+        """multicore.rs:33-76: run `f` on the host pool, return a Waiter for its result."""
+        fut = self._host_pool().submit(f)
+        return Waiter(fn=fut.result)
+
+    def scope(self, elements, f):
+        """multicore.rs:78-91: f(scope, chunk_size) with chunk_size = 1 if elements < threads else
+        elements // threads; `scope.spawn(g)` schedules g(scope) and every spawned task has finished
+        when this call returns."""
+        self._host_pool()
+        n = self._host_threads
+        chunk = 1 if elements < n else elements // n
+        sc = _Scope(self._host_pool())
+        try:
+            out = f(sc, chunk)
+        finally:
+            sc.join()
+        return out
+
     def trim(self):
         """give idle cached device memory (job workspaces, FFT tables) back to the driver"""
         check(self._lib.bh_ctx_trim(self._ctx))
@@ -58,6 +91,22 @@ class Worker:
 
     def download(self, arr, dev):
         check(self._lib.bh_dev_download(self._ctx, arr.ctypes.data_as(ctypes.c_void_p), dev, arr.nbytes))
+
+
+class _Scope:
+    """rayon::Scope stand-in for Worker.scope"""
+
+    def __init__(self, pool):
+        self._pool, self._futs = pool, []
+
+    def spawn(self, g):
+        self._futs.append(self._pool.submit(g, self))
+
+    def join(self):
+        i = 0
+        while i < len(self._futs):   # tasks may spawn further tasks
+            self._futs[i].result()
+            i += 1
 
 
 class Waiter:

@@ -599,3 +599,26 @@ def test_window_table_error_semantics(worker):
     assert rc == 0 and np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want)
     with pytest.raises(bellman_amd.UnexpectedEof):
         bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, skip=1).wait()
+
+
+def test_worker_compute_and_scope_host_helpers(worker):
+    """multicore.rs:33-91 mirrors: compute -> Waiter; scope chunking rule and join-on-return"""
+    w = worker.compute(lambda: sum(range(1000)))
+    assert w.wait() == 499500
+    import os
+
+    n_thr = os.cpu_count() or 1
+    out = [0] * 1000
+
+    def body(scope, chunk):
+        assert chunk == (1 if len(out) < n_thr else len(out) // n_thr)
+        for lo in range(0, len(out), chunk):
+            def task(_scope, lo=lo):
+                for i in range(lo, min(len(out), lo + chunk)):
+                    out[i] = i * i
+            scope.spawn(task)
+        return chunk
+
+    assert worker.scope(len(out), body) >= 1
+    assert out == [i * i for i in range(1000)]      # every spawned task finished before scope returned
+    assert worker.scope(3, lambda s, chunk: chunk) == (1 if 3 < n_thr else 3 // n_thr)
