@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the create_proof (config C4) measurement")
     ap.add_argument("--proof-log-n", type=int, default=20)
+    ap.add_argument("--c5-log-n", type=int, default=26,
+                    help="N > 1 only: total size of the extra sharded MSM of BASELINE configs[4] (0 = skip)")
     ap.add_argument("--timed-steps-only", action="store_true",
                     help="run only warm-up + the K timed steps (no overlapped / PCIe extras): the command profiled for "
                          "profiles/*kernel_stats.csv, so that rocprof's per-kernel average matches the live HIP-event figure")
@@ -398,6 +400,40 @@ def main():
     sharded_proof = None
     if distributed and not args.no_proof:
         sharded_proof = bench_create_proof_sharded(worker, args.proof_log_n, world, rank, coll_dev)
+    # BASELINE.json configs[4]: ONE 2^26-term G1 MSM sharded by bases over all ranks (strong scaling of a
+    # fixed problem; extra information, not `value`)
+    c5 = None
+    if distributed and args.c5_log_n:
+        n5 = (1 << args.c5_log_n) // world
+        t5 = torch.from_numpy(splitmix_scalars(n5, 0xC5 + rank * 8 * n5).view(np.int64)).cuda()
+        b5 = torch.empty((n5, 12), dtype=torch.int64, device="cuda")
+        assert lib.bh_fixed_base_mul_dev(worker.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t5.data_ptr()),
+                                         n5, 0, ctypes.c_void_p(b5.data_ptr()), None) == 0
+        worker.synchronize()
+        bases5 = bellman_amd.Bases.wrap_device(worker, 1, ctypes.c_void_p(b5.data_ptr()), n5)
+        s5 = torch.from_numpy(splitmix_scalars(n5, 0x5CA1A25 + rank * 8 * n5).view(np.int64)).cuda()
+
+        def step5():
+            part = bellman_amd.multiexp(worker, bases5, bellman_amd.FullDensity(), None,
+                                        scalars_dev=ctypes.c_void_p(s5.data_ptr()), n=n5).wait()
+            return sharding.fold_partials(part, 1, device=coll_dev if coll_dev == "cuda" else None)
+
+        step5()
+        barrier()
+        t0 = time.perf_counter()
+        steps5 = 3
+        for _ in range(steps5):
+            step5()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e5 = float(tt.item())
+        c5 = {"workload": "one G1 MSM of 2^%d terms sharded by bases over %d ranks (%d terms per rank) + all-gather + fold"
+                          % (args.c5_log_n, world, n5),
+              "value": round(world * n5 * steps5 / e5 / 1e6, 3), "unit": "Mscalar-mul/s", "ms_per_msm": round(e5 * 1e3 / steps5, 2),
+              "scaling": "strong", "steps": steps5}
+        del bases5, b5, t5, s5
+        worker.trim()
     out = None
     if rank == 0:
         acc_ms = float(stage[2])
@@ -467,6 +503,8 @@ def main():
             }
         if sharded_proof is not None:
             out["create_proof_sharded"] = sharded_proof
+        if c5 is not None:
+            out["msm_2p26_sharded"] = c5
         if not args.no_proof and not distributed:
             out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
