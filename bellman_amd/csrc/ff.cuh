@@ -321,10 +321,27 @@ BH_HD void fe_inv(Fe<P> &r, const Fe<P> &a) {  // a^(m-2); a != 0
 }
 
 // out-of-line Fp product used by all curve code (the FFT keeps its 8-limb Fr product inline)
-BH_NOINLINE_HD static fp_t fp_mul_call(fp_t a, fp_t b) {
-  fp_t r;
+// The operands travel as six 4-word vectors, not as two structs: clang's AMDGPU ABI passes at most 16
+// registers' worth of *aggregate* arguments directly, so the second 12-word struct of a (fp_t, fp_t)
+// signature went through scratch memory - a store/load round trip in front of every product that the
+// one or two resident wavefronts of the G2 kernels could not hide.  Scalars and vectors are not
+// subject to that cap: all 24 words arrive in v0-v23.
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+BH_NOINLINE_HD static fp_t fp_mul_vec(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2) {
+  fp_t a, b, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
+  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w;
+  b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w;
+  b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w;
+  b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w;
   fe_mul(r, a, b);
   return r;
+}
+BH_HD fp_t fp_mul_call(const fp_t &a, const fp_t &b) {
+  return fp_mul_vec(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]},
+                    u32x4{a.l[8], a.l[9], a.l[10], a.l[11]}, u32x4{b.l[0], b.l[1], b.l[2], b.l[3]},
+                    u32x4{b.l[4], b.l[5], b.l[6], b.l[7]}, u32x4{b.l[8], b.l[9], b.l[10], b.l[11]});
 }
 
 // ---------------------------------------------------------------------------------------
