@@ -82,15 +82,19 @@ typedef Fe<FpParams> fp_t;
 // ---------------------------------------------------------------------------------------
 // carry helpers (single definition so the lowering can be tuned in one place)
 // ---------------------------------------------------------------------------------------
+// The clang carry builtins lower to v_add_co_u32 / v_addc_co_u32 (carry in VCC): one instruction per
+// limb.  Written with 64-bit arithmetic the same chains became v_lshl_add_u64 + shift + mask per limb.
 BH_HD u32 addc(u32 a, u32 b, u32 cin, u32 &cout) {
-  u64 s = (u64)a + b + cin;
-  cout = (u32)(s >> 32);
-  return (u32)s;
+  unsigned co;
+  const u32 s = __builtin_addc(a, b, cin, &co);
+  cout = co;
+  return s;
 }
 BH_HD u32 subb(u32 a, u32 b, u32 bin, u32 &bout) {
-  u64 d = (u64)a - b - bin;
-  bout = (u32)(d >> 63);
-  return (u32)d;
+  unsigned bo;
+  const u32 d = __builtin_subc(a, b, bin, &bo);
+  bout = bo;
+  return d;
 }
 
 template <class P>
