@@ -280,12 +280,31 @@ BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
 // Also evaluated and rejected on the MI355X: the interleaved product-scanning form (retire each column
 // immediately; 70 instead of 97 VGPRs for the out-of-line call) - 24 % more 64-bit add/shift work,
 // 46 vs 57 G mul/s, and callers still do not reach three waves per SIMD.
-// A dedicated squaring (91 instead of 169 product mads) was evaluated and rejected: the operand
-// of the product is a * 2^SHIFT, so the symmetric half-product needs an extra normalise-and-shift
-// pass over the 2L columns (~180 full-rate ops) that costs as much as the 78 mads it saves.
+//
+// Squaring: the product above is a * (b * 2^SHIFT); with SHIFT even the same scaling comes from
+// (a * 2^(SHIFT/2))^2, whose operands are equal - so the off-diagonal limb products are computed once and
+// doubled: L(L-1)/2 + L = 91 instead of 169 product mads for Fp (the reduction is unchanged).
 template <class P>
 BH_HD void fe_sqr(Fe<P> &r, const Fe<P> &a) {
-  fe_mul(r, a, a);
+  typedef Radix30<P> R;
+  constexpr int L = R::L;
+  static_assert(R::SHIFT % 2 == 0, "squaring splits the Montgomery pre-shift evenly");
+  u32 A[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) A[i] = fe_limb30<P, R::SHIFT / 2>(a, i);
+  u64 c[2 * L];
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+#pragma unroll
+    for (int j = i + 1; j < L; j++) c[i + j] += (u64)A[i] * A[j];   // < (L/2) * 2^60 per column
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) c[k] <<= 1;
+#pragma unroll
+  for (int i = 0; i < L; i++) c[2 * i] += (u64)A[i] * A[i];        // column total < L * 2^60 < 2^64
+  fe_mont_reduce30<P>(r, c);
 }
 
 // canonical <-> Montgomery
@@ -342,6 +361,18 @@ BH_NOINLINE_HD static fp_t fp_mul_vec(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u3
   fe_mul(r, a, b);
   return r;
 }
+BH_NOINLINE_HD static fp_t fp_sqr_vec(u32x4 a0, u32x4 a1, u32x4 a2) {
+  fp_t a, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
+  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w;
+  fe_sqr(r, a);
+  return r;
+}
+BH_HD fp_t fp_sqr_call(const fp_t &a) {
+  return fp_sqr_vec(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]},
+                    u32x4{a.l[8], a.l[9], a.l[10], a.l[11]});
+}
 BH_HD fp_t fp_mul_call(const fp_t &a, const fp_t &b) {
   return fp_mul_vec(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]},
                     u32x4{a.l[8], a.l[9], a.l[10], a.l[11]}, u32x4{b.l[0], b.l[1], b.l[2], b.l[3]},
@@ -368,7 +399,7 @@ struct FpOps {
   BH_HD static void neg(T &r, const T &a) { fe_neg(r, a); }
   BH_HD static void dbl(T &r, const T &a) { fe_add(r, a, a); }
   BH_HD static void mul(T &r, const T &a, const T &b) { r = fp_mul_call(a, b); }
-  BH_HD static void sqr(T &r, const T &a) { r = fp_mul_call(a, a); }
+  BH_HD static void sqr(T &r, const T &a) { r = fp_sqr_call(a); }
   BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
     T one2;
     fe_one(r);
@@ -383,7 +414,7 @@ struct FpOps {
     T acc;
     fe_one(acc);
     for (int i = 383; i >= 0; i--) {
-      acc = fp_mul_call(acc, acc);
+      acc = fp_sqr_call(acc);
       if ((e[i / 32] >> (i % 32)) & 1) acc = fp_mul_call(acc, a);
     }
     r = acc;
@@ -429,8 +460,8 @@ struct Fp2Ops {
   }
   BH_HD static void inv(T &r, const T &a) {
     fp_t n, t;
-    n = fp_mul_call(a.c0, a.c0);
-    t = fp_mul_call(a.c1, a.c1);
+    n = fp_sqr_call(a.c0);
+    t = fp_sqr_call(a.c1);
     fe_add(n, n, t);
     FpOps::inv(n, n);
     r.c0 = fp_mul_call(a.c0, n);
