@@ -205,6 +205,8 @@ BH_HD void xyzz_to_affine(Affine<F> &r, const XYZZ<F> &p) {
   F::sqr(zi3, zi2);              // 1/Z^2 = 1/ZZ
   F::mul(r.x, p.x, zi3);
   (void)zi3;
+  F::canon(r.x);   // the curve code computes with lazily reduced values (ff.cuh): affine records are canonical
+  F::canon(r.y);
 }
 
 }  // namespace bh

@@ -212,7 +212,7 @@ BH_HD u32 fe_limb30(const Fe<P> &x, int i) {
 }
 
 // column-wise Montgomery reduction of the 2L product columns c[] + repack + final subtraction
-template <class P>
+template <class P, bool CANONICAL = true>
 BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
   typedef Radix30<P> R;
   constexpr int N = P::N, L = R::L;
@@ -252,10 +252,15 @@ BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
     }
   }
   if (wi < N) w[wi] = (u32)acc;
-  fe_reduce_once<P>(r, w);
+  if (CANONICAL) {
+    fe_reduce_once<P>(r, w);
+  } else {   // lazily reduced result (see the fpl_* helpers): < 1.5 m for operands < 2 m
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = w[i];
+  }
 }
 
-template <class P>
+template <class P, bool CANONICAL = true>
 BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
   typedef Radix30<P> R;
   constexpr int L = R::L;
@@ -274,7 +279,7 @@ BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
 #pragma unroll
     for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
   }
-  fe_mont_reduce30<P>(r, c);
+  fe_mont_reduce30<P, CANONICAL>(r, c);
 }
 
 // Also evaluated and rejected on the MI355X: the interleaved product-scanning form (retire each column
@@ -284,7 +289,7 @@ BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
 // Squaring: the product above is a * (b * 2^SHIFT); with SHIFT even the same scaling comes from
 // (a * 2^(SHIFT/2))^2, whose operands are equal - so the off-diagonal limb products are computed once and
 // doubled: L(L-1)/2 + L = 91 instead of 169 product mads for Fp (the reduction is unchanged).
-template <class P>
+template <class P, bool CANONICAL = true>
 BH_HD void fe_sqr(Fe<P> &r, const Fe<P> &a) {
   typedef Radix30<P> R;
   constexpr int L = R::L;
@@ -304,7 +309,7 @@ BH_HD void fe_sqr(Fe<P> &r, const Fe<P> &a) {
   for (int k = 0; k < 2 * L; k++) c[k] <<= 1;
 #pragma unroll
   for (int i = 0; i < L; i++) c[2 * i] += (u64)A[i] * A[i];        // column total < L * 2^60 < 2^64
-  fe_mont_reduce30<P>(r, c);
+  fe_mont_reduce30<P, CANONICAL>(r, c);
 }
 
 // canonical <-> Montgomery
@@ -344,6 +349,63 @@ BH_HD void fe_inv(Fe<P> &r, const Fe<P> &a) {  // a^(m-2); a != 0
 }
 
 // out-of-line Fp product used by all curve code (the FFT keeps its 8-limb Fr product inline)
+// ---------------------------------------------------------------------------------------
+// Lazily reduced Fp for the curve code.  All Fp values handled by FpOps / Fp2Ops live in [0, 2p):
+// the Montgomery product of two such values is < p (256 p / 2^390 + 1) < 1.5 p without its final
+// conditional subtraction (R = 2^390 is 2^9 times larger than p), so the products skip it; add / sub
+// keep the invariant with one conditional +-2p, exactly what the canonical versions spend on +-p.
+// Zero has two representatives (0 and p): is_zero / eq know both.  Values are made canonical where they
+// leave the curve code (xyzz_to_affine, the host tail of the MSM).
+// ---------------------------------------------------------------------------------------
+BH_HD constexpr u32 fp_mod2(int i) {   // limb i of 2p (< 2^382)
+  return (FpParams::mod(i) << 1) | (i ? FpParams::mod(i - 1) >> 31 : 0u);
+}
+BH_HD void fpl_add(fp_t &r, const fp_t &a, const fp_t &b) {   // a + b < 4p < 2^384
+  u32 t[12], d[12];
+  u32 c = 0, br = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) t[i] = addc(a.l[i], b.l[i], c, c);
+#pragma unroll
+  for (int i = 0; i < 12; i++) d[i] = subb(t[i], fp_mod2(i), br, br);
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = br ? t[i] : d[i];
+}
+BH_HD void fpl_sub(fp_t &r, const fp_t &a, const fp_t &b) {
+  u32 t[12];
+  u32 br = 0, c = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) t[i] = subb(a.l[i], b.l[i], br, br);
+  const u32 mask = 0u - br;
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = addc(t[i], fp_mod2(i) & mask, c, c);
+}
+BH_HD bool fpl_is_zero(const fp_t &a) {
+  u32 o = 0, q = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) { o |= a.l[i]; q |= a.l[i] ^ FpParams::mod(i); }
+  return o == 0 || q == 0;
+}
+BH_HD void fpl_neg(fp_t &r, const fp_t &a) {   // 2p - a, and -0 = 0 (a = 0 would give 2p)
+  const bool z = fe_is_zero(a);
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const u32 d = subb(fp_mod2(i), a.l[i], br, br);
+    r.l[i] = z ? 0u : d;
+  }
+}
+BH_HD void fpl_canon(fp_t &r, const fp_t &a) {   // [0, 2p) -> [0, p)
+  u32 t[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) t[i] = a.l[i];
+  fe_reduce_once<FpParams>(r, t);
+}
+BH_HD bool fpl_eq(const fp_t &a, const fp_t &b) {
+  fp_t d;
+  fpl_sub(d, a, b);
+  return fpl_is_zero(d);
+}
+
 // The operands travel as six 4-word vectors, not as two structs: clang's AMDGPU ABI passes at most 16
 // registers' worth of *aggregate* arguments directly, so the second 12-word struct of a (fp_t, fp_t)
 // signature went through scratch memory - a store/load round trip in front of every product that the
@@ -358,7 +420,7 @@ BH_NOINLINE_HD static fp_t fp_mul_vec(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u3
   b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w;
   b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w;
   b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w;
-  fe_mul(r, a, b);
+  fe_mul<FpParams, false>(r, a, b);   // lazily reduced
   return r;
 }
 BH_NOINLINE_HD static fp_t fp_sqr_vec(u32x4 a0, u32x4 a1, u32x4 a2) {
@@ -366,7 +428,7 @@ BH_NOINLINE_HD static fp_t fp_sqr_vec(u32x4 a0, u32x4 a1, u32x4 a2) {
   a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
   a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
   a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w;
-  fe_sqr(r, a);
+  fe_sqr<FpParams, false>(r, a);      // lazily reduced
   return r;
 }
 BH_HD fp_t fp_sqr_call(const fp_t &a) {
@@ -392,12 +454,13 @@ struct FpOps {
   static constexpr int WORDS = 12;
   BH_HD static void zero(T &r) { fe_zero(r); }
   BH_HD static void one(T &r) { fe_one(r); }
-  BH_HD static bool is_zero(const T &a) { return fe_is_zero(a); }
-  BH_HD static bool eq(const T &a, const T &b) { return fe_eq(a, b); }
-  BH_HD static void add(T &r, const T &a, const T &b) { fe_add(r, a, b); }
-  BH_HD static void sub(T &r, const T &a, const T &b) { fe_sub(r, a, b); }
-  BH_HD static void neg(T &r, const T &a) { fe_neg(r, a); }
-  BH_HD static void dbl(T &r, const T &a) { fe_add(r, a, a); }
+  BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a); }
+  BH_HD static bool eq(const T &a, const T &b) { return fpl_eq(a, b); }
+  BH_HD static void add(T &r, const T &a, const T &b) { fpl_add(r, a, b); }
+  BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub(r, a, b); }
+  BH_HD static void neg(T &r, const T &a) { fpl_neg(r, a); }
+  BH_HD static void dbl(T &r, const T &a) { fpl_add(r, a, a); }
+  BH_HD static void canon(T &r) { fpl_canon(r, r); }
   BH_HD static void mul(T &r, const T &a, const T &b) { r = fp_mul_call(a, b); }
   BH_HD static void sqr(T &r, const T &a) { r = fp_sqr_call(a); }
   BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
@@ -426,33 +489,34 @@ struct Fp2Ops {
   static constexpr int WORDS = 24;
   BH_HD static void zero(T &r) { fe_zero(r.c0); fe_zero(r.c1); }
   BH_HD static void one(T &r) { fe_one(r.c0); fe_zero(r.c1); }
-  BH_HD static bool is_zero(const T &a) { return fe_is_zero(a.c0) && fe_is_zero(a.c1); }
-  BH_HD static bool eq(const T &a, const T &b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
-  BH_HD static void add(T &r, const T &a, const T &b) { fe_add(r.c0, a.c0, b.c0); fe_add(r.c1, a.c1, b.c1); }
-  BH_HD static void sub(T &r, const T &a, const T &b) { fe_sub(r.c0, a.c0, b.c0); fe_sub(r.c1, a.c1, b.c1); }
-  BH_HD static void neg(T &r, const T &a) { fe_neg(r.c0, a.c0); fe_neg(r.c1, a.c1); }
+  BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a.c0) && fpl_is_zero(a.c1); }
+  BH_HD static bool eq(const T &a, const T &b) { return fpl_eq(a.c0, b.c0) && fpl_eq(a.c1, b.c1); }
+  BH_HD static void add(T &r, const T &a, const T &b) { fpl_add(r.c0, a.c0, b.c0); fpl_add(r.c1, a.c1, b.c1); }
+  BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub(r.c0, a.c0, b.c0); fpl_sub(r.c1, a.c1, b.c1); }
+  BH_HD static void neg(T &r, const T &a) { fpl_neg(r.c0, a.c0); fpl_neg(r.c1, a.c1); }
   BH_HD static void dbl(T &r, const T &a) { add(r, a, a); }
+  BH_HD static void canon(T &r) { fpl_canon(r.c0, r.c0); fpl_canon(r.c1, r.c1); }
   BH_HD static void mul(T &r, const T &a, const T &b) {
     // Karatsuba: 3 Fp products.  (Measured: making this an out-of-line by-value call passes 16 of the
     // 48 argument words through scratch and is 1.6x slower on the G2 accumulate kernel.)
     fp_t t0, t1, t2, t3;
     t0 = fp_mul_call(a.c0, b.c0);
     t1 = fp_mul_call(a.c1, b.c1);
-    fe_add(t2, a.c0, a.c1);
-    fe_add(t3, b.c0, b.c1);
+    fpl_add(t2, a.c0, a.c1);
+    fpl_add(t3, b.c0, b.c1);
     t2 = fp_mul_call(t2, t3);
-    fe_sub(t2, t2, t0);
-    fe_sub(r.c1, t2, t1);
-    fe_sub(r.c0, t0, t1);
+    fpl_sub(t2, t2, t0);
+    fpl_sub(r.c1, t2, t1);
+    fpl_sub(r.c0, t0, t1);
   }
   BH_HD static void sqr(T &r, const T &a) {
     // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp products
     fp_t s, d, p;
-    fe_add(s, a.c0, a.c1);
-    fe_sub(d, a.c0, a.c1);
+    fpl_add(s, a.c0, a.c1);
+    fpl_sub(d, a.c0, a.c1);
     p = fp_mul_call(a.c0, a.c1);
     r.c0 = fp_mul_call(s, d);
-    fe_add(r.c1, p, p);
+    fpl_add(r.c1, p, p);
   }
   BH_HD static void curve_b(T &r) {   // G2: y^2 = x^3 + 4(u + 1)
     FpOps::curve_b(r.c0);
@@ -462,11 +526,11 @@ struct Fp2Ops {
     fp_t n, t;
     n = fp_sqr_call(a.c0);
     t = fp_sqr_call(a.c1);
-    fe_add(n, n, t);
+    fpl_add(n, n, t);
     FpOps::inv(n, n);
     r.c0 = fp_mul_call(a.c0, n);
     t = fp_mul_call(a.c1, n);
-    fe_neg(r.c1, t);
+    fpl_neg(r.c1, t);
   }
 };
 

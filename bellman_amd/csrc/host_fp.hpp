@@ -124,6 +124,7 @@ struct HostFpOps {
   static void sub(T &r, const T &a, const T &b) { hostfp::sub(r, a, b); }
   static void neg(T &r, const T &a) { T z; zero(z); hostfp::sub(r, z, a); }
   static void dbl(T &r, const T &a) { hostfp::add(r, a, a); }
+  static void canon(T &) {}   // host values are always canonical
   static void mul(T &r, const T &a, const T &b) { hostfp::mul(r, a, b); }
   static void sqr(T &r, const T &a) { hostfp::mul(r, a, a); }
   static void inv(T &r, const T &a) { hostfp::inv(r, a); }
@@ -140,6 +141,7 @@ struct HostFp2Ops {
   static void sub(T &r, const T &a, const T &b) { B::sub(r.c0, a.c0, b.c0); B::sub(r.c1, a.c1, b.c1); }
   static void neg(T &r, const T &a) { B::neg(r.c0, a.c0); B::neg(r.c1, a.c1); }
   static void dbl(T &r, const T &a) { add(r, a, a); }
+  static void canon(T &) {}   // host values are always canonical
   static void mul(T &r, const T &a, const T &b) {
     hfp_t t0, t1, t2, t3;
     B::mul(t0, a.c0, b.c0);

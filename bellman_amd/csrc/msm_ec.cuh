@@ -524,7 +524,11 @@ template <class F>
 static void msm_host_tail(const MsmPlan &p, const XYZZ<F> *bits_dev_layout, void *out_dev_layout) {
   typedef typename HostOf<F>::type H;   // 64-bit-limb host arithmetic, identical record layout
   static_assert(sizeof(XYZZ<H>) == sizeof(XYZZ<F>) && sizeof(Affine<H>) == sizeof(Affine<F>), "layout");
-  const XYZZ<H> *bits = reinterpret_cast<const XYZZ<H> *>(bits_dev_layout);
+  // the device kernels hand over lazily reduced coordinates ([0, 2p), ff.cuh); the host arithmetic wants
+  // canonical ones
+  std::vector<XYZZ<F>> canon(bits_dev_layout, bits_dev_layout + (size_t)p.W * p.c);
+  for (XYZZ<F> &q : canon) { F::canon(q.x); F::canon(q.y); F::canon(q.zz); F::canon(q.zzz); }
+  const XYZZ<H> *bits = reinterpret_cast<const XYZZ<H> *>(canon.data());
   XYZZ<H> acc;
   xyzz_set_identity(acc);
   const u32 cb = p.c - 1;
