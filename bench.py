@@ -39,6 +39,9 @@ HBM_PEAK_GBPS = 8000.0
 BYTES_PER_TERM_G1 = 128  # 96 B affine base + 32 B scalar, each read once
 
 
+MADS_PER_MIXED_ADD = 8 * 351 + 2 * 273   # XYZZ madd: 8M + 2S; 13-limb radix-2^30 product/reduction, symmetric squaring
+
+
 def splitmix_scalars(n, seed):
     """Uniform-ish scalars < q: SplitMix64 limbs, top limb clamped below q's top limb."""
     idx = np.arange(n * 4, dtype=np.uint64) + np.uint64(seed)
@@ -473,9 +476,9 @@ def main():
                 # W*n mixed additions x 10 field products x 351 mads (ff.cuh); peak = 26.2 T mad/s measured
                 # on this chip (profiles/r1_microbench_int.txt).
                 "alu": {"unit": "Tmad/s", "peak": 26.2,
-                        "achieved": round(16 * n * 10 * 351 / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
-                        "frac": round(16 * n * 10 * 351 / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
-                        "work": "16 windows x n mixed additions x 10 Fp products x 351 v_mad_u64_u32"},
+                        "achieved": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
+                        "frac": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
+                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273) v_mad_u64_u32"},
             },
         }
         if not args.no_cpu_baseline and not distributed:   # rank 0 at N=1 only
