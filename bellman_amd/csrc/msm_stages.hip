@@ -227,7 +227,9 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   // sizes whose top window is not a sliver (256 = 32*8 = 16*16, 20*13 leaves 9 bits) avoid a
   // few huge buckets; larger c trades bucket-reduction work against accumulation passes.
   const u32 lg = ilog2(n ? n : 1);
-  int c = lg <= 13 ? 8 : lg <= 17 ? 13 : 16;
+  // re-swept after the field-arithmetic changes (profiles/r1_tune_small_sizes.txt, second table): the
+  // cheaper additions moved every boundary down by 2-3 powers of two
+  int c = g2 ? (lg <= 12 ? 8 : lg <= 15 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : 16);
   if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
