@@ -627,6 +627,26 @@ void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
 }
+int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b) {
+  // the lazily reduced Fp helpers of the curve code (ff.cuh), compiled for the host; operands in [0, 2p)
+  fp_t x, y, z;
+  memcpy(&x, a, sizeof x);
+  if (b) memcpy(&y, b, sizeof y); else fe_zero(y);
+  int flag = 0;
+  switch (op) {
+    case 0: fpl_add(z, x, y); break;
+    case 1: fpl_sub(z, x, y); break;
+    case 2: fpl_neg(z, x); break;
+    case 3: fpl_canon(z, x); break;
+    case 4: z = x; flag = fpl_is_zero(x) ? 1 : 0; break;
+    case 5: z = fp_mul_call(x, y); break;   // lazily reduced Montgomery product
+    case 6: z = fp_sqr_call(x); break;
+    case 7: z = x; flag = fpl_eq(x, y) ? 1 : 0; break;
+    default: return BH_ERR_INVALID_ARG;
+  }
+  memcpy(r, &z, sizeof z);
+  return flag;
+}
 void bh_test_fr_inv_host(void *r, const void *a, size_t n) {
   for (size_t i = 0; i < n; i++) fe_inv(((fr_t *)r)[i], ((const fr_t *)a)[i]);
 }

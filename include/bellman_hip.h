@@ -328,6 +328,9 @@ void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
 void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
+/* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
+ * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
+int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
 void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
 
 #ifdef __cplusplus

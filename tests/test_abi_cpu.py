@@ -171,3 +171,51 @@ def test_fr_wide_reduction_host():
         lib.bh_test_fr_from_u512_host(out.ctypes.data_as(ctypes.c_void_p), limbs.ctypes.data_as(ctypes.c_void_p))
         got = sum(int(x) << (64 * i) for i, x in enumerate(out))
         assert got == (v % q) * (1 << 256) % q
+
+
+def test_lazily_reduced_fp_helpers_host():
+    """The curve kernels keep Fp values in [0, 2p) (ff.cuh fpl_*): every helper must preserve the range,
+    agree with the integers mod p, and treat both representatives of zero (0 and p) as zero."""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    R = 1 << 384
+
+    def arr(v):
+        return np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(6)], dtype=np.uint64)
+
+    def val(a):
+        return sum(int(x) << (64 * i) for i, x in enumerate(a))
+
+    def call(op, a, b=None):
+        out = np.zeros(6, dtype=np.uint64)
+        xa, xb = arr(a), (arr(b) if b is not None else None)
+        flag = lib.bh_test_fp_lazy_host(op, out.ctypes.data_as(ctypes.c_void_p), xa.ctypes.data_as(ctypes.c_void_p),
+                                        xb.ctypes.data_as(ctypes.c_void_p) if xb is not None else None)
+        return val(out), flag
+
+    rnd = random.Random(11)
+    edge = [0, 1, p - 1, p, p + 1, 2 * p - 1]
+    vals = edge + [rnd.randrange(2 * p) for _ in range(40)]
+    for a in vals:
+        r, _ = call(2, a)
+        assert r < 2 * p and (r + a) % p == 0 and (a != 0 or r == 0)
+        r, _ = call(3, a)
+        assert r == a % p
+        assert call(4, a)[1] == (1 if a % p == 0 else 0)
+        r, _ = call(6, a)
+        assert r < 2 * p and (r * R - a * a) % p == 0          # Montgomery: a*a/R
+        for b in edge + [rnd.randrange(2 * p) for _ in range(6)]:
+            r, _ = call(0, a, b)
+            assert r < 2 * p and (r - a - b) % p == 0
+            r, _ = call(1, a, b)
+            assert r < 2 * p and (r - a + b) % p == 0
+            r, _ = call(5, a, b)
+            assert r < 2 * p and (r * R - a * b) % p == 0
+            assert call(7, a, b)[1] == (1 if (a - b) % p == 0 else 0)
