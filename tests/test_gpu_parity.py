@@ -5,6 +5,7 @@ against the KAT-pinned oracle/pyref).  Integer work => exact equality, no tolera
 Covers SURVEY.md Appendix A: MSM items 1-9, FFT/domain items 10-15."""
 
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -500,7 +501,7 @@ def test_fixed_base_mul(worker, group):
         assert np.array_equal(out[i], cref.point_mul(group, gen, ints[i])), i
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + int(os.environ.get("BH_FUZZ_EXTRA", "0"))))   # BH_FUZZ_EXTRA=n: n more seeds
 def test_msm_fuzz_random_shapes(worker, seed):
     """Randomised sweep over sizes, densities, skips, scalar mixes and the tuning knobs (c, K): chunk /
     bucket boundary handling (runs ending exactly on chunk borders, single-bucket chunks, long runs,
