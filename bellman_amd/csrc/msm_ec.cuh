@@ -489,6 +489,24 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
     SumJobs<F> js;
     js.j[0] = make_job(pts, rows, dr); js.j[1] = make_job(pts, cols, dc); js.j[2] = js.j[1]; js.j[2].nblocks = 0;
+    if (F::WORDS == 24) {
+      // G2 (one resident wavefront per SIMD, so sharing a SIMD doubles every step): the two jobs share one
+      // launch, choose their lane counts jointly - the launch lasts as long as its longest chain,
+      // stretched by how many wavefronts each SIMD has to interleave.  (Measured on G1, where two
+      // wavefronts per SIMD interleave almost for free, the per-job choice above is better.)
+      const double simds = (double)c.num_cus * 4;
+      double best = 1e30;
+      u32 best_r = js.j[0].d.lanes, best_c = js.j[1].d.lanes;
+      for (u32 gr = 1, lr = 0; gr <= 64 && gr <= std::max(1u, dr.count); gr <<= 1, lr++)
+        for (u32 gc = 1, lc = 0; gc <= 64 && gc <= std::max(1u, dc.count); gc <<= 1, lc++) {
+          const double steps = std::max((double)((dr.count + gr - 1) / gr) + lr, (double)((dc.count + gc - 1) / gc) + lc);
+          const double waves = ((double)dr.groups * gr + (double)dc.groups * gc) / 64.0;
+          const double cost = steps * std::max(1.0, waves / simds);
+          if (cost < best) { best = cost; best_r = gr; best_c = gc; }
+        }
+      js.j[0].d.lanes = best_r; js.j[0].nblocks = (u32)(((u64)dr.groups * best_r + 63) / 64);
+      js.j[1].d.lanes = best_c; js.j[1].nblocks = (u32)(((u64)dc.groups * best_c + 63) / 64);
+    }
     hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
     // sum_idx (idx+1) B[idx] = sum_p 2^p U[p] + T, idx = hi*2^l + lo:
