@@ -1067,6 +1067,29 @@ int bh_groth16_params_vk(const bh_params *p, void *alpha_g1, void *beta_g1, void
   if (delta_g2) memcpy(delta_g2, &vk.delta_g2, 192);
   return BH_OK;
 }
+double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode) {
+  // host-only timing of circuit synthesis (no device involved): mode 0 = ProvingAssignment (the
+  // reference's structure: every linear combination evaluated on the host), 1 = WitnessAssignment
+  using namespace groth16;
+  std::vector<Fr> constants(circuit_kind == 0 ? size : 0, Fr::from_u64(7));
+  Fr wit[2] = {Fr::from_u64(123456789), Fr::from_u64(987654321)};
+  double ms = -1.0;
+  with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &c) -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (mode == 0) {
+      ProvingAssignment pa;
+      pa.alloc_input([] { return Fr::one(); });
+      c.synthesize(pa);
+    } else {
+      WitnessAssignment w;
+      w.alloc_input([] { return Fr::one(); });
+      c.synthesize(w);
+    }
+    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+  });
+  return ms;
+}
 void bh_test_fr_from_u512_host(void *r, const void *limbs8) {
   uint64_t w[8];
   memcpy(w, limbs8, 64);

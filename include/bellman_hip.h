@@ -331,6 +331,9 @@ void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out
 /* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
  * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
 int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
+/* host-only: milliseconds to synthesise a demo circuit (kind/size/seed as bh_groth16_prove_demo) into a
+ * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); no device involved */
+double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
 void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
 
 #ifdef __cplusplus
