@@ -79,6 +79,25 @@ def main():
                           "toxic": toxic, "image": hx(circuits.mimc_hash(xl, xr, cons)),
                           "a": pt1(proof.a), "b": pt2(proof.b), "c": pt1(proof.c),
                           "proof_bytes_zcash": (bls.g1_compress(proof.a) + bls.g2_compress(proof.b) + bls.g1_compress(proof.c)).hex()}
+    # the same circuit's serialized Parameters (groth16/src/lib.rs:258-287) and the constraint
+    # evaluations / query densities the prover derives from the witness (prover.rs:19-55,105-145,208-215)
+    from oracle.pyref import params_io as pio
+    from oracle.pyref.core import INPUT, Variable
+    from oracle.pyref.prover import ProvingAssignment
+
+    vk = dict(alpha_g1=params.vk.alpha_g1, beta_g1=params.vk.beta_g1, beta_g2=params.vk.beta_g2, gamma_g2=params.vk.gamma_g2,
+              delta_g1=params.vk.delta_g1, delta_g2=params.vk.delta_g2, ic=list(params.vk.ic))
+    out["mimc3_proof"]["parameters_bytes"] = pio.parameters_write(vk, params.h, params.l, params.a, params.b_g1, params.b_g2).hex()
+    pa = ProvingAssignment(Q)
+    pa.alloc_input(lambda: 1)
+    circ(pa)
+    for i in range(len(pa.input_assignment)):
+        pa.enforce(lambda lc, i=i: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
+    out["mimc3_proof"]["assignment"] = {
+        "a": [hx(v) for v in pa.a], "b": [hx(v) for v in pa.b], "c": [hx(v) for v in pa.c],
+        "inputs": [hx(v) for v in pa.input_assignment], "aux": [hx(v) for v in pa.aux_assignment],
+        "a_aux_density": list(pa.a_aux_density.bv), "b_input_density": list(pa.b_input_density.bv),
+        "b_aux_density": list(pa.b_aux_density.bv)}
     json.dump(out, open(os.path.join(HERE, "bls12_381_small.json"), "w"), indent=1)
     # the reference's own KAT (groth16/src/tests/mod.rs:91-373), as data
     kat = {

@@ -71,3 +71,29 @@ def test_c_prover_matches_golden_proof():
                                        G1.to_array(p.a), G1.to_array(p.b_g1), G2.to_array(p.b_g2), r, s)
     assert cref.g1_to_py(a)[0] == g1(m["a"]) and cref.g2_to_py(b)[0] == g2(m["b"]) and cref.g1_to_py(c)[0] == g1(m["c"])
     assert len(bytes.fromhex(m["proof_bytes_zcash"])) == 192
+
+
+def test_golden_parameters_bytes_and_assignment():
+    """frozen Parameters::write bytes and ProvingAssignment of the 3-round MiMC fixture: the oracle's reader
+    accepts the bytes (checked), re-serialising gives them back, the C-engine generator reproduces them, and
+    the product's host-side R1CS capture evaluates to the frozen a/b/c and densities."""
+    from bellman_amd import groth16 as pg
+    from oracle.pyref import params_io as pio
+    from tests import circuits
+
+    m = G["mimc3_proof"]
+    blob = bytes.fromhex(m["parameters_bytes"])
+    got = pio.parameters_read(blob, True)
+    assert pio.parameters_write(got["vk"], got["h"], got["l"], got["a"], got["b_g1"], got["b_g2"]) == blob
+    ints = lambda xs: [int(x, 16) for x in xs]  # noqa: E731
+    cons, xl, xr = ints(m["constants"]), int(m["xl"], 16), int(m["xr"], 16)
+    cs = pg.ShapeAssembly.capture(circuits.mimc_circuit(0, 0, cons))
+    matrices, table = cs.csr()
+    w = ints(m["assignment"]["inputs"]) + ints(m["assignment"]["aux"])
+    wit = pg.WitnessAssignment()
+    wit.alloc_input(lambda: 1)
+    circuits.mimc_circuit(xl, xr, cons)(wit)
+    assert wit.input_assignment + wit.aux_assignment == w
+    for (row_ptr, var, coeff), name in zip(matrices, "abc"):
+        vals = [sum(table[coeff[t]] * w[var[t]] for t in range(row_ptr[i], row_ptr[i + 1])) % pg.Q for i in range(len(row_ptr) - 1)]
+        assert vals == ints(m["assignment"][name]), name

@@ -181,3 +181,22 @@ def test_golden_fixtures_on_device(worker):
         a, b, c = cref.g1_to_py(proof.a)[0], cref.g2_to_py(proof.b)[0], cref.g1_to_py(proof.c)[0]
         assert [hex(a[0]), hex(a[1])] == m["a"] and [hex(c[0]), hex(c[1])] == m["c"]
         assert [[hex(b[0][0]), hex(b[0][1])], [hex(b[1][0]), hex(b[1][1])]] == m["b"]
+        assert proof.write().hex() == m["proof_bytes_zcash"]                     # Proof::write
+    # the frozen Parameters::write bytes: device generator -> same bytes; reader (checked) -> same proof;
+    # device-resident R1CS -> the frozen a/b/c evaluations and densities
+    blob = bytes.fromhex(m["parameters_bytes"])
+    r1cs = pg.R1CS.from_circuit(worker, circuits.mimc_circuit(0, 0, cons))
+    gen = pg.Parameters.generate(worker, r1cs, np.frombuffer(bytes(CBls12.G1.gen), dtype=np.uint64), np.frombuffer(bytes(CBls12.G2.gen), dtype=np.uint64),
+                                 *[m["toxic"][k] for k in ("alpha", "beta", "gamma", "delta", "tau")])
+    assert gen.write() == blob
+    rd = pg.Parameters.read(worker, blob, True)
+    assert rd.write() == blob
+    proof = pg.create_proof_r1cs(circuits.mimc_circuit(xl, xr, cons), r1cs, rd, r, s)
+    assert proof.write().hex() == m["proof_bytes_zcash"]
+    asg = m["assignment"]
+    ev = r1cs.eval(ints(asg["inputs"]), ints(asg["aux"]))
+    n_cons = len(asg["a"])
+    for arr, name in zip(ev, "abc"):
+        assert cref.arr_to_ints(cref.fr_from_mont(arr[:n_cons])) == ints(asg[name]), name
+    for which, name in enumerate(("a_aux_density", "b_input_density", "b_aux_density")):
+        assert list(r1cs.density(which)[0]) == asg[name], name
