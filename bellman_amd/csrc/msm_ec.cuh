@@ -516,10 +516,14 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     bl.mode = SUM_BITS; bl.stride = 1; bl.istride = 0;
     bl.groups = p.W * p.lo_bits; bl.count = Lw; bl.inner = std::max(1u, p.lo_bits); bl.group_shift = p.lo_bits;
     bh_ = bl; bh_.groups = p.W * p.hi_bits; bh_.count = H; bh_.inner = std::max(1u, p.hi_bits); bh_.group_shift = p.hi_bits;
-    bt.mode = SUM_STRIDED; bt.groups = p.W; bt.count = H; bt.inner = 1; bt.stride = 1; bt.istride = 0; bt.group_shift = p.hi_bits;
+    // the plain total is the sum of the column sums as well as of the row sums: take the shorter vector
+    // (this job is the longest chain of the launch)
+    const bool t_from_cols = Lw < H;
+    bt.mode = SUM_STRIDED; bt.groups = p.W; bt.count = t_from_cols ? Lw : H; bt.inner = 1; bt.stride = 1; bt.istride = 0;
+    bt.group_shift = t_from_cols ? p.lo_bits : p.hi_bits;
     js.j[0] = make_job(cols, bits, bl);
     js.j[1] = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
-    js.j[2] = make_job(rows, bits + (u64)p.W * cb, bt);
+    js.j[2] = make_job(t_from_cols ? cols : rows, bits + (u64)p.W * cb, bt);
     hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
   }
