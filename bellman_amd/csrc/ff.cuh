@@ -379,6 +379,44 @@ BH_HD void fpl_sub(fp_t &r, const fp_t &a, const fp_t &b) {
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = addc(t[i], fp_mod2(i) & mask, c, c);
 }
+// Two independent additions / subtractions with their limb operations interleaved: consecutive
+// instructions then belong to different carry chains (one carry in VCC, the other in an SGPR pair), which
+// removes the wait states a single v_addc/v_subb chain needs between dependent limbs.  Fp2 add/sub are
+// exactly such pairs.
+BH_HD void fpl_sub2(fp_t &r0, const fp_t &a0, const fp_t &b0, fp_t &r1, const fp_t &a1, const fp_t &b1) {
+  u32 t0[12], t1[12];
+  u32 br0 = 0, br1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    t0[i] = subb(a0.l[i], b0.l[i], br0, br0);
+    t1[i] = subb(a1.l[i], b1.l[i], br1, br1);
+  }
+  const u32 m0 = 0u - br0, m1 = 0u - br1;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    r0.l[i] = addc(t0[i], fp_mod2(i) & m0, c0, c0);
+    r1.l[i] = addc(t1[i], fp_mod2(i) & m1, c1, c1);
+  }
+}
+BH_HD void fpl_add2(fp_t &r0, const fp_t &a0, const fp_t &b0, fp_t &r1, const fp_t &a1, const fp_t &b1) {
+  u32 t0[12], t1[12], d0[12], d1[12];
+  u32 c0 = 0, c1 = 0, br0 = 0, br1 = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    t0[i] = addc(a0.l[i], b0.l[i], c0, c0);
+    t1[i] = addc(a1.l[i], b1.l[i], c1, c1);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    d0[i] = subb(t0[i], fp_mod2(i), br0, br0);
+    d1[i] = subb(t1[i], fp_mod2(i), br1, br1);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    r0.l[i] = br0 ? t0[i] : d0[i];
+    r1.l[i] = br1 ? t1[i] : d1[i];
+  }
+}
 BH_HD bool fpl_is_zero(const fp_t &a) {
   u32 o = 0, q = 0;
 #pragma unroll
@@ -491,8 +529,8 @@ struct Fp2Ops {
   BH_HD static void one(T &r) { fe_one(r.c0); fe_zero(r.c1); }
   BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a.c0) && fpl_is_zero(a.c1); }
   BH_HD static bool eq(const T &a, const T &b) { return fpl_eq(a.c0, b.c0) && fpl_eq(a.c1, b.c1); }
-  BH_HD static void add(T &r, const T &a, const T &b) { fpl_add(r.c0, a.c0, b.c0); fpl_add(r.c1, a.c1, b.c1); }
-  BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub(r.c0, a.c0, b.c0); fpl_sub(r.c1, a.c1, b.c1); }
+  BH_HD static void add(T &r, const T &a, const T &b) { fpl_add2(r.c0, a.c0, b.c0, r.c1, a.c1, b.c1); }
+  BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub2(r.c0, a.c0, b.c0, r.c1, a.c1, b.c1); }
   BH_HD static void neg(T &r, const T &a) { fpl_neg(r.c0, a.c0); fpl_neg(r.c1, a.c1); }
   BH_HD static void dbl(T &r, const T &a) { add(r, a, a); }
   BH_HD static void canon(T &r) { fpl_canon(r.c0, r.c0); fpl_canon(r.c1, r.c1); }
