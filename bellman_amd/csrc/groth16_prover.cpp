@@ -1,0 +1,453 @@
+// groth16::create_proof and friends: linear-combination evaluation during synthesis, the eight
+// multiexps + h block on the device, proof assembly, the R1CS capture and the witness-only path.
+// Reference map in groth16.hpp.
+#include <string.h>
+
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include "groth16_internal.hpp"
+
+namespace groth16 {
+using namespace bellman;
+using namespace detail;
+
+// ---- prover.rs:19-55 ------------------------------------------------------------------------------
+static Fr eval(const LinearCombination &lc, DensityTracker *input_density, DensityTracker *aux_density,
+               const std::vector<Fr> &input_assignment, const std::vector<Fr> &aux_assignment) {
+  Fr acc = Fr::zero();
+  const Fr one = Fr::one();
+  for (size_t t = 0; t < lc.size(); t++) {
+    const Variable &var = lc[t].first;
+    const Fr &coeff = lc[t].second;
+    if (coeff.is_zero()) continue;          // zero coefficients count for neither value nor density (:31)
+    Fr tmp;
+    if (var.kind == Index::Input) {
+      tmp = input_assignment[var.idx];
+      if (input_density) input_density->inc(var.idx);
+    } else {
+      tmp = aux_assignment[var.idx];
+      if (aux_density) aux_density->inc(var.idx);
+    }
+    if (tmp == one) tmp = coeff;            // 1 * coeff (the ubiquitous `(c, CS::one())` terms)
+    else if (coeff != one) tmp = tmp * coeff;
+    acc = acc + tmp;
+  }
+  return acc;
+}
+
+// ---- prover.rs:73-162 -----------------------------------------------------------------------------
+Variable ProvingAssignment::alloc(ValueFn f) {
+  aux_assignment.push_back(f());
+  a_aux_density.add_element();
+  b_aux_density.add_element();
+  return Variable::new_unchecked(Index::Aux, aux_assignment.size() - 1);
+}
+Variable ProvingAssignment::alloc_input(ValueFn f) {
+  input_assignment.push_back(f());
+  b_input_density.add_element();
+  return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
+}
+void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
+  const LinearCombination la = fa(LinearCombination::zero()), lb = fb(LinearCombination::zero()),
+                          lc = fc(LinearCombination::zero());
+  // inputs have full density in the A query; there is no C query (prover.rs:119-141)
+  a.push_back(eval(la, nullptr, &a_aux_density, input_assignment, aux_assignment));
+  b.push_back(eval(lb, &b_input_density, &b_aux_density, input_assignment, aux_assignment));
+  c.push_back(eval(lc, nullptr, nullptr, input_assignment, aux_assignment));
+}
+
+namespace {
+struct ProofStream {   // uploads + h block of one proof; independent of other proofs in flight
+  bh_ctx *ctx;
+  void *st = nullptr;
+  explicit ProofStream(bh_ctx *c) : ctx(c) { check(bh_stream_create(ctx, &st)); }
+  ~ProofStream() { if (st) { (void)bh_stream_synchronize(ctx, st); (void)bh_stream_destroy(ctx, st); } }
+  ProofStream(const ProofStream &) = delete;
+};
+// Every issued multiexp owns device buffers and reads ours: if anything throws between issue and
+// wait, the jobs still in flight are drained before the DevBufs they read are released.
+struct JobSet {
+  std::vector<bh_msm_job **> slots;
+  void track(bh_msm_job **j) { slots.push_back(j); }
+  int wait(bh_msm_job *&j, void *out) {
+    bh_msm_job *job = j;
+    j = nullptr;
+    return bh_msm_wait(job, out);
+  }
+  ~JobSet() {
+    unsigned char sink[192];
+    for (bh_msm_job **s : slots)
+      if (*s) { (void)bh_msm_wait(*s, sink); *s = nullptr; }
+  }
+};
+template <class A> A add_pts(int group, const A &x, const A &y) { A r; bh_point_add(group, &r, &x, &y, 1); return r; }
+template <class A> A mul_pt(int group, const A &x, const Fr &k) {
+  uint64_t kc[4];
+  k.to_canonical(kc);
+  A r;
+  bh_point_mul(group, &r, &x, kc);
+  return r;
+}
+}  // namespace
+
+// ---- prover.rs:217-360 ----------------------------------------------------------------------------
+namespace {
+// What differs between the two ways of getting the constraint evaluations into HBM
+struct AssignmentSource {
+  const Fr *inputs; size_t n_in;
+  const Fr *aux; size_t n_aux;
+  size_t n_cons;
+  // host path (prove_assignment): evaluations and density bitmaps computed during synthesis
+  const ProvingAssignment *host = nullptr;
+  // device path (prove_witness): matrices and densities already resident
+  const R1cs *r1cs = nullptr;
+};
+}  // namespace
+
+namespace {
+// The slice of an n-term multiexp that part `k` of `parts` computes when one proof is spread over
+// several GPUs: contiguous in the scalar index, cut at multiples of 64 so that the
+// density bitmap of the slice starts on a word.  parts = 1 gives [0, n).
+struct Slice { size_t lo, hi; };
+Slice slice_of(size_t n, size_t part, size_t parts) {
+  auto cut = [&](size_t k) {
+    if (k >= parts) return n;
+    const size_t c = (size_t)((unsigned __int128)n * k / parts) & ~size_t(63);
+    return c < n ? c : n;
+  };
+  return Slice{cut(part), cut(part + 1)};
+}
+size_t popcount_prefix(const uint64_t *words, size_t bits) {   // bits is a multiple of 64
+  size_t t = 0;
+  for (size_t w = 0; w < bits / 64; w++) t += (size_t)__builtin_popcountll(words[w]);
+  return t;
+}
+}  // namespace
+
+// prover.rs:217-318 + the waits of :339-354: the eight multiexp results (of this part's slices)
+static void msm_sums(const AssignmentSource &src, Parameters &params, size_t part, size_t parts, MsmSums &out,
+                     ProveTimings *tm) {
+  bh_ctx *ctx = params.ctx;
+  const double t0 = now_ms();
+  const size_t n_cons = src.n_cons;
+  // EvaluationDomain::from_coeffs (domain.rs:47-79)
+  uint32_t log_m = 0;
+  size_t m = 1;
+  while (m < n_cons) {
+    m *= 2;
+    log_m++;
+    if (log_m >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
+  }
+  // assignments: uploaded once, shared by seven multiexps (prover.rs:248-318)
+  const size_t n_in = src.n_in, n_aux = src.n_aux;
+  DevBuf d_in(ctx, n_in * 32 + 32), d_aux(ctx, n_aux * 32 + 32);
+  ProofStream ps(ctx);
+  check(bh_dev_upload_on(ctx, d_in.p, src.inputs, n_in * 32, ps.st));
+  if (n_aux) check(bh_dev_upload_on(ctx, d_aux.p, src.aux, n_aux * 32, ps.st));
+  std::unique_ptr<DevBuf> dens_buf[3];
+  const uint64_t *dens_a_aux = nullptr, *dens_b_in = nullptr, *dens_b_aux = nullptr;
+  const uint64_t *hw_a_aux = nullptr, *hw_b_in = nullptr, *hw_b_aux = nullptr;   // the same bitmaps on the host
+  size_t b_in_total = 0;
+  if (src.host) {
+    auto upload_density = [&](const DensityTracker &d, std::unique_ptr<DevBuf> &buf) {
+      const size_t nw = (d.get_query_size() + 63) / 64;
+      buf.reset(new DevBuf(ctx, nw * 8 + 8));
+      if (nw) check(bh_dev_upload_on(ctx, buf->p, d.words(), nw * 8, ps.st));
+      return (const uint64_t *)buf->p;
+    };
+    dens_a_aux = upload_density(src.host->a_aux_density, dens_buf[0]);
+    dens_b_in = upload_density(src.host->b_input_density, dens_buf[1]);
+    dens_b_aux = upload_density(src.host->b_aux_density, dens_buf[2]);
+    b_in_total = src.host->b_input_density.get_total_density();
+    hw_a_aux = src.host->a_aux_density.words(); hw_b_in = src.host->b_input_density.words();
+    hw_b_aux = src.host->b_aux_density.words();
+  } else {
+    check(bh_r1cs_density(src.r1cs->handle, 0, &dens_a_aux, &hw_a_aux, nullptr));
+    check(bh_r1cs_density(src.r1cs->handle, 1, &dens_b_in, &hw_b_in, &b_in_total));
+    check(bh_r1cs_density(src.r1cs->handle, 2, &dens_b_aux, &hw_b_aux, nullptr));
+  }
+
+  BH_TRACE("prove_core start: uploads queued");
+  check(bh_stream_synchronize(ctx, ps.st));   // the multiexp jobs run on their own streams
+  BH_TRACE("assignment resident");
+  bh_msm_job *l_job = nullptr, *a_in_job = nullptr, *a_aux_job = nullptr, *b1_in_job = nullptr, *b1_aux_job = nullptr,
+             *b2_in_job = nullptr, *b2_aux_job = nullptr, *h_job = nullptr;
+  // h-block buffers are declared here so that `jobs` (declared after every buffer a job reads) is
+  // destroyed first and drains whatever is still in flight if an exception unwinds this frame
+  DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
+  JobSet jobs;
+  for (bh_msm_job **j : {&l_job, &a_in_job, &a_aux_job, &b1_in_job, &b1_aux_job, &b2_in_job, &b2_aux_job, &h_job}) jobs.track(j);
+  // one multiexp over this part's slice of the scalars: `skip` advances by the number of bases the
+  // skipped scalars would have consumed (all of them without a density map, the set bits with one)
+  auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
+                   const uint64_t *dens_host, bh_msm_job **job) {
+    const Slice sl = slice_of(n, part, parts);
+    const size_t base_skip = skip + (dens_dev ? popcount_prefix(dens_host, sl.lo) : sl.lo);
+    check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
+                           dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
+  };
+  issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
+  // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
+  issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job);
+  issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
+  // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
+  issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job);
+  issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
+  issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job);
+  issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
+
+  // The seven multiexps above only need the assignments, so they are already running on their own
+  // streams while the h block below uploads a/b/c and runs its FFTs (the reference issues h first,
+  // prover.rs:221-245; the order of issue is unobservable, the order of waits is kept).
+  // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
+  // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
+  if (src.host) {
+    // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
+    const std::vector<Fr> *ev[3] = {&src.host->a, &src.host->b, &src.host->c};
+    void *dst[3] = {da.p, db.p, dc.p};
+    for (int i = 0; i < 3; i++) {
+      if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
+      check(bh_dev_upload_on(ctx, dst[i], ev[i]->data(), n_cons * 32, ps.st));
+    }
+  } else {
+    // a = A.w, b = B.w, c = C.w straight into the FFT buffers (prover.rs:19-55,105-145 on the device)
+    check(bh_r1cs_eval_dev(ctx, src.r1cs->handle, d_in.p, d_aux.p, da.p, db.p, dc.p, log_m, ps.st));
+  }
+  BH_TRACE("7 multiexps issued; n_cons=%zu m=%zu a/b/c queued", n_cons, m);
+  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, ps.st));   // synchronises ps.st before returning
+  BH_TRACE("h poly done");
+  const double t1 = now_ms();
+  issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
+
+  BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
+  // every job must be waited on (it owns device resources), even when an earlier one fails
+  int rcs[8];
+  // prover.rs:339-354 waits in this order: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
+  rcs[0] = jobs.wait(a_in_job, &out.a_in);
+  rcs[1] = jobs.wait(a_aux_job, &out.a_aux);
+  rcs[2] = jobs.wait(b1_in_job, &out.b1_in);
+  rcs[3] = jobs.wait(b1_aux_job, &out.b1_aux);
+  rcs[4] = jobs.wait(b2_in_job, &out.b2_in);
+  rcs[5] = jobs.wait(b2_aux_job, &out.b2_aux);
+  rcs[6] = jobs.wait(h_job, &out.h);
+  rcs[7] = jobs.wait(l_job, &out.l);
+  const double t2 = now_ms();
+  BH_TRACE("waits done rc=%d %d %d %d %d %d %d %d", rcs[0], rcs[1], rcs[2], rcs[3], rcs[4], rcs[5], rcs[6], rcs[7]);
+  if (params.vk.delta_g1.is_identity() || params.vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
+  for (int i = 0; i < 8; i++) check(rcs[i]);                      // first failing `?` in wait order
+  if (tm) {
+    tm->h_poly_ms = (float)(t1 - t0);
+    tm->msm_ms = (float)(t2 - t1);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+}
+
+// prover.rs:326-360 from the eight multiexp results
+Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, const Fr &s) {
+  const VerifyingKey &vk = params.vk;
+  if (vk.delta_g1.is_identity() || vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
+  G1Affine g_a = add_pts(BH_G1, mul_pt(BH_G1, vk.delta_g1, r), vk.alpha_g1);   // :326-327
+  G2Affine g_b = add_pts(BH_G2, mul_pt(BH_G2, vk.delta_g2, s), vk.beta_g2);    // :328-329
+  const Fr rs = r * s;
+  G1Affine g_c = mul_pt(BH_G1, vk.delta_g1, rs);                                // :331-338
+  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.alpha_g1, s));
+  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.beta_g1, r));
+  G1Affine a_answer = add_pts(BH_G1, m.a_in, m.a_aux);                          // :339-343
+  g_a = add_pts(BH_G1, g_a, a_answer);
+  a_answer = mul_pt(BH_G1, a_answer, s);
+  g_c = add_pts(BH_G1, g_c, a_answer);
+  G1Affine b1_answer = add_pts(BH_G1, m.b1_in, m.b1_aux);                       // :345-354
+  G2Affine b2_answer = add_pts(BH_G2, m.b2_in, m.b2_aux);
+  g_b = add_pts(BH_G2, g_b, b2_answer);
+  b1_answer = mul_pt(BH_G1, b1_answer, r);
+  g_c = add_pts(BH_G1, g_c, b1_answer);
+  g_c = add_pts(BH_G1, g_c, m.h);
+  g_c = add_pts(BH_G1, g_c, m.l);
+  Proof p;
+  p.a = g_a; p.b = g_b; p.c = g_c;
+  return p;
+}
+
+void MsmSums::add(const MsmSums &o) {
+  a_in = add_pts(BH_G1, a_in, o.a_in); a_aux = add_pts(BH_G1, a_aux, o.a_aux);
+  b1_in = add_pts(BH_G1, b1_in, o.b1_in); b1_aux = add_pts(BH_G1, b1_aux, o.b1_aux);
+  b2_in = add_pts(BH_G2, b2_in, o.b2_in); b2_aux = add_pts(BH_G2, b2_aux, o.b2_aux);
+  h = add_pts(BH_G1, h, o.h); l = add_pts(BH_G1, l, o.l);
+}
+
+static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  MsmSums sums;
+  msm_sums(src, params, 0, 1, sums, tm);
+  Proof p = assemble_proof(params, sums, r, s);
+  if (tm) tm->total_ms = (float)(now_ms() - t0);
+  return p;
+}
+
+MsmSums prove_witness_part(const R1cs &r1cs, Parameters &params, const Fr *inputs, size_t n_inputs, const Fr *aux, size_t n_aux,
+                           size_t part, size_t parts, ProveTimings *tm) {
+  if (n_inputs != r1cs.num_inputs || n_aux != r1cs.num_aux || parts == 0 || part >= parts)
+    throw std::invalid_argument("witness does not have the shape of the captured circuit / bad part");
+  AssignmentSource src;
+  src.inputs = inputs; src.n_in = n_inputs;
+  src.aux = aux; src.n_aux = n_aux;
+  src.n_cons = r1cs.num_constraints;
+  src.r1cs = &r1cs;
+  MsmSums sums;
+  msm_sums(src, params, part, parts, sums, tm);
+  return sums;
+}
+
+Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  AssignmentSource src;
+  src.inputs = prover.input_assignment.data(); src.n_in = prover.input_assignment.size();
+  src.aux = prover.aux_assignment.data(); src.n_aux = prover.aux_assignment.size();
+  src.n_cons = prover.a.size();
+  src.host = &prover;
+  return prove_core(src, params, r, s, tm);
+}
+
+Proof prove_witness(const R1cs &r1cs, Parameters &params, const Fr *inputs, size_t n_inputs, const Fr *aux, size_t n_aux,
+                    const Fr &r, const Fr &s, ProveTimings *tm) {
+  if (n_inputs != r1cs.num_inputs || n_aux != r1cs.num_aux)
+    throw std::invalid_argument("witness does not have the shape of the captured circuit");
+  AssignmentSource src;
+  src.inputs = inputs; src.n_in = n_inputs;
+  src.aux = aux; src.n_aux = n_aux;
+  src.n_cons = r1cs.num_constraints;
+  src.r1cs = &r1cs;
+  return prove_core(src, params, r, s, tm);
+}
+
+// ---- structure capture (generator.rs:43-131 KeypairAssembly, plus the input rows of prover.rs:208-215)
+namespace {
+struct FrHash {
+  size_t operator()(const Fr &f) const {
+    uint64_t h = f.l[0] * 0x9E3779B97F4A7C15ULL;
+    h ^= f.l[1] + 0xBF58476D1CE4E5B9ULL + (h << 6) + (h >> 2);
+    h ^= f.l[2] + 0x94D049BB133111EBULL + (h << 6) + (h >> 2);
+    h ^= f.l[3] + (h << 6) + (h >> 2);
+    return (size_t)h;
+  }
+};
+class ShapeAssembly : public ConstraintSystem {
+ public:
+  size_t num_inputs = 0, num_aux = 0;
+  struct Term { Index kind; uint32_t idx, coeff; };
+  std::vector<uint32_t> row_ptr[3];
+  std::vector<Term> terms[3];
+  std::vector<Fr> coeffs;
+  std::unordered_map<Fr, uint32_t, FrHash> coeff_index;
+  ShapeAssembly() {
+    coeffs.push_back(Fr::one());
+    coeff_index.emplace(Fr::one(), 0);
+    for (auto &rp : row_ptr) rp.push_back(0);
+  }
+  Variable alloc(ValueFn) override { return Variable::new_unchecked(Index::Aux, num_aux++); }
+  Variable alloc_input(ValueFn) override { return Variable::new_unchecked(Index::Input, num_inputs++); }
+  void enforce(LcFn fa, LcFn fb, LcFn fc) override {
+    const LinearCombination lcs[3] = {fa(LinearCombination::zero()), fb(LinearCombination::zero()),
+                                      fc(LinearCombination::zero())};
+    for (int m = 0; m < 3; m++) {
+      for (size_t i = 0; i < lcs[m].size(); i++) {
+        const Variable &v = lcs[m][i].first;
+        const Fr &k = lcs[m][i].second;
+        if (k.is_zero()) continue;   // prover.rs:31: no value, no density
+        auto it = coeff_index.find(k);
+        uint32_t ci;
+        if (it == coeff_index.end()) {
+          ci = (uint32_t)coeffs.size();
+          coeffs.push_back(k);
+          coeff_index.emplace(k, ci);
+        } else {
+          ci = it->second;
+        }
+        terms[m].push_back(Term{v.kind, (uint32_t)v.idx, ci});
+      }
+      row_ptr[m].push_back((uint32_t)terms[m].size());
+    }
+  }
+};
+}  // namespace
+
+R1cs::R1cs(Circuit &shape_of, bh_ctx *ctx) {
+  ShapeAssembly cs;
+  cs.alloc_input([] { return Fr::one(); });
+  shape_of.synthesize(cs);
+  for (size_t i = 0; i < cs.num_inputs; i++) {
+    cs.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+               [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+  }
+  num_inputs = cs.num_inputs; num_aux = cs.num_aux; num_constraints = cs.row_ptr[0].size() - 1;
+  std::vector<uint32_t> var[3], coeff[3];
+  bh_csr abc[3];
+  for (int m = 0; m < 3; m++) {
+    var[m].reserve(cs.terms[m].size()); coeff[m].reserve(cs.terms[m].size());
+    for (const auto &t : cs.terms[m]) {
+      var[m].push_back(t.kind == Index::Input ? t.idx : (uint32_t)(num_inputs + t.idx));   // inputs first, then aux
+      coeff[m].push_back(t.coeff);
+    }
+    abc[m] = bh_csr{cs.row_ptr[m].data(), var[m].data(), coeff[m].data()};
+  }
+  check(bh_r1cs_create(ctx, num_inputs, num_aux, num_constraints, abc, cs.coeffs.data(), cs.coeffs.size(), &handle));
+}
+R1cs::R1cs(bh_r1cs *existing) : handle(existing) {
+  check(bh_r1cs_shape(existing, &num_inputs, &num_aux, &num_constraints));
+}
+R1cs::~R1cs() { bh_r1cs_release(handle); }
+
+Variable WitnessAssignment::alloc(ValueFn f) {
+  aux_assignment.push_back(f());
+  return Variable::new_unchecked(Index::Aux, aux_assignment.size() - 1);
+}
+Variable WitnessAssignment::alloc_input(ValueFn f) {
+  input_assignment.push_back(f());
+  return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
+}
+
+Proof create_proof(Circuit &circuit, const R1cs &r1cs, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  WitnessAssignment w;
+  w.input_assignment.reserve(r1cs.num_inputs);
+  w.aux_assignment.reserve(r1cs.num_aux);
+  w.alloc_input([] { return Fr::one(); });
+  circuit.synthesize(w);
+  const double t1 = now_ms();
+  ProveTimings local;
+  Proof p = prove_witness(r1cs, params, w.input_assignment.data(), w.input_assignment.size(), w.aux_assignment.data(),
+                          w.aux_assignment.size(), r, s, &local);
+  if (tm) {
+    *tm = local;
+    tm->synthesis_ms = (float)(t1 - t0);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+  return p;
+}
+
+// ---- prover.rs:182-215 ----------------------------------------------------------------------------
+Proof create_proof(Circuit &circuit, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  const double t0 = now_ms();
+  ProvingAssignment prover;
+  prover.alloc_input([] { return Fr::one(); });
+  circuit.synthesize(prover);
+  for (size_t i = 0; i < prover.input_assignment.size(); i++) {
+    prover.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+                   [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+  }
+  const double t1 = now_ms();
+  BH_TRACE("synthesised: %zu constraints", prover.a.size());
+  ProveTimings local;
+  Proof p = prove_assignment(prover, params, r, s, &local);
+  if (tm) {
+    *tm = local;
+    tm->synthesis_ms = (float)(t1 - t0);
+    tm->total_ms = (float)(now_ms() - t0);
+  }
+  return p;
+}
+
+}  // namespace groth16

@@ -283,7 +283,7 @@ def create_random_proof(circuit, params, rng=None, r1cs=None):
 
 
 def create_proof_demo(params, kind, size, seed, witness, constants, r, s, timings=None):
-    """create_proof on one of the C++ demo circuits (groth16.cpp): 0 = MiMCDemo, 1 = chain."""
+    """create_proof on one of the C++ demo circuits (groth16_capi.cpp): 0 = MiMCDemo, 1 = chain."""
     lib = _lib.load()
     wit = fr_to_mont_array(list(witness))
     con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)

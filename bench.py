@@ -73,7 +73,7 @@ G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1
 
 def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     """BASELINE config C4: groth16::create_proof on a synthetic 2^log_n-constraint R1CS (the C++
-    chain circuit of groth16.cpp).  The CRS is a real one for this circuit, made by the product's
+    chain circuit of groth16_capi.cpp).  The CRS is a real one for this circuit, made by the product's
     device generator (generate_parameters, generator.rs:163-510) from fixed toxic waste - as the
     reference's own tests do (groth16/src/tests/mod.rs:93-99); not a secure setup."""
     from bellman_amd import groth16 as pg

@@ -1,6 +1,6 @@
 """Circuits used by the prover tests, written once against the ConstraintSystem interface shared by
 the oracle restatement (oracle/pyref/core.py) and the product's Python mirror (bellman_amd/groth16.py).
-The C++ versions of the same circuits live in bellman_amd/csrc/groth16.cpp."""
+The C++ versions of the same circuits live in bellman_amd/csrc/groth16_capi.cpp."""
 
 Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 MASK64 = (1 << 64) - 1
@@ -56,7 +56,7 @@ def chain_constants(rounds, seed):
 
 
 def chain_circuit(rounds, seed, x0):
-    """ChainCircuit::synthesize of groth16.cpp (synthetic R1CS of SURVEY.md 8d)."""
+    """ChainCircuit::synthesize of groth16_capi.cpp (synthetic R1CS of SURVEY.md 8d)."""
 
     def synth(cs):
         x_v = x0 % Q
