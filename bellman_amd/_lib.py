@@ -27,7 +27,7 @@ EXPORTS = [
     "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
-    "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
+    "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
 ]
 
 
@@ -70,6 +70,9 @@ def load():
     lib.bh_ctx_synchronize.argtypes = [vp]
     lib.bh_ctx_trim.argtypes = [vp]
     lib.bh_test_fp_lazy_host.argtypes = [i32, vp, vp, vp]
+    lib.bh_test_msm_plan.argtypes = [sz, i32, c.c_uint, vp]
+    lib.bh_test_proof_slice.argtypes = [sz, sz, sz, c.POINTER(sz), c.POINTER(sz)]
+    lib.bh_test_proof_slice.restype = None
     lib.bh_test_synthesis_ms.argtypes = [i32, sz, c.c_uint64, i32]
     lib.bh_test_synthesis_ms.restype = c.c_double
     lib.bh_fft_fr.argtypes = [vp, vp, u32, i32]

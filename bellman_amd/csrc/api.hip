@@ -627,6 +627,15 @@ void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
 }
+int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9) {
+  // host only: the plan make_plan picks - out9 = c, W, buckets per window, K, chunks per window, sort passes,
+  // lo_bits, hi_bits, pairs (W*n) low 32 bits
+  if (!out9 || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
+  const MsmPlan p = make_plan(n, forced_c, 0, group == BH_G2);
+  out9[0] = p.c; out9[1] = p.W; out9[2] = p.nb; out9[3] = p.chunk; out9[4] = p.chunks_per_window; out9[5] = p.sort_passes;
+  out9[6] = p.lo_bits; out9[7] = p.hi_bits; out9[8] = (unsigned)((u64)p.W * p.n);
+  return BH_OK;
+}
 int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b) {
   // the lazily reduced Fp helpers of the curve code (ff.cuh), compiled for the host; operands in [0, 2p)
   fp_t x, y, z;

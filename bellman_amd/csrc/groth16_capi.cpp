@@ -221,6 +221,9 @@ int bh_groth16_params_vk(const bh_params *p, void *alpha_g1, void *beta_g1, void
   if (delta_g2) memcpy(delta_g2, &vk.delta_g2, 192);
   return BH_OK;
 }
+void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi) {
+  groth16::proof_slice_for_tests(n, part, parts, lo, hi);
+}
 double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode) {
   // host-only timing of circuit synthesis (no device involved): mode 0 = ProvingAssignment (the
   // reference's structure: every linear combination evaluated on the host), 1 = WitnessAssignment

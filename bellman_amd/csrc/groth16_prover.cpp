@@ -126,6 +126,13 @@ size_t popcount_prefix(const uint64_t *words, size_t bits) {   // bits is a mult
 }
 }  // namespace
 
+// test hook (host only): the slice of an n-term multiexp part `part` of `parts` computes
+void proof_slice_for_tests(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi) {
+  const Slice sl = slice_of(n, part, parts);
+  *lo = sl.lo;
+  *hi = sl.hi;
+}
+
 // prover.rs:217-318 + the waits of :339-354: the eight multiexp results (of this part's slices)
 static void msm_sums(const AssignmentSource &src, Parameters &params, size_t part, size_t parts, MsmSums &out,
                      ProveTimings *tm) {

@@ -328,6 +328,11 @@ void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
 void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
+/* host only: the MSM plan for n terms (out9 = c, W, buckets per window, K, chunks per window, sort passes,
+ * lo_bits, hi_bits, low 32 bits of W*n) and the scalar-index slice [lo, hi) that part `part` of `parts`
+ * of a sharded proof computes */
+int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9);
+void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);
 /* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
  * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
 int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);

@@ -219,3 +219,49 @@ def test_lazily_reduced_fp_helpers_host():
             r, _ = call(5, a, b)
             assert r < 2 * p and (r * R - a * b) % p == 0
             assert call(7, a, b)[1] == (1 if (a - b) % p == 0 else 0)
+
+
+def test_msm_plan_invariants_host():
+    """make_plan (msm_stages.hip), host only: the windows cover 256 bits, signed digits need 2^(c-1) buckets,
+    the 2-D reduction splits the bucket index exactly, a typical bucket never spans many chunks."""
+    import ctypes
+
+    import numpy as np
+
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    out = np.zeros(9, dtype=np.uint32)
+    for group in (1, 2):
+        for lg in range(0, 27):
+            for n in {1 << lg, (1 << lg) + 1, max(1, (1 << lg) - 1)}:
+                for forced in (0, 2, 7, 13, 16, 24):
+                    assert lib.bh_test_msm_plan(n, group, forced, out.ctypes.data_as(ctypes.c_void_p)) == 0
+                    c_, W, nb, K, cpw, passes, lo, hi, pairs = (int(x) for x in out)
+                    assert 2 <= c_ <= 24 and (forced == 0 or c_ == forced)
+                    assert W == -(-256 // c_) and W * c_ >= 256 and nb == 1 << (c_ - 1)
+                    assert lo + hi == c_ - 1 and passes == -(-c_ // 8)
+                    assert K >= 1 and cpw == -(-n // K) and K >= (n >> (c_ - 1))
+                    assert pairs == (W * n) & 0xFFFFFFFF
+
+
+def test_proof_slices_partition_the_scalar_range_host():
+    """slice_of (groth16_prover.cpp), host only: the parts of a sharded proof tile [0, n) without gaps or
+    overlap and every interior cut is a multiple of 64 (so a density bitmap slice starts on a word)."""
+    import ctypes
+    import random
+
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    rnd = random.Random(5)
+    for n in [0, 1, 2, 63, 64, 65, 1000, (1 << 20) - 3, (1 << 24) + 17] + [rnd.randrange(1 << 26) for _ in range(20)]:
+        for parts in (1, 2, 3, 4, 7, 8, 64, 1000):
+            prev = 0
+            for part in range(parts):
+                lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+                lib.bh_test_proof_slice(n, part, parts, ctypes.byref(lo), ctypes.byref(hi))
+                assert lo.value == prev and lo.value <= hi.value <= n
+                assert hi.value % 64 == 0 or hi.value == n
+                prev = hi.value
+            assert prev == n
