@@ -290,6 +290,17 @@ def h_coeffs(a, b, c, threads=8):
     return a[:-1]
 
 
+def fr_dot(a, b, threads=0):
+    """sum_i a[i]*b[i] mod q (canonical [n,4] inputs) as a Python int - test helper for the MSM identity
+    sum_i s_i [t_i]G = [sum_i s_i t_i]G."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape == b.shape
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_fr_dot(_p(out), _p(a), _p(b), ctypes.c_size_t(a.shape[0]), ctypes.c_int(threads))
+    return limbs_to_int(out)
+
+
 def random_fr(n, seed, canonical_lt_q=True):
     """n pseudo-random values < q as [n,4] uint64 (top limb clamped below q's top limb)."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,142 @@
+"""Isolated workloads for rocprofv3 / hand timing on the MI355X (one workload per process so the kernel
+statistics of a run belong to exactly one configuration).
+
+  python tools/profile_suite.py msm <group 1|2> <log_n> [iters] [c] [K]   device-resident scalars, default plan
+  python tools/profile_suite.py fft <log_n> [iters]                       fft, ifft, coset_fft, icoset_fft
+  python tools/profile_suite.py mimc [iters]                              create_proof on MiMC-322 (config C1)
+  python tools/profile_suite.py sizes <group> <lo> <hi>                   per-stage device ms for 2^lo..2^hi
+
+Prints host-side timings; run it under `rocprofv3 --kernel-trace --stats` for the per-kernel view."""
+import ctypes
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bellman_amd  # noqa: E402
+from bellman_amd import _lib  # noqa: E402
+from bench import G1_GEN_MONT, G2_GEN_MONT, splitmix_scalars  # noqa: E402
+
+
+def make_bases(w, lib, group, n):
+    words = 12 if group == 1 else 24
+    t = splitmix_scalars(n, 1)
+    dt, dout = w.alloc(n * 32), w.alloc(n * 8 * words)
+    w.upload(dt, t)
+    gen = G1_GEN_MONT if group == 1 else G2_GEN_MONT
+    assert lib.bh_fixed_base_mul_dev(w.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+    w.synchronize()
+    w.free(dt)
+    return dout
+
+
+def run_msm(args):
+    group, log_n = int(args[0]), int(args[1])
+    iters = int(args[2]) if len(args) > 2 else 10
+    c = int(args[3]) if len(args) > 3 else 0
+    k = int(args[4]) if len(args) > 4 else 0
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    n = 1 << log_n
+    dout = make_bases(w, lib, group, n)
+    bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
+    s = splitmix_scalars(n, 2)
+    ds = w.alloc(n * 32)
+    w.upload(ds, s)
+    if c or k:
+        lib.bh_msm_set_window_bits(w.ctx, c)
+        lib.bh_msm_set_chunk(w.ctx, k)
+    walls, best = [], None
+    for it in range(iters + 2):
+        t0 = time.perf_counter()
+        r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
+        wall = (time.perf_counter() - t0) * 1e3
+        if it >= 2:
+            walls.append(wall)
+            if best is None or ms[0] < best[0]:
+                best = ms
+    walls.sort()
+    print("G%d MSM 2^%d c=%d K=%d: wall median %.3f ms (min %.3f); device best total %.3f = sort %.3f + accumulate %.3f + reduce %.3f" %
+          (group, log_n, c, k, walls[len(walls) // 2], walls[0], *best), flush=True)
+
+
+def run_sizes(args):
+    group, lo, hi = int(args[0]), int(args[1]), int(args[2])
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    nmax = 1 << hi
+    dout = make_bases(w, lib, group, nmax)
+    s = splitmix_scalars(nmax, 2)
+    ds = w.alloc(nmax * 32)
+    w.upload(ds, s)
+    for log_n in range(lo, hi + 1):
+        n = 1 << log_n
+        bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
+        best, walls = None, []
+        for it in range(7):
+            t0 = time.perf_counter()
+            r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
+            walls.append((time.perf_counter() - t0) * 1e3)
+            if it and (best is None or ms[0] < best[0]):
+                best = ms
+        walls = sorted(walls[1:])
+        print("G%d log_n=%d  wall median %.3f ms  device total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" %
+              (group, log_n, walls[len(walls) // 2], *best), flush=True)
+
+
+def run_fft(args):
+    log_n = int(args[0])
+    iters = int(args[1]) if len(args) > 1 else 10
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    n = 1 << log_n
+    data = splitmix_scalars(n, 3)
+    d = w.alloc(n * 32)
+    w.upload(d, data)
+    for mode, name in enumerate(("fft", "ifft", "coset_fft", "icoset_fft")):
+        ts = []
+        for it in range(iters + 2):
+            w.synchronize()
+            t0 = time.perf_counter()
+            assert lib.bh_fft_fr_dev(w.ctx, d, log_n, mode, None) == 0
+            w.synchronize()
+            if it >= 2:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        t = ts[len(ts) // 2]
+        print("log_n=%d %-10s median %.3f ms (min %.3f)  algorithmic %.1f GB/s (64 B/elem)  %.1f Gbutterfly/s" %
+              (log_n, name, t, ts[0], n * 64 / t / 1e6, n / 2 * log_n / t / 1e6), flush=True)
+
+
+def run_mimc(args):
+    iters = int(args[0]) if args else 20
+    from bellman_amd import groth16 as pg
+    from tests import circuits
+    from oracle.pyref import bls12_381 as bls
+
+    w = bellman_amd.Worker(0)
+    rnd = random.Random(322)
+    cons = [rnd.randrange(bls.Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr = rnd.randrange(bls.Q), rnd.randrange(bls.Q)
+    r1cs = pg.R1CS.from_demo(w, 0, circuits.MIMC_ROUNDS, 0, cons)
+    params = pg.Parameters.generate(w, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+    walls, tms = [], []
+    for it in range(iters + 3):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        pg.create_proof_demo(params, 0, circuits.MIMC_ROUNDS, 0, [xl + it, xr], cons, 12345 + it, 67890, tm)
+        wall = (time.perf_counter() - t0) * 1e3
+        if it >= 3:
+            walls.append(wall)
+            tms.append(tm)
+    walls.sort()
+    med = [sorted(t[i] for t in tms)[len(tms) // 2] for i in range(4)]
+    print("MiMC-322 create_proof: wall median %.3f ms (min %.3f); host ms [synthesis %.3f, h %.3f, msm %.3f, total %.3f]" %
+          (walls[len(walls) // 2], walls[0], *med), flush=True)
+
+
+if __name__ == "__main__":
+    {"msm": run_msm, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes}[sys.argv[1]](sys.argv[2:])
