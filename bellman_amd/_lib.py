@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
 
-# every symbol include/bellman_hip.h declares
+# every symbol include/bellman_hip.h declares, then the test hooks of include/bellman_hip_test.h
 EXPORTS = [
     "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
@@ -20,7 +20,7 @@ EXPORTS = [
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
-    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_set_window_bits", "bh_msm_set_chunk",
+    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_async_opts", "bh_msm_async_dev_opts",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
     "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev", "bh_r1cs_eval_transposed_dev", "bh_fr_powers_dev", "bh_fr_qap_ext_dev",
@@ -99,7 +99,8 @@ def load():
     lib.bh_point_add.restype = None
     lib.bh_point_mul.argtypes = [i32, vp, vp, vp]
     lib.bh_point_mul.restype = None
-    lib.bh_msm_set_window_bits.argtypes = [vp, c.c_uint]
+    lib.bh_msm_async_opts.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, c.POINTER(vp)]
+    lib.bh_msm_async_dev_opts.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, c.POINTER(vp)]
     lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
     lib.bh_groth16_params_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, c.POINTER(vp)]
     lib.bh_groth16_params_release.argtypes = [vp]
@@ -140,7 +141,6 @@ def load():
     lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]
     lib.bh_test_msm_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp]
-    lib.bh_msm_set_chunk.argtypes = [vp, c.c_uint]
     for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz]
         getattr(lib, name).restype = None

@@ -1,8 +1,7 @@
 // extern "C" surface of libbellman_hip (declared and documented in include/bellman_hip.h).
 #include <string.h>
 
-#include <atomic>
-
+#include "../../include/bellman_hip_test.h"
 #include "common.hpp"
 #include "msm_types.hpp"
 
@@ -20,7 +19,7 @@ struct MsmJobImpl;
 MsmJobImpl *msm_job_new(Context *ctx, int group);
 void msm_job_delete(MsmJobImpl *j);
 int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                    int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
+                    int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
 hipStream_t msm_job_stream(MsmJobImpl &job);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
@@ -35,8 +34,6 @@ int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsign
 void host_point_mul(int group, void *r, const void *a, const void *k);
 void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n);
 void devhdr_point_mul(int group, void *r, const void *a, const void *k);
-
-static std::atomic<unsigned> g_forced_c{0};
 
 // packs strided host records (optionally with an `infinity` flag byte) into dense device records
 __global__ void pack_bases_kernel(const unsigned char *raw, size_t stride, long inf_offset, u32 rec_words,
@@ -120,6 +117,17 @@ struct bh_bases {
 };
 struct bh_msm_job {
   MsmJobImpl *impl;
+};
+
+// hipMalloc'ed block freed on scope exit unless released: the BH_HIP_CHECK early returns of the register /
+// read paths must not leak device memory
+struct DevGuard {
+  void *p = nullptr;
+  DevGuard() = default;
+  DevGuard(const DevGuard &) = delete;
+  DevGuard &operator=(const DevGuard &) = delete;
+  ~DevGuard() { if (p) (void)hipFree(p); }
+  void *release() { void *q = p; p = nullptr; return q; }
 };
 
 static inline hipStream_t pick_stream(bh_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->c.stream; }
@@ -341,24 +349,23 @@ int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n,
   const size_t rec = group == BH_G1 ? 96 : 192;
   if (stride < rec) return BH_ERR_INVALID_ARG;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  void *dev = nullptr;
-  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  DevGuard dev;
+  BH_HIP_CHECK(hipMalloc(&dev.p, n ? n * rec : 16));
   if (n) {
     if (stride == rec && inf_offset < 0) {
-      BH_HIP_CHECK(hipMemcpyAsync(dev, host_points, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
+      BH_HIP_CHECK(hipMemcpyAsync(dev.p, host_points, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
     } else {
-      void *raw = nullptr;
-      BH_HIP_CHECK(hipMalloc(&raw, n * stride));
-      BH_HIP_CHECK(hipMemcpyAsync(raw, host_points, n * stride, hipMemcpyHostToDevice, ctx->c.stream));
+      DevGuard raw;
+      BH_HIP_CHECK(hipMalloc(&raw.p, n * stride));
+      BH_HIP_CHECK(hipMemcpyAsync(raw.p, host_points, n * stride, hipMemcpyHostToDevice, ctx->c.stream));
       hipLaunchKernelGGL(pack_bases_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->c.stream,
-                         (const unsigned char *)raw, stride, inf_offset, (u32)(rec / 4), (u32 *)dev, (u64)n);
+                         (const unsigned char *)raw.p, stride, inf_offset, (u32)(rec / 4), (u32 *)dev.p, (u64)n);
       BH_HIP_CHECK(hipGetLastError());
       BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
-      BH_HIP_CHECK(hipFree(raw));
     }
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
-  *out = new bh_bases{group, dev, n, true};
+  *out = new bh_bases{group, dev.release(), n, true};
   return BH_OK;
 }
 int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, bh_bases **out) {
@@ -366,27 +373,23 @@ int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_byte
   const size_t rec = group == BH_G1 ? 96 : 192;
   const u32 cpp = group == BH_G1 ? 2 : 4;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  void *dev = nullptr, *raw = nullptr;
-  u32 *flag = nullptr;
-  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
-  int rc = BH_OK;
+  DevGuard dev, raw;
+  BH_HIP_CHECK(hipMalloc(&dev.p, n ? n * rec : 16));
   if (n) {
-    BH_HIP_CHECK(hipMalloc(&raw, n * rec + 4));
-    flag = (u32 *)((char *)raw + n * rec);
-    BH_HIP_CHECK(hipMemcpyAsync(raw, host_bytes, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
+    BH_HIP_CHECK(hipMalloc(&raw.p, n * rec + 4));
+    u32 *flag = (u32 *)((char *)raw.p + n * rec);
+    BH_HIP_CHECK(hipMemcpyAsync(raw.p, host_bytes, n * rec, hipMemcpyHostToDevice, ctx->c.stream));
     BH_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->c.stream));
     const u64 threads = (u64)n * cpp;
     hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, ctx->c.stream,
-                       (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, flag, (u32 *)nullptr);
+                       (const unsigned char *)raw.p, cpp, (fp_t *)dev.p, (u64)n, flag, (u32 *)nullptr);
     BH_HIP_CHECK(hipGetLastError());
     u32 bad = 0;
     BH_HIP_CHECK(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->c.stream));
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
-    BH_HIP_CHECK(hipFree(raw));
-    if (bad) rc = BH_ERR_INVALID_ARG;
+    if (bad) return BH_ERR_INVALID_ARG;
   }
-  if (rc != BH_OK) { (void)hipFree(dev); return rc; }
-  *out = new bh_bases{group, dev, n, true};
+  *out = new bh_bases{group, dev.release(), n, true};
   return BH_OK;
 }
 int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, unsigned flags,
@@ -395,51 +398,42 @@ int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, s
   const size_t rec = group == BH_G1 ? 96 : 192;
   const u32 cpp = group == BH_G1 ? 2 : 4;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  void *dev = nullptr;
-  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  DevGuard dev;
+  BH_HIP_CHECK(hipMalloc(&dev.p, n ? n * rec : 16));
   if (n) {
     hipStream_t st = ctx->c.stream;
-    void *raw = nullptr;
+    DevGuard raw;
     const size_t status_off = (n * rec + 15) & ~size_t(15);
-    if (hipMalloc(&raw, status_off + n * 4 + 16) != hipSuccess) { (void)hipFree(dev); return BH_ERR_HIP; }
-    u32 *status = (u32 *)((char *)raw + status_off);
+    BH_HIP_CHECK(hipMalloc(&raw.p, status_off + n * 4 + 16));
+    u32 *status = (u32 *)((char *)raw.p + status_off);
     unsigned long long *min_idx = (unsigned long long *)((char *)status + ((n * 4 + 7) & ~size_t(7)));
     unsigned long long first = ~0ULL;
     u32 first_status = 0;
-    int rc = BH_OK;
-    auto run = [&]() -> int {
-      BH_HIP_CHECK(hipMemcpyAsync(raw, host_bytes, n * rec, hipMemcpyHostToDevice, st));
-      BH_HIP_CHECK(hipMemsetAsync(status, 0, n * 4, st));
-      BH_HIP_CHECK(hipMemsetAsync(min_idx, 0xff, 8, st));
-      const u64 threads = (u64)n * cpp;
-      hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st,
-                         (const unsigned char *)raw, cpp, (fp_t *)dev, (u64)n, (u32 *)nullptr, status);
-      BH_HIP_CHECK(hipGetLastError());
-      if (flags & BH_POINTS_CHECKED) {
-        int r = points_check(group, dev, n, status, st);
-        if (r != BH_OK) return r;
-      }
-      const u64 blocks = (n + 255) / 256;
-      hipLaunchKernelGGL(first_bad_point_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, status,
-                         (u64)n, (flags & BH_POINTS_FORBID_IDENTITY) ? 1u : 0u, min_idx);
-      BH_HIP_CHECK(hipGetLastError());
-      BH_HIP_CHECK(hipMemcpyAsync(&first, min_idx, 8, hipMemcpyDeviceToHost, st));
-      BH_HIP_CHECK(hipStreamSynchronize(st));
-      if (first != ~0ULL) {
-        BH_HIP_CHECK(hipMemcpyAsync(&first_status, status + first, 4, hipMemcpyDeviceToHost, st));
-        BH_HIP_CHECK(hipStreamSynchronize(st));
-      }
-      return BH_OK;
-    };
-    rc = run();
-    (void)hipFree(raw);
-    if (rc == BH_OK && first != ~0ULL) {
-      if (bad_index) *bad_index = (size_t)first;
-      rc = (first_status & PT_INVALID_MASK) ? BH_ERR_INVALID_POINT : BH_ERR_POINT_AT_INFINITY;
+    BH_HIP_CHECK(hipMemcpyAsync(raw.p, host_bytes, n * rec, hipMemcpyHostToDevice, st));
+    BH_HIP_CHECK(hipMemsetAsync(status, 0, n * 4, st));
+    BH_HIP_CHECK(hipMemsetAsync(min_idx, 0xff, 8, st));
+    const u64 threads = (u64)n * cpp;
+    hipLaunchKernelGGL(decode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned char *)raw.p, cpp, (fp_t *)dev.p, (u64)n, (u32 *)nullptr, status);
+    BH_HIP_CHECK(hipGetLastError());
+    if (flags & BH_POINTS_CHECKED) {
+      int r = points_check(group, dev.p, n, status, st);
+      if (r != BH_OK) { (void)hipStreamSynchronize(st); return r; }
     }
-    if (rc != BH_OK) { (void)hipFree(dev); return rc; }
+    const u64 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(first_bad_point_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, status,
+                       (u64)n, (flags & BH_POINTS_FORBID_IDENTITY) ? 1u : 0u, min_idx);
+    BH_HIP_CHECK(hipGetLastError());
+    BH_HIP_CHECK(hipMemcpyAsync(&first, min_idx, 8, hipMemcpyDeviceToHost, st));
+    BH_HIP_CHECK(hipStreamSynchronize(st));
+    if (first != ~0ULL) {
+      BH_HIP_CHECK(hipMemcpyAsync(&first_status, status + first, 4, hipMemcpyDeviceToHost, st));
+      BH_HIP_CHECK(hipStreamSynchronize(st));
+      if (bad_index) *bad_index = (size_t)first;
+      return (first_status & PT_INVALID_MASK) ? BH_ERR_INVALID_POINT : BH_ERR_POINT_AT_INFINITY;
+    }
   }
-  *out = new bh_bases{group, dev, n, true};
+  *out = new bh_bases{group, dev.release(), n, true};
   return BH_OK;
 }
 int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host) {
@@ -456,13 +450,13 @@ int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, 
   if (!ctx || !out || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
   const size_t rec = group == BH_G1 ? 96 : 192;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  void *dev = nullptr;
-  BH_HIP_CHECK(hipMalloc(&dev, n ? n * rec : 16));
+  DevGuard dev;
+  BH_HIP_CHECK(hipMalloc(&dev.p, n ? n * rec : 16));
   if (n) {
-    BH_HIP_CHECK(hipMemcpyAsync(dev, dev_points, n * rec, hipMemcpyDeviceToDevice, ctx->c.stream));
+    BH_HIP_CHECK(hipMemcpyAsync(dev.p, dev_points, n * rec, hipMemcpyDeviceToDevice, ctx->c.stream));
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
-  *out = new bh_bases{group, dev, n, true};
+  *out = new bh_bases{group, dev.release(), n, true};
   return BH_OK;
 }
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {
@@ -513,21 +507,15 @@ void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
 size_t bh_bases_len(const bh_bases *b) { return b->n; }
 
 // ---- multiexp -----------------------------------------------------------------------------------
-int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c) {
-  (void)ctx;
-  g_forced_c.store((g_forced_c.load() & ~0xffu) | (c & 0xffu));   // c <= 24
-  return BH_OK;
-}
-int bh_msm_set_chunk(bh_ctx *ctx, unsigned k) {
-  (void)ctx;
-  // bits 8..23: chunk K; bits 24/25 (k = 0x10000 / 0x20000 ored in): force register / LDS accumulator
-  g_forced_c.store((g_forced_c.load() & 0xffu) | (k << 8));
-  return BH_OK;
-}
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      bh_msm_job **out) {
-  if (!bases || !out) return BH_ERR_INVALID_ARG;
+                      const bh_msm_opts *o, bh_msm_job **out) {
+  if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
+  MsmOpts opts;
+  if (o) {
+    if (o->window_bits && (o->window_bits < 2 || o->window_bits > 24)) return BH_ERR_INVALID_ARG;
+    opts.c = o->window_bits; opts.chunk = o->chunk; opts.flags = o->flags;
+  }
   if (fmt != BH_SCALARS_CANONICAL && fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
   if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
@@ -558,7 +546,7 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   }
   if (rc == BH_OK)
     rc = msm_job_enqueue(*impl, bases->table ? bases->table : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
-                         g_forced_c.load(), bases->table ? &bases->tab : nullptr);
+                         opts, bases->table ? &bases->tab : nullptr);
   if (rc != BH_OK) {
     float ms[4];
     unsigned char dummy[192];
@@ -571,11 +559,20 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
 }
 int bh_msm_async(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host, size_t n, int fmt,
                  const uint64_t *density_words, size_t density_len, bh_msm_job **job) {
-  return msm_common(ctx, bases, skip, scalars_host, true, n, fmt, density_words, true, density_len, job);
+  return msm_common(ctx, bases, skip, scalars_host, true, n, fmt, density_words, true, density_len, nullptr, job);
+}
+int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host, size_t n, int fmt,
+                      const uint64_t *density_words, size_t density_len, const bh_msm_opts *opts, bh_msm_job **job) {
+  return msm_common(ctx, bases, skip, scalars_host, true, n, fmt, density_words, true, density_len, opts, job);
 }
 int bh_msm_async_dev(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev, size_t n, int fmt,
                      const uint64_t *density_words_dev, size_t density_len, bh_msm_job **job) {
-  return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, job);
+  return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, nullptr, job);
+}
+int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev, size_t n, int fmt,
+                          const uint64_t *density_words_dev, size_t density_len, const bh_msm_opts *opts,
+                          bh_msm_job **job) {
+  return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, opts, job);
 }
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;

@@ -6,6 +6,7 @@
 #include <functional>
 #include <vector>
 
+#include "../../include/bellman_hip_test.h"
 #include "groth16_internal.hpp"
 
 namespace groth16 {
@@ -284,20 +285,27 @@ int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const vo
                                 const uint64_t *b_input_density, const uint64_t *b_aux_density, const void *r,
                                 const void *s, void *proof_out, float *timings4) {
   using namespace groth16;
-  ProvingAssignment pa;
-  auto fill = [](std::vector<Fr> &v, const void *src, size_t n) { v.resize(n); if (n) memcpy(v.data(), src, n * 32); };
-  fill(pa.a, a_evals, n_constraints); fill(pa.b, b_evals, n_constraints); fill(pa.c, c_evals, n_constraints);
-  fill(pa.input_assignment, input_assignment, n_inputs); fill(pa.aux_assignment, aux_assignment, n_aux);
-  auto fill_d = [](bellman::DensityTracker &d, const uint64_t *w, size_t n) {
-    for (size_t i = 0; i < n; i++) { d.add_element(); if ((w[i >> 6] >> (i & 63)) & 1) d.inc(i); }
-  };
-  fill_d(pa.a_aux_density, a_aux_density, n_aux);
-  fill_d(pa.b_input_density, b_input_density, n_inputs);
-  fill_d(pa.b_aux_density, b_aux_density, n_aux);
-  Fr rr, ss;
-  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  if (!params || !r || !s || !proof_out) return BH_ERR_INVALID_ARG;
+  if ((n_constraints && (!a_evals || !b_evals || !c_evals)) || (n_inputs && (!input_assignment || !b_input_density)) ||
+      (n_aux && (!aux_assignment || !a_aux_density || !b_aux_density)))
+    return BH_ERR_INVALID_ARG;
   ProveTimings tm = {0, 0, 0, 0};
-  int rc = run_guarded([&] { return prove_assignment(pa, *params->p, rr, ss, &tm); }, proof_out);
+  // everything that can allocate runs inside the guard: no C++ exception may cross the C boundary
+  int rc = run_guarded([&] {
+    ProvingAssignment pa;
+    auto fill = [](std::vector<Fr> &v, const void *src, size_t n) { v.resize(n); if (n) memcpy(v.data(), src, n * 32); };
+    fill(pa.a, a_evals, n_constraints); fill(pa.b, b_evals, n_constraints); fill(pa.c, c_evals, n_constraints);
+    fill(pa.input_assignment, input_assignment, n_inputs); fill(pa.aux_assignment, aux_assignment, n_aux);
+    auto fill_d = [](bellman::DensityTracker &d, const uint64_t *w, size_t n) {
+      for (size_t i = 0; i < n; i++) { d.add_element(); if ((w[i >> 6] >> (i & 63)) & 1) d.inc(i); }
+    };
+    fill_d(pa.a_aux_density, a_aux_density, n_aux);
+    fill_d(pa.b_input_density, b_input_density, n_inputs);
+    fill_d(pa.b_aux_density, b_aux_density, n_aux);
+    Fr rr, ss;
+    memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+    return prove_assignment(pa, *params->p, rr, ss, &tm);
+  }, proof_out);
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
 }
@@ -306,16 +314,18 @@ int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void 
                              const void *aux_assignment, size_t n_aux, const void *r, const void *s, void *proof_out,
                              float *timings4) {
   using namespace groth16;
-  if (!params || !r1cs) return BH_ERR_INVALID_ARG;
-  R1csView view(r1cs);
-  std::vector<Fr> in(n_inputs), aux(n_aux);   // caller records may be unaligned
-  if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
-  if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
-  Fr rr, ss;
-  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  if (!params || !r1cs || !r || !s || !proof_out || (n_inputs && !input_assignment) || (n_aux && !aux_assignment))
+    return BH_ERR_INVALID_ARG;
   ProveTimings tm = {0, 0, 0, 0};
-  int rc = run_guarded([&] { return prove_witness(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, rr, ss, &tm); },
-                       proof_out);
+  int rc = run_guarded([&] {
+    R1csView view(r1cs);
+    std::vector<Fr> in(n_inputs), aux(n_aux);   // caller records may be unaligned
+    if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
+    if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
+    Fr rr, ss;
+    memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+    return prove_witness(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, rr, ss, &tm);
+  }, proof_out);
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
 }
@@ -337,13 +347,12 @@ int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circu
                                const void *witness, const void *constants, const void *r, const void *s, void *proof_out,
                                float *timings4) {
   using namespace groth16;
-  if (!params || !r1cs) return BH_ERR_INVALID_ARG;
-  R1csView view(r1cs);
+  if (!params || !r1cs || !r || !s || !proof_out) return BH_ERR_INVALID_ARG;
   Fr rr, ss;
   memcpy(&rr, r, 32); memcpy(&ss, s, 32);
   ProveTimings tm = {0, 0, 0, 0};
   int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
-    return run_guarded([&] { return create_proof(c, view.r, *params->p, rr, ss, &tm); }, proof_out);
+    return run_guarded([&] { R1csView view(r1cs); return create_proof(c, view.r, *params->p, rr, ss, &tm); }, proof_out);
   });
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
@@ -353,14 +362,15 @@ int bh_groth16_prove_witness_part(bh_params *params, const bh_r1cs *r1cs, const 
                                   const void *aux_assignment, size_t n_aux, size_t part, size_t parts, void *sums_out,
                                   float *timings4) {
   using namespace groth16;
-  if (!params || !r1cs || !sums_out) return BH_ERR_INVALID_ARG;
-  R1csView view(r1cs);
-  std::vector<Fr> in(n_inputs), aux(n_aux);
-  if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
-  if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
+  if (!params || !r1cs || !sums_out || (n_inputs && !input_assignment) || (n_aux && !aux_assignment)) return BH_ERR_INVALID_ARG;
   ProveTimings tm = {0, 0, 0, 0};
-  int rc = run_guarded_sums([&] { return prove_witness_part(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, part, parts, &tm); },
-                            sums_out);
+  int rc = run_guarded_sums([&] {
+    R1csView view(r1cs);
+    std::vector<Fr> in(n_inputs), aux(n_aux);
+    if (n_inputs) memcpy(in.data(), input_assignment, n_inputs * 32);
+    if (n_aux) memcpy(aux.data(), aux_assignment, n_aux * 32);
+    return prove_witness_part(view.r, *params->p, in.data(), n_inputs, aux.data(), n_aux, part, parts, &tm);
+  }, sums_out);
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
 }
@@ -370,10 +380,10 @@ int bh_groth16_prove_demo_r1cs_part(bh_params *params, const bh_r1cs *r1cs, int 
                                     float *timings4) {
   using namespace groth16;
   if (!params || !r1cs || !sums_out) return BH_ERR_INVALID_ARG;
-  R1csView view(r1cs);
   ProveTimings tm = {0, 0, 0, 0};
   int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
     return run_guarded_sums([&] {
+      R1csView view(r1cs);
       const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
       WitnessAssignment w;
       w.input_assignment.reserve(view.r.num_inputs);
@@ -402,7 +412,7 @@ void bh_groth16_sums_add(void *acc, const void *other) {
 
 int bh_groth16_assemble(bh_params *params, const void *sums, const void *r, const void *s, void *proof_out) {
   using namespace groth16;
-  if (!params || !sums) return BH_ERR_INVALID_ARG;
+  if (!params || !sums || !r || !s || !proof_out) return BH_ERR_INVALID_ARG;
   MsmSums m;
   memcpy(&m, sums, sizeof m);
   Fr rr, ss;
@@ -413,6 +423,7 @@ int bh_groth16_assemble(bh_params *params, const void *sums, const void *r, cons
 int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed, const void *witness,
                           const void *constants, const void *r, const void *s, void *proof_out, float *timings4) {
   using namespace groth16;
+  if (!params || !witness || !r || !s || !proof_out) return BH_ERR_INVALID_ARG;
   Fr rr, ss;
   memcpy(&rr, r, 32); memcpy(&ss, s, 32);
   ProveTimings tm = {0, 0, 0, 0};

@@ -17,11 +17,17 @@ bool G2Affine::is_identity() const { uint64_t o = 0; for (uint64_t x : v) o |= x
 Parameters::Parameters(bh_ctx *c, const VerifyingKey &k, const G1Affine *hq, size_t nh, const G1Affine *lq, size_t nl,
                        const G1Affine *aq, size_t na, const G1Affine *b1, size_t nb1, const G2Affine *b2, size_t nb2)
     : ctx(c), vk(k) {
-  check(bh_bases_register(ctx, BH_G1, hq, nh, 96, -1, &h));
-  check(bh_bases_register(ctx, BH_G1, lq, nl, 96, -1, &l));
-  check(bh_bases_register(ctx, BH_G1, aq, na, 96, -1, &a));
-  check(bh_bases_register(ctx, BH_G1, b1, nb1, 96, -1, &b_g1));
-  check(bh_bases_register(ctx, BH_G2, b2, nb2, 192, -1, &b_g2));
+  h = l = a = b_g1 = b_g2 = nullptr;
+  try {
+    check(bh_bases_register(ctx, BH_G1, hq, nh, 96, -1, &h));
+    check(bh_bases_register(ctx, BH_G1, lq, nl, 96, -1, &l));
+    check(bh_bases_register(ctx, BH_G1, aq, na, 96, -1, &a));
+    check(bh_bases_register(ctx, BH_G1, b1, nb1, 96, -1, &b_g1));
+    check(bh_bases_register(ctx, BH_G2, b2, nb2, 192, -1, &b_g2));
+  } catch (...) {   // the destructor does not run for a half-built object: release what was registered
+    for (bh_bases *b : {h, l, a, b_g1, b_g2}) bh_bases_release(ctx, b);
+    throw;
+  }
 }
 // ---- groth16/src/lib.rs:159-215 (VerifyingKey::read) + :289-398 (Parameters::read) --------------------
 namespace {

@@ -66,6 +66,13 @@ struct ProofStream {   // uploads + h block of one proof; independent of other p
   ~ProofStream() { if (st) { (void)bh_stream_synchronize(ctx, st); (void)bh_stream_destroy(ctx, st); } }
   ProofStream(const ProofStream &) = delete;
 };
+// Declared after every DevBuf the proof stream writes (and so destroyed before them): if an exception
+// unwinds the frame, queued uploads / memsets / evaluations finish before their targets return to the
+// shared pool, where another proof's thread could pick them up.
+struct StreamDrain {
+  ProofStream &ps;
+  ~StreamDrain() { if (ps.st) (void)bh_stream_synchronize(ps.ctx, ps.st); }
+};
 // Every issued multiexp owns device buffers and reads ours: if anything throws between issue and
 // wait, the jobs still in flight are drained before the DevBufs they read are released.
 struct JobSet {
@@ -184,6 +191,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // h-block buffers are declared here so that `jobs` (declared after every buffer a job reads) is
   // destroyed first and drains whatever is still in flight if an exception unwinds this frame
   DevBuf da(ctx, m * 32), db(ctx, m * 32), dc(ctx, m * 32);
+  StreamDrain drain{ps};
   JobSet jobs;
   for (bh_msm_job **j : {&l_job, &a_in_job, &a_aux_job, &b1_in_job, &b1_aux_job, &b2_in_job, &b2_aux_job, &h_job}) jobs.track(j);
   // one multiexp over this part's slice of the scalars: `skip` advances by the number of bases the

@@ -77,11 +77,11 @@ void msm_job_delete(MsmJobImpl *j) {
 hipStream_t msm_job_stream(MsmJobImpl &job) { return job.stream; }
 void msm_job_own(MsmJobImpl &job, void *dev_ptr) { job.dev_allocs.push_back(dev_ptr); }
 int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                    int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table) {
+                    int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
   if (n == 0) { job.trivial = true; job.early_rc = BH_OK; return BH_OK; }
   return job.group == BH_G1
-             ? msm_enqueue_g1(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, forced_c, table)
-             : msm_enqueue_g2(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, forced_c, table);
+             ? msm_enqueue_g1(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table)
+             : msm_enqueue_g2(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);
 }
 int window_table(int group, void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {
   return group == BH_G1 ? window_table_g1(table_dev, n, c, W, st) : window_table_g2(table_dev, n, c, W, st);

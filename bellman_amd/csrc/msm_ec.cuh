@@ -379,17 +379,16 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // ============================================================================================
 template <class F>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
-                       u64 n, int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table) {
+                       u64 n, int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
   // a window table is used when it exists, nobody forces another window size, and its row indices
   // fit the 31-bit base field of a pair
-  const bool use_table = table && ((forced_c & 0xffu) == 0 || (forced_c & 0xffu) == table->c) &&
+  const bool use_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c) &&
                          (u64)table->W * table->stride < ((u64)1 << 31) && (u64)table->W * n < ((u64)1 << 32);
-  const MsmPlan p = use_table ? make_table_plan(n, *table, (forced_c >> 8) & 0xffffu, F::WORDS == 24, c.num_cus)
-                              : make_plan(n, forced_c & 0xffu, (forced_c >> 8) & 0xffffu, F::WORDS == 24);
-  // accumulator placement: bit 24 of the tuning word forces registers, bit 25 forces LDS
-  const bool lds_acc = (forced_c & (1u << 25)) ? true : (forced_c & (1u << 24)) ? false : (F::WORDS == 24);
+  const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, F::WORDS == 24, c.num_cus)
+                              : make_plan(n, opts.c, opts.chunk, F::WORDS == 24);
+  const bool lds_acc = (opts.flags & BH_MSM_ACC_LDS) ? true : (opts.flags & BH_MSM_ACC_REGISTERS) ? false : (F::WORDS == 24);
   job.plan = p;
   if ((u64)p.Wd * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
   if (n_bases >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;        // base index shares its word with the sign bit
@@ -693,9 +692,9 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
 
 #define BH_INSTANTIATE_MSM(SUFFIX, OPS)                                                                       \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
-                           const void *scalars_dev, u64 n, int fmt, const u64 *density_dev, unsigned fc,     \
-                           const WindowTable *table) {                                                       \
-    return msm_enqueue<OPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, fc, table);      \
+                           const void *scalars_dev, u64 n, int fmt, const u64 *density_dev,                 \
+                           const MsmOpts &opts, const WindowTable *table) {                                  \
+    return msm_enqueue<OPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);    \
   }                                                                                                           \
   int window_table_##SUFFIX(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {                           \
     return window_table_t<OPS>(table_dev, n, c, W, st);                                                       \

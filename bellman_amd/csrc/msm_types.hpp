@@ -27,6 +27,13 @@ struct LongRun {   // a bucket whose entries span more than MERGE_WALK chunks
   u32 w, lane, d;
 };
 
+// per-job plan overrides (bh_msm_opts): zero = tuned default
+struct MsmOpts {
+  u32 c = 0;        // window bits
+  u32 chunk = 0;    // K
+  u32 flags = 0;    // BH_MSM_*
+};
+
 struct MsmPlan {
   u32 n, c, W, nb, NB, lo_bits, hi_bits, num_tiles, sort_passes;
   u32 chunk;             // K: sorted entries per accumulation lane
@@ -84,9 +91,9 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
 
 // msm_g1.hip / msm_g2.hip
 int msm_enqueue_g1(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                   int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
+                   int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
-                   int fmt, const u64 *density_dev, unsigned forced_c, const WindowTable *table);
+                   int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);   // ms: float[4] or null
 int msm_finish_g2(MsmJobImpl &job, void *out_affine, float *ms);
 int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);

@@ -9,8 +9,10 @@ class UnexpectedIdentity(SynthesisError):
     """src/multiexp.rs:63-65"""
 
 
-class UnexpectedEof(SynthesisError):
-    """io::ErrorKind::UnexpectedEof, "expected more bases from source" (src/multiexp.rs:55-61)"""
+class UnexpectedEof(SynthesisError, IOError):
+    """io::ErrorKind::UnexpectedEof: `SynthesisError::IoError` "expected more bases from source" from multiexp
+    (src/multiexp.rs:55-61) and the plain `io::Error` of a truncated `Parameters::read` / `VerifyingKey::read`
+    (groth16/src/lib.rs:159-215,289-398) - so it is both a SynthesisError and an IOError."""
 
 
 class PolynomialDegreeTooLarge(SynthesisError):

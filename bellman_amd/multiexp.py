@@ -165,13 +165,22 @@ class Bases:
             pass
 
 
+class MsmOpts(ctypes.Structure):
+    """bh_msm_opts: per-job plan overrides (window bits c, chunk K, BH_MSM_* flags); zero = tuned default"""
+    _fields_ = [("window_bits", ctypes.c_uint32), ("chunk", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH = 1, 2, 4, 8
+
+
 def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,
-             density_dev=None):
+             density_dev=None, window_bits=0, chunk=0, flags=0):
     """multiexp(pool, (bases, skip), density_map, exponents) -> Waiter (src/multiexp.rs:305-332).
 
     exponents: [n,4] uint64 scalars on the host; or pass scalars_dev (device pointer) + n.
     The Waiter's wait() returns the affine result record (numpy uint64[12|24]) or raises the
-    SynthesisError the reference would return.  With timed=True it returns (record, [total, sort, accumulate, reduce] device ms)."""
+    SynthesisError the reference would return.  With timed=True it returns (record, [total, sort, accumulate, reduce] device ms).
+    window_bits / chunk / flags override the plan of THIS job only (tests, tuning sweeps)."""
     lib = _lib.load()
     words = None
     dlen = 0
@@ -180,15 +189,17 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
         words = density_map.words()
     job = ctypes.c_void_p()
     fmt = 1 if mont else 0
+    opts = MsmOpts(window_bits, chunk, flags)
+    po = ctypes.cast(ctypes.pointer(opts), ctypes.c_void_p)
     if scalars_dev is None:
         sc = np.ascontiguousarray(exponents, dtype=np.uint64).reshape(-1, 4)
         n = sc.shape[0]
-        rc = lib.bh_msm_async(pool.ctx, bases._h, skip, sc.ctypes.data_as(ctypes.c_void_p), n, fmt,
-                              None if words is None else words.ctypes.data_as(ctypes.c_void_p), dlen,
-                              ctypes.byref(job))
+        rc = lib.bh_msm_async_opts(pool.ctx, bases._h, skip, sc.ctypes.data_as(ctypes.c_void_p), n, fmt,
+                                   None if words is None else words.ctypes.data_as(ctypes.c_void_p), dlen, po,
+                                   ctypes.byref(job))
     else:
-        rc = lib.bh_msm_async_dev(pool.ctx, bases._h, skip, scalars_dev, n, fmt, density_dev,
-                                  dlen if density_dev is not None else 0, ctypes.byref(job))
+        rc = lib.bh_msm_async_dev_opts(pool.ctx, bases._h, skip, scalars_dev, n, fmt, density_dev,
+                                       dlen if density_dev is not None else 0, po, ctypes.byref(job))
     check(rc, "multiexp")
     w = _WORDS[bases.group]
 

@@ -10,7 +10,8 @@
  *   Fr element   32 B  4 x u64 little-endian limbs.  FFT/polynomial data is in MONTGOMERY
  *                      form (R = 2^256), exactly the bytes of a Rust `bls12_381::Scalar`.
  *   MSM scalar   32 B  either canonical little-endian (BH_SCALARS_CANONICAL - the bits of
- *                      `Exponent::Bits`, src/multiexp.rs:179) or Montgomery (BH_SCALARS_MONT -
+ *                      `Exponent::Bits`, src/multiexp.rs:179; a value >= q, which the reference
+ *                      cannot produce, is taken mod q) or Montgomery (BH_SCALARS_MONT -
  *                      a Rust `Scalar` as is; converted on the device).
  *   G1 affine    96 B  x | y, each 6 x u64 LE limbs, Montgomery form (R = 2^384).
  *   G2 affine   192 B  x.c0 | x.c1 | y.c0 | y.c1 (Fp2 = c0 + c1*u).
@@ -177,10 +178,24 @@ void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);
 /* r = [k] a on the HOST, k = 32-byte canonical little-endian scalar: the five single scalar
  * multiplications of create_proof (groth16/src/prover.rs:326-338, 342, 351) */
 void bh_point_mul(int group, void *r, const void *a, const void *k_canonical);
-/* tuning knob for experiments: window bits c (0 = automatic) */
-int bh_msm_set_window_bits(bh_ctx *ctx, unsigned c);
-/* tuning knob: sorted entries per accumulation lane K (0 = default) */
-int bh_msm_set_chunk(bh_ctx *ctx, unsigned k);
+/* Per-job plan overrides (experiments, tests, tuning sweeps): NULL or all-zero = the tuned defaults.
+ * They travel with the job, so concurrent jobs on one context never see each other's settings.  The
+ * result is the same group element whatever the plan. */
+typedef struct {
+  uint32_t window_bits; /* c, 2..24; 0 = automatic */
+  uint32_t chunk;       /* K: sorted entries per accumulation lane; 0 = automatic */
+  uint32_t flags;       /* BH_MSM_* below */
+} bh_msm_opts;
+#define BH_MSM_ACC_REGISTERS 1u /* keep the running bucket sum in registers */
+#define BH_MSM_ACC_LDS 2u       /* ... in LDS */
+#define BH_MSM_NO_TABLE 4u      /* ignore a window table attached to the bases */
+#define BH_MSM_NO_SMALL_PATH 8u /* run the full pipeline even for a handful of terms */
+int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
+                      size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
+                      size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
+int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev,
+                          size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
+                          size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
 
 /* ---- fixed-base scalar multiplication (fixture / CRS generation; SURVEY §8 f4,
  * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device */
@@ -312,34 +327,6 @@ int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t se
 int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
                                uint64_t seed, const void *witness, const void *constants, const void *r,
                                const void *s, void *proof_out, float *timings4);
-
-/* ---- self-test hooks used by tests/ (element-wise field / group ops on the device) ---- */
-int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
-int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
-/* r[i] = a[i] + b[i] on the curve (affine in, affine out) */
-int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
-/* runs MSM stages 1-3 (digits, radix sort, zero-digit count) for window size c and copies the
- * sorted (digit<<32|base) pairs [W*n] and the per-window count of zero digits [W] back (bring-up aid) */
-int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *zstart_out_host);
-/* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
-void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
-void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
-void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
-void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
-void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
-/* host only: the MSM plan for n terms (out9 = c, W, buckets per window, K, chunks per window, sort passes,
- * lo_bits, hi_bits, low 32 bits of W*n) and the scalar-index slice [lo, hi) that part `part` of `parts`
- * of a sharded proof computes */
-int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9);
-void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);
-/* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
- * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
-int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
-/* host-only: milliseconds to synthesise a demo circuit (kind/size/seed as bh_groth16_prove_demo) into a
- * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); no device involved */
-double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
-void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
 
 #ifdef __cplusplus
 }

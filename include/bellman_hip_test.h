@@ -1,0 +1,43 @@
+/* libbellman_hip - self-test hooks used by tests/ and tools/ only.  NOT part of the product boundary
+ * (include/bellman_hip.h): nothing here is needed by a caller of multiexp / EvaluationDomain /
+ * create_proof.  The symbols live in the same shared library so the tests exercise the shipped code. */
+#ifndef BELLMAN_HIP_TEST_H
+#define BELLMAN_HIP_TEST_H
+#include "bellman_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element-wise field / group ops on the device */
+int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+int bh_test_fp_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+/* r[i] = a[i] + b[i] on the curve (affine in, affine out) */
+int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev, const void *b_dev, size_t n);
+/* runs MSM stages 1-3 (digits, radix sort, zero-digit count) for window size c and copies the
+ * sorted (digit<<32|base) pairs [W*n] and the per-window count of zero digits [W] back (bring-up aid) */
+int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
+                       uint64_t *pairs_out_host, uint32_t *zstart_out_host);
+/* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
+void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
+void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
+void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
+void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
+void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
+/* host only: the MSM plan for n terms (out9 = c, W, buckets per window, K, chunks per window, sort passes,
+ * lo_bits, hi_bits, low 32 bits of W*n) and the scalar-index slice [lo, hi) that part `part` of `parts`
+ * of a sharded proof computes */
+int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9);
+void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);
+/* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
+ * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
+int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
+/* host-only: milliseconds to synthesise a demo circuit (kind/size/seed as bh_groth16_prove_demo) into a
+ * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); no device involved */
+double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
+void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -32,6 +32,12 @@ def test_header_symbols_all_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "bellman_hip.h")).read()
     declared = set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
+    # the product boundary carries no test hooks: they live in their own header
+    assert not [d for d in declared if d.startswith("bh_test_")]
+    test_hdr = open(os.path.join(ROOT, "include", "bellman_hip_test.h")).read()
+    hooks = set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", test_hdr))
+    assert hooks and all(h.startswith("bh_test_") for h in hooks)
+    declared |= hooks
     assert declared == set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym

@@ -436,12 +436,8 @@ def test_msm_window_bits_do_not_change_result(worker):
     sc = cref.random_fr(n, 9)
     hb = bellman_amd.Bases(worker, 1, bases)
     rc, want = cref.multiexp(1, bases, 0, None, sc)
-    try:
-        for c in (2, 3, 5, 8, 9, 13, 16):
-            _lib.load().bh_msm_set_window_bits(worker.ctx, c)
-            assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want), c
-    finally:
-        _lib.load().bh_msm_set_window_bits(worker.ctx, 0)
+    for c in (2, 3, 5, 8, 9, 13, 16):   # per-job override (bh_msm_opts): nothing on the context changes
+        assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, window_bits=c).wait(), want), c
 
 
 def test_msm_chunk_size_does_not_change_result(worker):
@@ -455,12 +451,8 @@ def test_msm_chunk_size_does_not_change_result(worker):
     sc[100:400] = sc[100]  # a bucket spanning many chunks in every window
     hb = bellman_amd.Bases(worker, 1, bases)
     rc, want = cref.multiexp(1, bases, 0, None, sc)
-    try:
-        for k in (1, 2, 3, 7, 32, 100, 10000):
-            _lib.load().bh_msm_set_chunk(worker.ctx, k)
-            assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), want), k
-    finally:
-        _lib.load().bh_msm_set_chunk(worker.ctx, 0)
+    for k in (1, 2, 3, 7, 32, 100, 10000):
+        assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, chunk=k).wait(), want), k
 
 
 def test_msm_2_20_config_c2(worker):
@@ -511,47 +503,41 @@ def test_msm_fuzz_random_shapes(worker, seed):
 
     lib = _lib.load()
     rnd = np.random.default_rng(1000 + seed)
-    try:
-        for _ in range(5):
-            group = 1 if rnd.random() < 0.75 else 2
-            n = int(rnd.choice([3, 17, 64, 65, 127, 500, 1023, 2048, 3001, 9000]))
-            if group == 2:
-                n = min(n, 2048)
-            sc = cref.random_fr(n, int(rnd.integers(1 << 30)))
-            mode = int(rnd.integers(5))
-            if mode == 1:  # few distinct scalars -> very long bucket runs
-                sc[:] = sc[rnd.integers(0, 3, size=n)]
-            elif mode == 2:  # small scalars: upper windows empty
-                sc[:, 1:] = 0
-            elif mode == 3:  # boolean-heavy witness
-                k = rnd.integers(0, 3, size=n)
-                sc[k == 0] = 0
-                sc[k == 1] = cref.ints_to_arr([1], 4)[0]
-            elif mode == 4:  # values near q and powers of two
-                sc[::3] = cref.ints_to_arr([Q - 1], 4)[0]
-                sc[1::3] = cref.ints_to_arr([1 << int(rnd.integers(1, 254))], 4)[0]
-            dens = None
-            nb, skip = n, 0
-            if rnd.random() < 0.5:
-                dens = rnd.random(n) < rnd.choice([0.1, 0.5, 0.9])
-                skip = int(rnd.integers(0, 5))
-                nb = int(dens.sum()) + skip
-            bases = cref.gen_bases(group, max(nb, 1), a=int(rnd.integers(1, 1000)), b=int(rnd.integers(1, 1000)))[:nb]
-            if nb > 10 and rnd.random() < 0.3:
-                bases[5] = bases[4]
-            c = int(rnd.choice([0, 2, 3, 4, 7, 8, 11, 13, 16]))
-            K = int(rnd.choice([0, 1, 2, 5, 8, 16, 33, 1000]))
-            lib.bh_msm_set_window_bits(worker.ctx, c)
-            lib.bh_msm_set_chunk(worker.ctx, K)
-            hb = bellman_amd.Bases(worker, group, bases)
-            dm = bellman_amd.FullDensity() if dens is None else bellman_amd.DensityTracker(dens)
-            got = bellman_amd.multiexp(worker, hb, dm, sc, skip=skip).wait()
-            rc, want = cref.multiexp(group, bases, skip, None if dens is None else cref.density_bitmap(dens), sc)
-            assert rc == 0
-            assert np.array_equal(got, want), (group, n, mode, c, K, skip, dens is not None)
-    finally:
-        lib.bh_msm_set_window_bits(worker.ctx, 0)
-        lib.bh_msm_set_chunk(worker.ctx, 0)
+    for _ in range(5):
+        group = 1 if rnd.random() < 0.75 else 2
+        n = int(rnd.choice([3, 17, 64, 65, 127, 500, 1023, 2048, 3001, 9000]))
+        if group == 2:
+            n = min(n, 2048)
+        sc = cref.random_fr(n, int(rnd.integers(1 << 30)))
+        mode = int(rnd.integers(5))
+        if mode == 1:  # few distinct scalars -> very long bucket runs
+            sc[:] = sc[rnd.integers(0, 3, size=n)]
+        elif mode == 2:  # small scalars: upper windows empty
+            sc[:, 1:] = 0
+        elif mode == 3:  # boolean-heavy witness
+            k = rnd.integers(0, 3, size=n)
+            sc[k == 0] = 0
+            sc[k == 1] = cref.ints_to_arr([1], 4)[0]
+        elif mode == 4:  # values near q and powers of two
+            sc[::3] = cref.ints_to_arr([Q - 1], 4)[0]
+            sc[1::3] = cref.ints_to_arr([1 << int(rnd.integers(1, 254))], 4)[0]
+        dens = None
+        nb, skip = n, 0
+        if rnd.random() < 0.5:
+            dens = rnd.random(n) < rnd.choice([0.1, 0.5, 0.9])
+            skip = int(rnd.integers(0, 5))
+            nb = int(dens.sum()) + skip
+        bases = cref.gen_bases(group, max(nb, 1), a=int(rnd.integers(1, 1000)), b=int(rnd.integers(1, 1000)))[:nb]
+        if nb > 10 and rnd.random() < 0.3:
+            bases[5] = bases[4]
+        c = int(rnd.choice([0, 2, 3, 4, 7, 8, 11, 13, 16]))
+        K = int(rnd.choice([0, 1, 2, 5, 8, 16, 33, 1000]))
+        hb = bellman_amd.Bases(worker, group, bases)
+        dm = bellman_amd.FullDensity() if dens is None else bellman_amd.DensityTracker(dens)
+        got = bellman_amd.multiexp(worker, hb, dm, sc, skip=skip, window_bits=c, chunk=K).wait()
+        rc, want = cref.multiexp(group, bases, skip, None if dens is None else cref.density_bitmap(dens), sc)
+        assert rc == 0
+        assert np.array_equal(got, want), (group, n, mode, c, K, skip, dens is not None)
 
 
 @pytest.mark.parametrize("group", [1, 2])

@@ -46,13 +46,11 @@ def run_msm(args):
     s = splitmix_scalars(n, 2)
     ds = w.alloc(n * 32)
     w.upload(ds, s)
-    if c or k:
-        lib.bh_msm_set_window_bits(w.ctx, c)
-        lib.bh_msm_set_chunk(w.ctx, k)
     walls, best = [], None
     for it in range(iters + 2):
         t0 = time.perf_counter()
-        r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
+        r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
+                                     window_bits=c, chunk=k).wait()
         wall = (time.perf_counter() - t0) * 1e3
         if it >= 2:
             walls.append(wall)

@@ -39,11 +39,10 @@ def main():
             bases.precompute(c)
             print("  window table c=%d: %s built in %.2f s" % (c, bases.table_info(), time.time() - t0), flush=True)
         for k in ks:
-            lib.bh_msm_set_window_bits(w.ctx, c)
-            lib.bh_msm_set_chunk(w.ctx, k | (int(os.environ.get('BH_ACC', '0')) << 16))
             best = None
-            for it in range(4):
-                r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
+            for it in range(4):   # BH_ACC=1 / 2: force the register / LDS accumulator (bh_msm_opts.flags)
+                r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
+                                             window_bits=c, chunk=k, flags=int(os.environ.get('BH_ACC', '0'))).wait()
                 if best is None or ms[0] < best[0]:
                     best = ms
             if ref is None:
