@@ -1,0 +1,297 @@
+//! Safe Rust wrapper over libbellman_hip (include/bellman_hip.h) for bellman's generic call sites.
+//!
+//! bellman's `multiexp`, `EvaluationDomain` and `Worker` are generic over curves, fields, base sources
+//! and density maps (reference: src/multiexp.rs:305-332, src/domain.rs:21-190, src/multicore.rs:21-130).
+//! The device only implements the BLS12-381 instantiation with a shared base vector, so the patch in
+//! `shim/patches/` routes exactly that case here (decided at run time by `TypeId`, with two trait hooks
+//! for the base source and the density map) and leaves every other instantiation on the CPU path.
+//!
+//! NOT COMPILED in the image this repository is built in (no Rust toolchain there): `ffi.rs` is generated
+//! from the C header and checked by `tests/test_shim_cpu.py`; the rest is written against the `bls12_381`
+//! 0.8 / `ff` 0.13 / `group` 0.13 APIs bellman pins.
+pub mod ffi;
+pub mod layout;
+
+use bls12_381::{G1Affine, G2Affine, Scalar};
+use std::collections::HashMap;
+use std::os::raw::{c_int, c_long, c_void};
+use std::ptr;
+use std::sync::{Arc, Mutex, OnceLock, Weak};
+
+/// Return codes of the C ABI that correspond to `bellman::SynthesisError` variants
+/// (include/bellman_hip.h; reference: src/lib.rs:303-319).  The patch converts them.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum HipError {
+    /// `SynthesisError::UnexpectedIdentity` (src/multiexp.rs:63-65)
+    UnexpectedIdentity,
+    /// `SynthesisError::IoError(UnexpectedEof, "expected more bases from source")` (src/multiexp.rs:55-61)
+    UnexpectedEof,
+    /// `SynthesisError::PolynomialDegreeTooLarge` (src/domain.rs:57-59)
+    PolynomialDegreeTooLarge,
+    /// HIP runtime failure or invalid argument: a bug or a dead device, never a property of the input
+    Runtime(i32),
+}
+
+fn check(rc: c_int) -> Result<(), HipError> {
+    match rc {
+        ffi::BH_OK => Ok(()),
+        ffi::BH_ERR_UNEXPECTED_IDENTITY => Err(HipError::UnexpectedIdentity),
+        ffi::BH_ERR_UNEXPECTED_EOF => Err(HipError::UnexpectedEof),
+        ffi::BH_ERR_DEGREE_TOO_LARGE => Err(HipError::PolynomialDegreeTooLarge),
+        other => Err(HipError::Runtime(other)),
+    }
+}
+
+/// One context per process and GPU == bellman's `Worker` for device work (src/multicore.rs:24-27).
+pub struct Context {
+    raw: *mut ffi::BhCtx,
+    layout: layout::Layout,
+    g1_cache: Mutex<BasesCache<G1Affine>>,
+    g2_cache: Mutex<BasesCache<G2Affine>>,
+}
+// the library is thread-safe and re-entrant per context (include/bellman_hip.h: "one per (process, GPU); thread-safe")
+unsafe impl Send for Context {}
+unsafe impl Sync for Context {}
+
+static CONTEXT: OnceLock<Option<Context>> = OnceLock::new();
+
+/// The process-wide context on device `BELLMAN_HIP_DEVICE` (default 0), or `None` when there is no gfx950
+/// device or the layout probe fails - callers then stay on bellman's CPU path.
+pub fn context() -> Option<&'static Context> {
+    CONTEXT
+        .get_or_init(|| {
+            let layout = layout::Layout::probe()?;
+            let device: c_int = std::env::var("BELLMAN_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+            let mut raw: *mut ffi::BhCtx = ptr::null_mut();
+            let rc = unsafe { ffi::bh_ctx_create(device, &mut raw) };
+            if rc != ffi::BH_OK || raw.is_null() {
+                return None;
+            }
+            Some(Context { raw, layout, g1_cache: Mutex::new(BasesCache::new()), g2_cache: Mutex::new(BasesCache::new()) })
+        })
+        .as_ref()
+}
+
+impl Context {
+    /// `Worker::log_num_threads` analogue (src/multicore.rs:29-31): log2 of the CU count
+    pub fn log_num_cus(&self) -> u32 {
+        unsafe { ffi::bh_ctx_log_num_cus(self.raw) }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident copies of `Arc<Vec<Affine>>` (the CRS queries, groth16/src/lib.rs:443-473: the same Arc is
+// handed out for every proof).  Keyed by the vector's address and length; a `Weak` detects that the Arc died
+// and its address was reused, in which case the stale device copy is dropped and the vector uploaded again.
+// ------------------------------------------------------------------------------------------------
+struct CachedBases<A> {
+    owner: Weak<Vec<A>>,
+    dev: *mut ffi::BhBases,
+}
+struct BasesCache<A> {
+    map: HashMap<(usize, usize), CachedBases<A>>,
+}
+impl<A> BasesCache<A> {
+    fn new() -> Self {
+        BasesCache { map: HashMap::new() }
+    }
+}
+
+impl Context {
+    fn bases_for<A>(
+        &self,
+        cache: &Mutex<BasesCache<A>>,
+        group: c_int,
+        pl: layout::PointLayout,
+        v: &Arc<Vec<A>>,
+    ) -> Result<*const ffi::BhBases, HipError> {
+        let key = (Arc::as_ptr(v) as usize, v.len());
+        let mut c = cache.lock().unwrap();
+        // forget entries whose vector is gone (bounded work: the map holds a handful of CRS queries)
+        let dead: Vec<_> = c.map.iter().filter(|(_, e)| e.owner.strong_count() == 0).map(|(k, _)| *k).collect();
+        for k in dead {
+            if let Some(e) = c.map.remove(&k) {
+                unsafe { ffi::bh_bases_release(self.raw, e.dev) };
+            }
+        }
+        if let Some(e) = c.map.get(&key) {
+            if let Some(alive) = e.owner.upgrade() {
+                if Arc::ptr_eq(&alive, v) {
+                    return Ok(e.dev as *const _);
+                }
+            }
+        }
+        let mut dev: *mut ffi::BhBases = ptr::null_mut();
+        check(unsafe {
+            ffi::bh_bases_register(
+                self.raw,
+                group,
+                v.as_ptr() as *const c_void,
+                v.len(),
+                pl.stride,
+                pl.inf_offset as c_long,
+                &mut dev,
+            )
+        })?;
+        c.map.insert(key, CachedBases { owner: Arc::downgrade(v), dev });
+        Ok(dev as *const _)
+    }
+}
+
+/// Density map of a multiexp as the C ABI wants it: `None` = `FullDensity` (src/multiexp.rs:95-115), else the
+/// raw LSB0 words of `DensityTracker`'s `BitVec<usize, Lsb0>` (`:117-131`) and its length in bits.
+pub enum Density<'a> {
+    Full,
+    Bits { words: &'a [u64], len: usize },
+}
+
+/// An MSM in flight == `Waiter<Result<G, SynthesisError>>` (src/multicore.rs:94-118).
+pub struct MsmJob {
+    raw: *mut ffi::BhMsmJob,
+    group: c_int,
+}
+unsafe impl Send for MsmJob {}
+
+/// Result record of an MSM: affine coordinates in Montgomery form, all-zero = identity.
+pub enum MsmOutput {
+    G1([u64; 12]),
+    G2([u64; 24]),
+}
+
+impl MsmJob {
+    /// Blocks until the job's stream has finished (`Waiter::wait`), returns the affine result record.
+    pub fn wait(self) -> Result<MsmOutput, HipError> {
+        let mut g1 = [0u64; 12];
+        let mut g2 = [0u64; 24];
+        let out = if self.group == ffi::BH_G1 { g1.as_mut_ptr() as *mut c_void } else { g2.as_mut_ptr() as *mut c_void };
+        check(unsafe { ffi::bh_msm_wait(self.raw, out) })?;
+        Ok(if self.group == ffi::BH_G1 { MsmOutput::G1(g1) } else { MsmOutput::G2(g2) })
+    }
+}
+
+impl Context {
+    fn msm(
+        &self,
+        group: c_int,
+        bases: *const ffi::BhBases,
+        skip: usize,
+        scalars: *const c_void,
+        n: usize,
+        fmt: c_int,
+        density: &Density<'_>,
+    ) -> Result<MsmJob, HipError> {
+        let (words, dlen) = match density {
+            Density::Full => (ptr::null(), 0usize),
+            Density::Bits { words, len } => {
+                // multiexp.rs:324-329 asserts this; the library returns BH_ERR_INVALID_ARG, keep the panic
+                assert!(*len == n, "density map and exponents differ in length");
+                (words.as_ptr(), *len)
+            }
+        };
+        let mut raw: *mut ffi::BhMsmJob = ptr::null_mut();
+        check(unsafe { ffi::bh_msm_async(self.raw, bases, skip, scalars, n, fmt, words, dlen, &mut raw) })?;
+        Ok(MsmJob { raw, group })
+    }
+
+    /// `multiexp(pool, (bases, skip), density, exponents)` for G1 with `Scalar`s handed over as they are
+    /// (Montgomery; converted on the device - SURVEY.md 8 f1).
+    pub fn msm_g1(&self, bases: &Arc<Vec<G1Affine>>, skip: usize, scalars: &[Scalar], density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g1_cache, ffi::BH_G1, self.layout.g1, bases)?;
+        self.msm(ffi::BH_G1, dev, skip, scalars.as_ptr() as *const c_void, scalars.len(), ffi::BH_SCALARS_MONT, density)
+    }
+    pub fn msm_g2(&self, bases: &Arc<Vec<G2Affine>>, skip: usize, scalars: &[Scalar], density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g2_cache, ffi::BH_G2, self.layout.g2, bases)?;
+        self.msm(ffi::BH_G2, dev, skip, scalars.as_ptr() as *const c_void, scalars.len(), ffi::BH_SCALARS_MONT, density)
+    }
+    /// Same with canonical little-endian 256-bit scalars: what `Exponent::Bits` holds (src/multiexp.rs:179);
+    /// `Exponent::Zero` / `One` are written as 0 / 1 by the caller.
+    pub fn msm_g1_canonical(&self, bases: &Arc<Vec<G1Affine>>, skip: usize, scalars: &[[u64; 4]], density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g1_cache, ffi::BH_G1, self.layout.g1, bases)?;
+        self.msm(ffi::BH_G1, dev, skip, scalars.as_ptr() as *const c_void, scalars.len(), ffi::BH_SCALARS_CANONICAL, density)
+    }
+    pub fn msm_g2_canonical(&self, bases: &Arc<Vec<G2Affine>>, skip: usize, scalars: &[[u64; 4]], density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g2_cache, ffi::BH_G2, self.layout.g2, bases)?;
+        self.msm(ffi::BH_G2, dev, skip, scalars.as_ptr() as *const c_void, scalars.len(), ffi::BH_SCALARS_CANONICAL, density)
+    }
+
+    /// `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` (src/domain.rs:81-125) on a host vector of
+    /// 2^log_n Montgomery scalars, in place (upload, transform, download).
+    pub fn fft(&self, data: &mut [Scalar], log_n: u32, mode: c_int) -> Result<(), HipError> {
+        assert_eq!(data.len(), 1usize << log_n);
+        check(unsafe { ffi::bh_fft_fr(self.raw, data.as_mut_ptr() as *mut c_void, log_n, mode) })
+    }
+
+    /// The h block of `create_proof` (groth16/src/prover.rs:221-240) in one call: a, b, c evaluations in,
+    /// the m - 1 quotient coefficients out; everything between stays in HBM.
+    pub fn h_poly(&self, a: &[Scalar], b: &[Scalar], c: &[Scalar]) -> Result<Vec<Scalar>, HipError> {
+        assert!(a.len() == b.len() && b.len() == c.len());
+        let mut m = 1usize;
+        while m < a.len() {
+            m *= 2;
+        }
+        let mut out = vec![Scalar::zero(); m.max(2) - 1];
+        let mut h_len = 0usize;
+        check(unsafe {
+            ffi::bh_h_poly_fr(
+                self.raw,
+                a.as_ptr() as *const c_void,
+                b.as_ptr() as *const c_void,
+                c.as_ptr() as *const c_void,
+                a.len(),
+                out.as_mut_ptr() as *mut c_void,
+                &mut h_len,
+            )
+        })?;
+        out.truncate(h_len);
+        Ok(out)
+    }
+}
+
+/// Rebuilds a `G1Affine` from the library's result record (all-zero = identity).  Goes through the
+/// uncompressed encoding so that it depends on no private layout: canonical big-endian x | y.
+pub fn g1_from_record(rec: &[u64; 12]) -> Option<G1Affine> {
+    if rec.iter().all(|&w| w == 0) {
+        return Some(G1Affine::identity());
+    }
+    // the record is Montgomery; a G1Affine with the same object representation is obtained by writing the
+    // coordinates over a generator's (layout probed at start-up: coordinates first, flag byte after them)
+    let ctx = context()?;
+    debug_assert!(ctx.layout.g1.coords_at_zero);
+    let mut p = G1Affine::generator();
+    unsafe { ptr::copy_nonoverlapping(rec.as_ptr() as *const u8, &mut p as *mut G1Affine as *mut u8, 96) };
+    if bool::from(p.is_on_curve()) { Some(p) } else { None }
+}
+pub fn g2_from_record(rec: &[u64; 24]) -> Option<G2Affine> {
+    if rec.iter().all(|&w| w == 0) {
+        return Some(G2Affine::identity());
+    }
+    let ctx = context()?;
+    debug_assert!(ctx.layout.g2.coords_at_zero);
+    let mut p = G2Affine::generator();
+    unsafe { ptr::copy_nonoverlapping(rec.as_ptr() as *const u8, &mut p as *mut G2Affine as *mut u8, 192) };
+    if bool::from(p.is_on_curve()) { Some(p) } else { None }
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+    use ff::Field;
+    use group::{Curve, Group};
+
+    /// the reference's own property (src/multiexp.rs:334-378): multiexp == naive sum; needs a gfx950 device
+    #[test]
+    fn msm_matches_naive() {
+        let Some(ctx) = context() else { return };
+        let mut rng = rand_core::OsRng;
+        let n = 1 << 10;
+        let scalars: Vec<Scalar> = (0..n).map(|_| Scalar::random(&mut rng)).collect();
+        let bases: Vec<G1Affine> = (0..n).map(|_| bls12_381::G1Projective::random(&mut rng).to_affine()).collect();
+        let naive = bases.iter().zip(&scalars).fold(bls12_381::G1Projective::identity(), |acc, (b, s)| acc + b * s);
+        let bases = Arc::new(bases);
+        let got = match ctx.msm_g1(&bases, 0, &scalars, &Density::Full).unwrap().wait().unwrap() {
+            MsmOutput::G1(r) => g1_from_record(&r).unwrap(),
+            _ => unreachable!(),
+        };
+        assert_eq!(got, naive.to_affine());
+    }
+}
