@@ -26,7 +26,7 @@ EXPORTS = [
     "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev", "bh_r1cs_eval_transposed_dev", "bh_fr_powers_dev", "bh_fr_qap_ext_dev",
     "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
-    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_msm_stages",
+    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
 ]
 
@@ -141,6 +141,7 @@ def load():
     lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]
     lib.bh_test_msm_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp]
+    lib.bh_test_g2_k3_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz]
         getattr(lib, name).restype = None

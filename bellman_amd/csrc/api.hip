@@ -1,4 +1,5 @@
 // extern "C" surface of libbellman_hip (declared and documented in include/bellman_hip.h).
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/bellman_hip_test.h"
@@ -22,6 +23,7 @@ int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 ski
                     int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
 hipStream_t msm_job_stream(MsmJobImpl &job);
+void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
                    hipStream_t st);
@@ -106,11 +108,17 @@ __global__ void first_bad_point_kernel(const u32 *status, u64 n, u32 forbid_iden
 
 using namespace bh;
 
+constexpr size_t HOST_PREFIX_POINTS = 64;   // leading records mirrored on the host for the tiny-multiexp path
+constexpr size_t TINY_MSM_MAX = 8;          // multiexps of at most this many terms are answered on the host
+
 struct bh_bases {
   int group;
   void *dev;
   size_t n;
   bool owned;
+  // the first min(n, HOST_PREFIX_POINTS) records on the host: create_proof's `inputs` multiexps have one or
+  // two terms (prover.rs:275-280,296-300,312-316) - a kernel pipeline for them is all launch latency
+  std::vector<unsigned char> host_prefix = {};
   // optional window table (bh_bases_precompute): [W][n] affine records, row 0 = a copy of the bases
   void *table = nullptr;
   WindowTable tab = {0, 0, 0};
@@ -129,6 +137,44 @@ struct DevGuard {
   ~DevGuard() { if (p) (void)hipFree(p); }
   void *release() { void *q = p; p = nullptr; return q; }
 };
+
+// registers the finished device vector: mirrors its leading records on the host (ordered after whatever filled
+// the vector on the context stream)
+static int finish_bases(bh_ctx *ctx, bh_bases *b) {
+  const size_t rec = b->group == BH_G1 ? 96 : 192;
+  const size_t k = b->n < HOST_PREFIX_POINTS ? b->n : HOST_PREFIX_POINTS;
+  b->host_prefix.resize(k * rec);
+  if (k) {
+    BH_HIP_CHECK(hipMemcpyAsync(b->host_prefix.data(), b->dev, k * rec, hipMemcpyDeviceToHost, ctx->c.stream));
+    BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+  }
+  return BH_OK;
+}
+// Base vectors of up to 2^BELLMAN_HIP_TABLE_MAX_LOG2 points (default 12; 0 = never) get their window table at
+// registration: a multiexp over a few thousand terms is a chain of latency-bound steps, and with the table the
+// chain loses the 255-step doubling ladder over the windows (the CRS is registered once per circuit).
+static unsigned auto_table_max_log2() {
+  static const unsigned v = [] {
+    const char *e = getenv("BELLMAN_HIP_TABLE_MAX_LOG2");
+    if (!e || !*e) return 12u;
+    const long x = strtol(e, nullptr, 10);
+    return (unsigned)(x < 0 ? 0 : x > 24 ? 24 : x);
+  }();
+  return v;
+}
+static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
+  bh_bases *b = new bh_bases{group, dev, n, owned};
+  int rc = finish_bases(ctx, b);
+  if (rc != BH_OK) {
+    if (owned && dev) (void)hipFree(dev);
+    delete b;
+    return rc;
+  }
+  const unsigned lg = auto_table_max_log2();
+  if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) (void)bh_bases_precompute(ctx, b, 0);   // best effort
+  *out = b;
+  return BH_OK;
+}
 
 static inline hipStream_t pick_stream(bh_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->c.stream; }
 
@@ -365,8 +411,7 @@ int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n,
     }
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
-  *out = new bh_bases{group, dev.release(), n, true};
-  return BH_OK;
+  return new_bases(ctx, group, dev.release(), n, true, out);
 }
 int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, bh_bases **out) {
   if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
@@ -389,8 +434,7 @@ int bh_bases_register_uncompressed(bh_ctx *ctx, int group, const void *host_byte
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
     if (bad) return BH_ERR_INVALID_ARG;
   }
-  *out = new bh_bases{group, dev.release(), n, true};
-  return BH_OK;
+  return new_bases(ctx, group, dev.release(), n, true, out);
 }
 int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, size_t n, unsigned flags,
                                bh_bases **out, size_t *bad_index) {
@@ -433,8 +477,7 @@ int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, s
       return (first_status & PT_INVALID_MASK) ? BH_ERR_INVALID_POINT : BH_ERR_POINT_AT_INFINITY;
     }
   }
-  *out = new bh_bases{group, dev.release(), n, true};
-  return BH_OK;
+  return new_bases(ctx, group, dev.release(), n, true, out);
 }
 int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host) {
   if (!ctx || !b || first + count > b->n) return BH_ERR_INVALID_ARG;
@@ -456,14 +499,12 @@ int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, 
     BH_HIP_CHECK(hipMemcpyAsync(dev.p, dev_points, n * rec, hipMemcpyDeviceToDevice, ctx->c.stream));
     BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   }
-  *out = new bh_bases{group, dev.release(), n, true};
-  return BH_OK;
+  return new_bases(ctx, group, dev.release(), n, true, out);
 }
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {
-  (void)ctx;
-  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
-  *out = new bh_bases{group, const_cast<void *>(dev_points), n, false};
-  return BH_OK;
+  if (!ctx || !out || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return new_bases(ctx, group, const_cast<void *>(dev_points), n, false, out);
 }
 int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits) {
   if (!ctx || !b) return BH_ERR_INVALID_ARG;
@@ -507,6 +548,69 @@ void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
 size_t bh_bases_len(const bh_bases *b) { return b->n; }
 
 // ---- multiexp -----------------------------------------------------------------------------------
+// multiexp of a handful of terms on the host, at issue time (src/multiexp.rs:210-332 semantics incl. the error
+// precedence of Appendix A item 6).  Returns false when the case is not eligible (bases beyond the mirrored prefix).
+static bool tiny_msm_on_host(const bh_bases *bases, size_t skip, const void *scalars_host, size_t n, int fmt,
+                             const uint64_t *density_host, int *rc_out, unsigned char *result) {
+  const size_t rec = bases->group == BH_G1 ? 96 : 192;
+  const size_t have = bases->host_prefix.size() / rec;
+  if (bases->n > have && skip + n > have) return false;   // a base index could fall outside the mirror
+  memset(result, 0, rec);
+  // pass 1: base index of every dense entry, error conditions
+  fr_t sc[TINY_MSM_MAX];
+  size_t base_of[TINY_MSM_MAX];
+  bool dense[TINY_MSM_MAX];
+  size_t cursor = skip;
+  bool eof = false, ident = false, ident_top = false;
+  // the reference's window size for fewer than 32 terms is 3 (multiexp.rs:318-319): top window = bits [252, 255)
+  const u32 lo_ref = 3 * ((255 + 2) / 3 - 1);
+  for (size_t i = 0; i < n; i++) {
+    dense[i] = density_host ? ((density_host[i >> 6] >> (i & 63)) & 1) : true;
+    if (!dense[i]) continue;
+    base_of[i] = cursor++;
+    memcpy(&sc[i], (const char *)scalars_host + i * 32, 32);
+    if (fmt == BH_SCALARS_MONT) {
+      fe_from_mont(sc[i], sc[i]);
+    } else {
+      for (int k = 0; k < 2; k++) {   // values in [q, 2^256) are taken mod q, as on the device
+        fr_t t;
+        u32 br = 0;
+        for (int w = 0; w < 8; w++) t.l[w] = subb(sc[i].l[w], FrParams::mod(w), br, br);
+        if (!br) sc[i] = t;
+      }
+    }
+    if (base_of[i] >= bases->n) { eof = true; dense[i] = false; continue; }   // every dense entry checks EOF first
+    if (fe_is_zero(sc[i])) continue;                                          // a zero scalar skips its base unseen
+    const unsigned char *b = bases->host_prefix.data() + base_of[i] * rec;
+    bool is_id = true;
+    for (size_t k = 0; k < rec; k++) is_id &= b[k] == 0;
+    if (is_id) {
+      ident = true;
+      bool top = false;
+      for (u32 bit = lo_ref; bit < 256; bit++) top |= (sc[i].l[bit >> 5] >> (bit & 31)) & 1;
+      if (top && !eof) ident_top = true;   // in the top window, before the first EOF entry
+    }
+  }
+  if (eof && ident) { *rc_out = ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF; return true; }
+  if (eof) { *rc_out = BH_ERR_UNEXPECTED_EOF; return true; }
+  if (ident) { *rc_out = BH_ERR_UNEXPECTED_IDENTITY; return true; }
+  // pass 2: the sum
+  alignas(16) unsigned char acc[192], term[192];
+  memset(acc, 0, sizeof acc);
+  fr_t one;
+  fe_zero(one);
+  one.l[0] = 1;
+  for (size_t i = 0; i < n; i++) {
+    if (!dense[i] || fe_is_zero(sc[i])) continue;
+    const unsigned char *b = bases->host_prefix.data() + base_of[i] * rec;
+    if (fe_eq(sc[i], one)) memcpy(term, b, rec); else host_point_mul(bases->group, term, b, &sc[i]);
+    host_point_add(bases->group, acc, acc, term, 1);
+  }
+  memcpy(result, acc, rec);
+  *rc_out = BH_OK;
+  return true;
+}
+
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
                       const bh_msm_opts *o, bh_msm_job **out) {
@@ -521,6 +625,15 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);
   if (!impl) return BH_ERR_HIP;
+  if (n && n <= TINY_MSM_MAX && scalars_on_host && (!density || density_on_host) && !(opts.flags & BH_MSM_NO_SMALL_PATH)) {
+    int trc = BH_OK;
+    alignas(16) unsigned char res[192];
+    if (tiny_msm_on_host(bases, skip, scalars, n, fmt, density, &trc, res)) {
+      msm_job_set_result(*impl, trc, trc == BH_OK ? res : nullptr);
+      *out = new bh_msm_job{impl};
+      return BH_OK;
+    }
+  }
   hipStream_t st = msm_job_stream(*impl);
   const void *sc_dev = scalars;
   const u64 *dn_dev = density;
@@ -613,6 +726,12 @@ int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r, const void *a, const 
   int rc = test_point_add(group, r, a, b, n, ctx->c.stream);
   if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
   return rc;
+}
+int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
+                      const void *b_dev, size_t n) {
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return test_g2_k3(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
 }
 int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
                        uint64_t *pairs_out_host, uint32_t *zstart_out_host) {

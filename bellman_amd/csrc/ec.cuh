@@ -24,6 +24,28 @@ struct alignas(16) XYZZ {
   typename F::T x, y, zz, zzz;
 };
 
+// records in memory (Affine<F::Mem> / XYZZ<F::Mem>) <-> what a lane computes with (identical unless F spreads
+// an element over several lanes, fp2k3.cuh)
+template <class F>
+BH_HD void load_affine(Affine<F> &q, const Affine<typename F::Mem> *p) {
+  F::load(q.x, &p->x);
+  F::load(q.y, &p->y);
+}
+template <class F>
+BH_HD void load_xyzz(XYZZ<F> &q, const XYZZ<typename F::Mem> *p) {
+  F::load(q.x, &p->x);
+  F::load(q.y, &p->y);
+  F::load(q.zz, &p->zz);
+  F::load(q.zzz, &p->zzz);
+}
+template <class F>
+BH_HD void store_xyzz(XYZZ<typename F::Mem> *p, const XYZZ<F> &q) {
+  F::store(&p->x, q.x);
+  F::store(&p->y, q.y);
+  F::store(&p->zz, q.zz);
+  F::store(&p->zzz, q.zzz);
+}
+
 template <class F>
 BH_HD bool aff_is_identity(const Affine<F> &p) {
   return F::is_zero(p.x) && F::is_zero(p.y);

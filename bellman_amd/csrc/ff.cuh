@@ -489,7 +489,11 @@ struct alignas(16) fp2_t {
 // "Field ops" bundles so curve code is written once for G1 (Fp) and G2 (Fp2).
 struct FpOps {
   typedef fp_t T;
+  typedef FpOps Mem;                   // record format in memory == what a lane holds
   static constexpr int WORDS = 12;
+  static constexpr int LANES = 1;      // lanes per group element (3 for the K3 form of Fp2, fp2k3.cuh)
+  BH_HD static void load(T &r, const T *p) { r = *p; }
+  BH_HD static void store(T *p, const T &v) { *p = v; }
   BH_HD static void zero(T &r) { fe_zero(r); }
   BH_HD static void one(T &r) { fe_one(r); }
   BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a); }
@@ -524,7 +528,11 @@ struct FpOps {
 
 struct Fp2Ops {
   typedef fp2_t T;
+  typedef Fp2Ops Mem;
   static constexpr int WORDS = 24;
+  static constexpr int LANES = 1;
+  BH_HD static void load(T &r, const T *p) { r = *p; }
+  BH_HD static void store(T *p, const T &v) { *p = v; }
   BH_HD static void zero(T &r) { fe_zero(r.c0); fe_zero(r.c1); }
   BH_HD static void one(T &r) { fe_one(r.c0); fe_zero(r.c1); }
   BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a.c0) && fpl_is_zero(a.c1); }

@@ -7,6 +7,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include <exception>
+#include <functional>
+
 #include "groth16_internal.hpp"
 
 namespace groth16 {
@@ -141,8 +144,10 @@ void proof_slice_for_tests(size_t n, size_t part, size_t parts, size_t *lo, size
 }
 
 // prover.rs:217-318 + the waits of :339-354: the eight multiexp results (of this part's slices)
+// `while_running` (optional) is host work that needs no multiexp result: it runs after the last job has been
+// issued and before the first wait, i.e. while the GPU is busy
 static void msm_sums(const AssignmentSource &src, Parameters &params, size_t part, size_t parts, MsmSums &out,
-                     ProveTimings *tm) {
+                     ProveTimings *tm, const std::function<void()> *while_running = nullptr) {
   bh_ctx *ctx = params.ctx;
   const double t0 = now_ms();
   const size_t n_cons = src.n_cons;
@@ -197,20 +202,27 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // one multiexp over this part's slice of the scalars: `skip` advances by the number of bases the
   // skipped scalars would have consumed (all of them without a density map, the set bits with one)
   auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
-                   const uint64_t *dens_host, bh_msm_job **job) {
+                   const uint64_t *dens_host, bh_msm_job **job, const void *scalars_host = nullptr) {
     const Slice sl = slice_of(n, part, parts);
     const size_t base_skip = skip + (dens_dev ? popcount_prefix(dens_host, sl.lo) : sl.lo);
+    if (scalars_host && sl.hi - sl.lo <= 8) {
+      // the `inputs` multiexps have one or two terms: handed over with their host scalars, the library
+      // answers them on the host instead of running a kernel pipeline per term
+      check(bh_msm_async(ctx, bases, base_skip, (const char *)scalars_host + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
+                         dens_host ? dens_host + sl.lo / 64 : nullptr, dens_host ? sl.hi - sl.lo : 0, job));
+      return;
+    }
     check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
                            dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
   };
   issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
   // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
-  issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job);
+  issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job, src.inputs);
   issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
   // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
-  issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job);
+  issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job, src.inputs);
   issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
-  issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job);
+  issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job, src.inputs);
   issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
 
   // The seven multiexps above only need the assignments, so they are already running on their own
@@ -237,6 +249,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
+  if (while_running) (*while_running)();
   // every job must be waited on (it owns device resources), even when an earlier one fails
   int rcs[8];
   // prover.rs:339-354 waits in this order: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
@@ -261,16 +274,28 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
 }
 
 // prover.rs:326-360 from the eight multiexp results
-Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, const Fr &s) {
+// prover.rs:320-338: the part of the proof elements that depends on the verifying key and r, s only
+struct ProofBlinding {
+  G1Affine g_a, g_c;
+  G2Affine g_b;
+};
+static ProofBlinding blind_terms(const Parameters &params, const Fr &r, const Fr &s) {
   const VerifyingKey &vk = params.vk;
   if (vk.delta_g1.is_identity() || vk.delta_g2.is_identity())   // subversion check, prover.rs:320-324
     throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
-  G1Affine g_a = add_pts(BH_G1, mul_pt(BH_G1, vk.delta_g1, r), vk.alpha_g1);   // :326-327
-  G2Affine g_b = add_pts(BH_G2, mul_pt(BH_G2, vk.delta_g2, s), vk.beta_g2);    // :328-329
+  ProofBlinding b;
+  b.g_a = add_pts(BH_G1, mul_pt(BH_G1, vk.delta_g1, r), vk.alpha_g1);   // :326-327
+  b.g_b = add_pts(BH_G2, mul_pt(BH_G2, vk.delta_g2, s), vk.beta_g2);    // :328-329
   const Fr rs = r * s;
-  G1Affine g_c = mul_pt(BH_G1, vk.delta_g1, rs);                                // :331-338
-  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.alpha_g1, s));
-  g_c = add_pts(BH_G1, g_c, mul_pt(BH_G1, vk.beta_g1, r));
+  b.g_c = mul_pt(BH_G1, vk.delta_g1, rs);                                // :331-338
+  b.g_c = add_pts(BH_G1, b.g_c, mul_pt(BH_G1, vk.alpha_g1, s));
+  b.g_c = add_pts(BH_G1, b.g_c, mul_pt(BH_G1, vk.beta_g1, r));
+  return b;
+}
+// prover.rs:339-360: fold the multiexp results in
+static Proof finish_proof(const ProofBlinding &b, const MsmSums &m, const Fr &r, const Fr &s) {
+  G1Affine g_a = b.g_a, g_c = b.g_c;
+  G2Affine g_b = b.g_b;
   G1Affine a_answer = add_pts(BH_G1, m.a_in, m.a_aux);                          // :339-343
   g_a = add_pts(BH_G1, g_a, a_answer);
   a_answer = mul_pt(BH_G1, a_answer, s);
@@ -286,6 +311,9 @@ Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, co
   p.a = g_a; p.b = g_b; p.c = g_c;
   return p;
 }
+Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, const Fr &s) {
+  return finish_proof(blind_terms(params, r, s), m, r, s);
+}
 
 void MsmSums::add(const MsmSums &o) {
   a_in = add_pts(BH_G1, a_in, o.a_in); a_aux = add_pts(BH_G1, a_aux, o.a_aux);
@@ -297,8 +325,16 @@ void MsmSums::add(const MsmSums &o) {
 static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   const double t0 = now_ms();
   MsmSums sums;
-  msm_sums(src, params, 0, 1, sums, tm);
-  Proof p = assemble_proof(params, sums, r, s);
+  // the five scalar multiplications that involve only the verifying key, r and s (prover.rs:326-338) run on the
+  // host while the multiexps run on the GPU; a failure there (identity delta) is reported after the jobs drain
+  ProofBlinding blind;
+  std::exception_ptr blind_err;
+  const std::function<void()> overlap = [&] {
+    try { blind = blind_terms(params, r, s); } catch (...) { blind_err = std::current_exception(); }
+  };
+  msm_sums(src, params, 0, 1, sums, tm, &overlap);
+  if (blind_err) std::rethrow_exception(blind_err);
+  Proof p = finish_proof(blind, sums, r, s);
   if (tm) tm->total_ms = (float)(now_ms() - t0);
   return p;
 }

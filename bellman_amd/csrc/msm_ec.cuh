@@ -7,11 +7,42 @@
 #include <algorithm>
 #include <cmath>
 
+#include "fp2k3.cuh"
 #include "host_fp.hpp"
 #include "msm_scalar.cuh"
 #include "msm_types.hpp"
 
 namespace bh {
+
+// ---------------------------------------------------------------------------------------------------------
+// Logical workers.  A kernel below is written for "workers": one thread when a lane holds a whole group
+// element (F::LANES == 1: G1, single-lane G2) or one lane TRIPLE for the K3 form of G2 (fp2k3.cuh), where a
+// wavefront carries PER_WAVE triples - 21, or 16 where shuffle trees want a power of two.  All lanes of a
+// triple see the same worker index and take the same branches (every predicate of the curve code is
+// triple-uniform).
+// ---------------------------------------------------------------------------------------------------------
+template <class F>
+constexpr u32 default_per_wave() { return F::LANES == 3 ? 21u : 64u; }
+template <class F>
+constexpr u32 tree_per_wave() { return F::LANES == 3 ? 16u : 64u; }
+template <class F>
+constexpr u32 workers_per_block(u32 threads, u32 per_wave) { return F::LANES == 1 ? threads : (threads / 64u) * per_wave; }
+
+// false for lanes that carry no worker (lane 63 of a K3 wavefront, lanes beyond PER_WAVE triples)
+template <class F>
+__device__ __forceinline__ bool worker_index(u32 per_wave, u32 &in_block, u32 &global) {
+  if constexpr (F::LANES == 1) {
+    in_block = threadIdx.x;
+    global = blockIdx.x * blockDim.x + threadIdx.x;
+    return true;
+  } else {
+    const u32 t = k3_triple(threadIdx.x & 63u);
+    const u32 wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+    in_block = wave * per_wave + t;
+    global = (blockIdx.x * waves_per_block + wave) * per_wave + t;
+    return t < per_wave;
+  }
+}
 
 // Only launched when both EOF and an identity were seen: decides which error the reference
 // would report (the highest window's, i.e. the first failing element of the top window;
@@ -65,15 +96,18 @@ __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lan
 // is the difference between spilling at one wave per SIMD and fitting two.
 template <class F, bool LDS_ACC>
 __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const u32 *zstart,
-                                                             const Affine<F> *bases, XYZZ<F> *pts,
-                                                             XYZZ<F> *head, XYZZ<F> *tail, u32 n, u32 c,
-                                                             u32 K, u32 chunks_per_window, ErrFlags *err) {
+                                                             const Affine<typename F::Mem> *bases,
+                                                             XYZZ<typename F::Mem> *pts, XYZZ<typename F::Mem> *head,
+                                                             XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
+                                                             u32 chunks_per_window, ErrFlags *err) {
+  static_assert(!LDS_ACC || F::LANES == 1, "the LDS accumulator belongs to the single-lane kernels");
   const u32 w = blockIdx.y;
-  const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 in_block, lane;
+  if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
   const u64 *src = pairs + (u64)w * n;
   ChunkView v;
   if (lane >= chunks_per_window || !chunk_view(src, n, zstart[w], lane, K, v)) return;
-  XYZZ<F> *bucket = pts + ((u64)w << (c - 1)) - 1;   // bucket[d], d = |digit| in [1, 2^(c-1)]
+  XYZZ<typename F::Mem> *bucket = pts + ((u64)w << (c - 1)) - 1;   // bucket[d], d = |digit| in [1, 2^(c-1)]
   const u64 slot = (u64)w * chunks_per_window + lane;
   __shared__ XYZZ<F> lds_acc[LDS_ACC ? 128 : 1];
   XYZZ<F> reg_acc;
@@ -85,18 +119,17 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
     const u64 e = src[p];
     const u32 d = (u32)(e >> 32);
     if (d != cur) {   // bucket `cur` ends inside this chunk
-      if (cur == v.d_first && v.head_partial) head[slot] = acc; else bucket[cur] = acc;
+      store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
       xyzz_set_identity(acc);
       cur = d;
     }
-    Affine<F> q = bases[(u32)e & 0x7fffffffu];
+    Affine<F> q;
+    load_affine<F>(q, bases + ((u32)e & 0x7fffffffu));
     if (aff_is_identity(q)) { saw_identity = true; continue; }
     if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
     xyzz_madd(acc, q);
   }
-  if (cur == v.d_first && v.head_partial) head[slot] = acc;
-  else if (v.tail_partial) tail[slot] = acc;
-  else bucket[cur] = acc;
+  store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : v.tail_partial ? &tail[slot] : &bucket[cur], acc);
   if (saw_identity) atomicOr(&err->ident, 1u);
 }
 
@@ -106,12 +139,15 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
 // msm_merge_long_kernel so that no lane ever executes a long serial chain of point additions.
 // `walk` = chunks an owner folds serially (a few times the average run length).
 template <class F>
-__global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart, XYZZ<F> *pts,
-                                                               const XYZZ<F> *head, const XYZZ<F> *tail, u32 n,
-                                                               u32 c, u32 K, u32 chunks_per_window, u32 walk,
-                                                               LongRun *long_runs, u32 max_long, ErrFlags *err) {
+__global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart,
+                                                               XYZZ<typename F::Mem> *pts,
+                                                               const XYZZ<typename F::Mem> *head,
+                                                               const XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
+                                                               u32 chunks_per_window, u32 walk, LongRun *long_runs,
+                                                               u32 max_long, ErrFlags *err) {
   const u32 w = blockIdx.y;
-  const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 in_block, lane;
+  if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
   const u64 *src = pairs + (u64)w * n;
   const u32 z = zstart[w];
   ChunkView v;
@@ -120,12 +156,14 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
   if (v.head_partial && v.d_first == v.d_last) return;   // a middle piece of a long bucket
   const u32 d = v.d_last;
   const u64 slot0 = (u64)w * chunks_per_window;
-  XYZZ<F> acc = tail[slot0 + lane];
+  XYZZ<F> acc;
+  load_xyzz<F>(acc, tail + slot0 + lane);
   bool ended = false;
   for (u32 j = lane + 1; j < chunks_per_window && j <= lane + walk; j++) {
     ChunkView u;
     if (!chunk_view(src, n, z, j, K, u) || u.d_first != d) { ended = true; break; }
-    XYZZ<F> o = head[slot0 + j], r;
+    XYZZ<F> o, r;
+    load_xyzz<F>(o, head + slot0 + j);
     xyzz_add(r, acc, o);
     acc = r;
     if (u.d_last != d || !u.tail_partial) { ended = true; break; }   // the bucket ended in chunk j
@@ -134,25 +172,28 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
     // still running after `walk` chunks: hand the whole run to the workgroup-parallel merge
     ChunkView u;
     if (chunk_view(src, n, z, lane + walk + 1, K, u) && u.d_first == d) {
-      const u32 slot = atomicAdd(&err->nlong, 1u);
-      if (slot < max_long) { LongRun lr = {w, lane, d}; long_runs[slot] = lr; }
+      if (F::LANES == 1 || k3_role() == 0) {   // one entry per worker
+        const u32 slot = atomicAdd(&err->nlong, 1u);
+        if (slot < max_long) { LongRun lr = {w, lane, d}; long_runs[slot] = lr; }
+      }
       return;
     }
   }
-  pts[((u64)w << (c - 1)) + d - 1] = acc;
+  store_xyzz<F>(&pts[((u64)w << (c - 1)) + d - 1], acc);
 }
 
-// shuffle-based tree reduction of per-lane points over groups of G consecutive lanes
+// shuffle-based tree reduction of per-worker points over groups of G consecutive workers of one wavefront;
+// `sub` = the worker's index inside its group
 template <class F>
-__device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G) {
+__device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub) {
   constexpr int NW = sizeof(XYZZ<F>) / 4;
   for (u32 off = G >> 1; off >= 1; off >>= 1) {
     XYZZ<F> o;
     u32 *dst = reinterpret_cast<u32 *>(&o);
     const u32 *srcw = reinterpret_cast<const u32 *>(&acc);
 #pragma unroll
-    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(srcw[i], off);
-    if ((threadIdx.x & (G - 1)) < off) {
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(srcw[i], off * F::LANES);
+    if (sub < off) {
       XYZZ<F> r;
       xyzz_add(r, acc, o);
       acc = r;
@@ -164,20 +205,26 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G) {
 constexpr u32 LONG_THREADS = 512;
 template <class F>
 __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 *pairs, const u32 *zstart,
-                                                                      XYZZ<F> *pts, const XYZZ<F> *head,
-                                                                      const XYZZ<F> *tail, u32 n, u32 c, u32 K,
-                                                                      u32 chunks_per_window, const LongRun *long_runs,
-                                                                      u32 max_long, const ErrFlags *err) {
-  __shared__ XYZZ<F> wave_part[LONG_THREADS / 64];
+                                                                      XYZZ<typename F::Mem> *pts,
+                                                                      const XYZZ<typename F::Mem> *head,
+                                                                      const XYZZ<typename F::Mem> *tail, u32 n, u32 c,
+                                                                      u32 K, u32 chunks_per_window,
+                                                                      const LongRun *long_runs, u32 max_long,
+                                                                      const ErrFlags *err) {
+  constexpr u32 PW = tree_per_wave<F>(), NWAVES = LONG_THREADS / 64, NWORK = workers_per_block<F>(LONG_THREADS, PW);
+  __shared__ XYZZ<F> wave_part[NWAVES][F::LANES];
   __shared__ u32 s_last;
   u32 nlong = err->nlong;
   if (nlong > max_long) nlong = max_long;
-  const u32 tid = threadIdx.x;
+  u32 wid, gid;
+  const bool live = worker_index<F>(PW, wid, gid);   // idle lanes stay for the barriers
+  const u32 wave = threadIdx.x >> 6, t_in_wave = wid - wave * PW;
+  const u32 role = F::LANES == 1 ? 0u : k3_role();
   for (u32 e = blockIdx.x; e < nlong; e += gridDim.x) {
     const LongRun lr = long_runs[e];
     const u64 *src = pairs + (u64)lr.w * n;
     const u32 z = zstart[lr.w];
-    if (tid == 0) {   // last sorted position holding digit d -> last chunk of the run
+    if (threadIdx.x == 0) {   // last sorted position holding digit d -> last chunk of the run
       u32 lo = z + lr.lane * K, hi = n;   // first index with digit > d
       while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
@@ -190,19 +237,22 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
     const u64 slot0 = (u64)lr.w * chunks_per_window;
     XYZZ<F> acc;
     xyzz_set_identity(acc);
-    if (tid == 0) acc = tail[slot0 + lr.lane];
-    for (u32 j = lr.lane + 1 + tid; j <= l1; j += LONG_THREADS) {
-      XYZZ<F> o = head[slot0 + j], r;
-      xyzz_add(r, acc, o);
-      acc = r;
+    if (live) {
+      if (wid == 0) load_xyzz<F>(acc, tail + slot0 + lr.lane);
+      for (u32 j = lr.lane + 1 + wid; j <= l1; j += NWORK) {
+        XYZZ<F> o, r;
+        load_xyzz<F>(o, head + slot0 + j);
+        xyzz_add(r, acc, o);
+        acc = r;
+      }
+      group_reduce_points<F>(acc, PW, t_in_wave);
+      if (t_in_wave == 0) wave_part[wave][role] = acc;
     }
-    group_reduce_points<F>(acc, 64);
-    if ((tid & 63) == 0) wave_part[tid >> 6] = acc;
     __syncthreads();
-    if (tid < 64) {
-      if (tid < LONG_THREADS / 64) acc = wave_part[tid]; else xyzz_set_identity(acc);
-      group_reduce_points<F>(acc, LONG_THREADS / 64);
-      if (tid == 0) pts[((u64)lr.w << (c - 1)) + lr.d - 1] = acc;
+    if (wave == 0 && live) {
+      if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
+      group_reduce_points<F>(acc, NWAVES, t_in_wave);
+      if (t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
     }
     __syncthreads();
   }
@@ -216,10 +266,10 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
 //   SUM_BITS   : g = (outer, k):     elements in[(outer << group_shift) + i], i < count, bit k of i set
 template <class F>
 struct SumJob {
-  const XYZZ<F> *in;
-  XYZZ<F> *out;
+  const XYZZ<typename F::Mem> *in;
+  XYZZ<typename F::Mem> *out;
   SumDesc d;
-  u32 nblocks;   // 64-lane blocks assigned to this job
+  u32 nblocks;   // one-wavefront blocks assigned to this job
 };
 // up to three independent reductions per launch (rows + columns, then the bit-sum sets and the
 // plain window totals): they are latency-bound, so sharing a launch lets the hardware overlap them.
@@ -228,36 +278,41 @@ struct SumJobs {
   SumJob<F> j[3];
 };
 template <class F>
-__global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
+__global__ __launch_bounds__(64, F::LANES == 3 ? 2 : 1) void msm_sum_kernel(SumJobs<F> jobs) {
   u32 blk = blockIdx.x;
   u32 which = 0;
   if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
   const SumDesc d = jobs.j[which].d;
-  const XYZZ<F> *in = jobs.j[which].in;
-  XYZZ<F> *out = jobs.j[which].out;
+  const XYZZ<typename F::Mem> *in = jobs.j[which].in;
+  XYZZ<typename F::Mem> *out = jobs.j[which].out;
+  constexpr u32 PW = tree_per_wave<F>();
+  u32 t, gid;
+  const bool live = worker_index<F>(PW, t, gid);   // one wavefront per block: t = worker inside the wavefront
   const u32 G = d.lanes;
-  const u32 g = (blk * 64 + threadIdx.x) / G;
-  const u32 sub = threadIdx.x & (G - 1);
-  // G2: partial sums live in LDS slots (an XYZZ<Fp2> accumulator is 96 VGPRs) and the tree reads the
-  // partner's slot directly; G1 keeps registers + shuffles
-  constexpr bool LDS_ACC = (F::WORDS == 24);
+  const u32 g = (blk * PW + t) / G;
+  const u32 sub = t & (G - 1);
+  // single-lane G2: partial sums live in LDS slots (an XYZZ<Fp2> accumulator is 96 VGPRs) and the tree reads
+  // the partner's slot directly; G1 and K3-form G2 keep registers + shuffles
+  constexpr bool LDS_ACC = (F::LANES == 1 && F::WORDS == 24);
   __shared__ XYZZ<F> lds_acc[LDS_ACC ? 64 : 1];
   XYZZ<F> reg_acc;
   XYZZ<F> &acc = LDS_ACC ? lds_acc[threadIdx.x] : reg_acc;
   xyzz_set_identity(acc);
-  if (g < d.groups) {
+  if (live && g < d.groups) {
     const u32 outer = g / d.inner, in_idx = g % d.inner;
-    const XYZZ<F> *base = in + ((u64)outer << d.group_shift);
+    const XYZZ<typename F::Mem> *base = in + ((u64)outer << d.group_shift);
     if (d.mode == SUM_STRIDED) {
-      for (u32 t = sub; t < d.count; t += G) {
-        XYZZ<F> o = base[(u64)in_idx * d.istride + (u64)t * d.stride], r;
+      for (u32 k = sub; k < d.count; k += G) {
+        XYZZ<F> o, r;
+        load_xyzz<F>(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
         xyzz_add(r, acc, o);
         acc = r;
       }
-    } else {  // SUM_BITS: in_idx = bit position k
+    } else {  // SUM_BITS: in_idx = bit position
       for (u32 i = sub; i < d.count; i += G) {
         if ((i >> in_idx) & 1) {
-          XYZZ<F> o = base[i], r;
+          XYZZ<F> o, r;
+          load_xyzz<F>(o, base + i);
           xyzz_add(r, acc, o);
           acc = r;
         }
@@ -274,9 +329,9 @@ __global__ __launch_bounds__(64) void msm_sum_kernel(SumJobs<F> jobs) {
       }
     }
   } else {
-    group_reduce_points<F>(acc, G);
+    group_reduce_points<F>(acc, G, sub);
   }
-  if (sub == 0 && g < d.groups) out[g] = acc;
+  if (live && sub == 0 && g < d.groups) store_xyzz<F>(&out[g], acc);
 }
 
 // ============================================================================================
@@ -377,61 +432,69 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // ============================================================================================
 // host orchestration
 // ============================================================================================
+// F = the ops bundle the kernels compute with (FpOps for G1; Fp2K3Ops, or single-lane Fp2Ops, for G2);
+// records in memory are Affine / XYZZ over F::Mem.
 template <class F>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
                        u64 n, int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
+  typedef typename F::Mem M;
+  typedef XYZZ<M> Pt;
+  constexpr bool G2 = (M::WORDS == 24);
   Context &c = *job.ctx;
   hipStream_t st = job.stream;
   // a window table is used when it exists, nobody forces another window size, and its row indices
   // fit the 31-bit base field of a pair
   const bool use_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c) &&
                          (u64)table->W * table->stride < ((u64)1 << 31) && (u64)table->W * n < ((u64)1 << 32);
-  const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, F::WORDS == 24, c.num_cus)
-                              : make_plan(n, opts.c, opts.chunk, F::WORDS == 24);
-  const bool lds_acc = (opts.flags & BH_MSM_ACC_LDS) ? true : (opts.flags & BH_MSM_ACC_REGISTERS) ? false : (F::WORDS == 24);
+  const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, G2, c.num_cus)
+                              : make_plan(n, opts.c, opts.chunk, G2);
+  // running bucket sum in LDS: only meaningful for the single-lane G2 kernel (its default), or when forced
+  const bool lds_acc = F::LANES == 1 && ((opts.flags & BH_MSM_ACC_LDS) ? true : (opts.flags & BH_MSM_ACC_REGISTERS) ? false : G2);
   job.plan = p;
   if ((u64)p.Wd * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
   if (n_bases >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;        // base index shares its word with the sign bit
-  auto alloc = [&](size_t bytes) -> void * {
-    void *ptr = c.pool.acquire(bytes);
-    if (ptr) job.dev_allocs.push_back(ptr);
-    return ptr;
-  };
+
+  // ---- one workspace block per job, carved into its buffers (one pool round trip, one memset) ----------
   const u64 npairs = (u64)p.Wd * n;
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
-  MsmBuffers b;
-  b.pairs_a = (u64 *)alloc(npairs * 8);
-  b.pairs_b = (u64 *)alloc(npairs * 8);
-  b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
-  b.zstart = (u32 *)alloc((u64)p.W * 4);
   const u64 nslots = (u64)p.W * p.chunks_per_window;
-  XYZZ<F> *pts = (XYZZ<F> *)alloc((u64)p.NB * sizeof(XYZZ<F>));
-  XYZZ<F> *head = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
-  XYZZ<F> *tail = (XYZZ<F> *)alloc(nslots * sizeof(XYZZ<F>));
   // serial walk bound: 4x the average number of chunks per bucket, at least 8
   const u32 walk = std::max<u32>(8, 4 * ((p.n >> (p.c - 1)) / p.chunk + 1));
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
-  LongRun *long_runs = (LongRun *)alloc((u64)max_long * sizeof(LongRun));
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
-  XYZZ<F> *rowcol = (XYZZ<F> *)alloc((u64)p.W * (H + Lw) * sizeof(XYZZ<F>));
-  // per window: (c-1) bit sums U[w][p] followed by W plain totals T[w]
-  XYZZ<F> *bits = (XYZZ<F> *)alloc((u64)p.W * p.c * sizeof(XYZZ<F>));
-  b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
-  b.word_prefix = nullptr;
   const u64 nwords = (n + 63) / 64;
-  if (density_dev) b.word_prefix = (u32 *)alloc((nwords + 1) * 4);
-  if (!b.pairs_a || !b.pairs_b || !b.counts || !b.scan_tmp || !b.zstart || !pts || !head || !tail || !long_runs || !rowcol ||
-      !bits || !b.err || (density_dev && !b.word_prefix))
-    return BH_ERR_HIP;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
+  // zero-initialised region first: status words, then the buckets (all-zero XYZZ == identity)
+  const size_t o_err = carve(sizeof(ErrFlags));
+  const size_t o_pts = carve((u64)p.NB * sizeof(Pt));
+  const size_t zero_bytes = off;
+  const size_t o_pairs_a = carve(npairs * 8), o_pairs_b = carve(npairs * 8);
+  const size_t o_counts = carve(ncounts * 4), o_scan = carve(scan_tmp_elems(ncounts) * 4), o_zstart = carve((u64)p.W * 4);
+  const size_t o_head = carve(nslots * sizeof(Pt)), o_tail = carve(nslots * sizeof(Pt));
+  const size_t o_long = carve((u64)max_long * sizeof(LongRun));
+  const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
+  // per window: (c-1) bit sums U[w][p] followed by W plain totals T[w]
+  const size_t o_bits = carve((u64)p.W * p.c * sizeof(Pt));
+  const size_t o_prefix = density_dev ? carve((nwords + 1) * 4) : 0;
+  char *ws = (char *)c.pool.acquire(off);
+  if (!ws) return BH_ERR_HIP;
+  job.dev_allocs.push_back(ws);
+  MsmBuffers b;
+  b.err = (ErrFlags *)(ws + o_err);
+  b.pairs_a = (u64 *)(ws + o_pairs_a); b.pairs_b = (u64 *)(ws + o_pairs_b);
+  b.counts = (u32 *)(ws + o_counts); b.scan_tmp = (u32 *)(ws + o_scan); b.zstart = (u32 *)(ws + o_zstart);
+  b.word_prefix = density_dev ? (u32 *)(ws + o_prefix) : nullptr;
+  Pt *pts = (Pt *)(ws + o_pts), *head = (Pt *)(ws + o_head), *tail = (Pt *)(ws + o_tail);
+  LongRun *long_runs = (LongRun *)(ws + o_long);
+  Pt *rowcol = (Pt *)(ws + o_rowcol), *bits = (Pt *)(ws + o_bits);
   ErrFlags *err = b.err;
   job.err_dev = err;
   job.scalars_dev = scalars_dev; job.density_dev = density_dev; job.word_prefix = b.word_prefix;
   job.bases_dev = bases_dev; job.skip = skip; job.n_bases = n_bases; job.fmt = fmt;
 
   BH_HIP_CHECK(hipEventRecord(job.ev_begin, st));
-  BH_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(ErrFlags), st));
-  BH_HIP_CHECK(hipMemsetAsync(pts, 0, (u64)p.NB * sizeof(XYZZ<F>), st));   // all-zero XYZZ == identity
+  BH_HIP_CHECK(hipMemsetAsync(ws, 0, zero_bytes, st));
   const u64 *sorted = nullptr;
   {
     int rc = msm_run_stages(p, b, scalars_dev, fmt, density_dev, skip, n_bases, st, &sorted);
@@ -440,13 +503,20 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
   // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
   {
-    const dim3 grid((p.chunks_per_window + 127) / 128, p.W);
-    if (lds_acc)
-      hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart,
-                         (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
-    else
-      hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart,
-                         (const Affine<F> *)bases_dev, pts, head, tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
+    const dim3 grid((p.chunks_per_window + wpb - 1) / wpb, p.W);
+    const Affine<M> *bases = (const Affine<M> *)bases_dev;
+    if constexpr (F::LANES == 1) {
+      if (lds_acc)
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+      else
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    } else {
+      hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
+                         tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+    }
     BH_HIP_CHECK(hipGetLastError());
     BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
     hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
@@ -457,28 +527,30 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
-  // G lanes per output chosen so that each launch is about one wavefront per SIMD.
-  XYZZ<F> *rows = rowcol, *cols = rowcol + (u64)p.W * H;
-  // lanes per output: minimise (serial adds per lane + tree depth) x (waves per SIMD, at least 1);
+  // G workers per output chosen so that each launch is about one wavefront per SIMD.
+  Pt *rows = rowcol, *cols = rowcol + (u64)p.W * H;
+  constexpr u32 PW = tree_per_wave<F>();   // workers per one-wavefront block of the sum kernel
+  // workers per output: minimise (serial adds per worker + tree depth) x (waves per SIMD, at least 1);
   // these kernels are latency-bound chains of point additions, not throughput-bound.
   auto pick_lanes = [&](u32 groups, u32 count) {
     const double simds = (double)c.num_cus * 4;
     u32 best = 1;
     double best_cost = 1e30;
-    for (u32 g = 1, lg = 0; g <= 64; g <<= 1, lg++) {
+    for (u32 g = 1, lg = 0; g <= PW; g <<= 1, lg++) {
       if (g > count && g > 1) break;
       const double steps = (double)((count + g - 1) / g) + lg;
-      const double waves = (double)groups * g / 64.0;
+      const double waves = (double)groups * g / (double)PW;
       const double cost = steps * std::max(1.0, waves / simds);
       if (cost < best_cost) { best_cost = cost; best = g; }
     }
     return best;
   };
-  auto make_job = [&](const XYZZ<F> *in, XYZZ<F> *out, SumDesc d) {
+  auto blocks_for = [&](u32 groups, u32 lanes) { return (u32)(((u64)groups * lanes + PW - 1) / PW); };
+  auto make_job = [&](const Pt *in, Pt *out, SumDesc d) {
     SumJob<F> j;
     d.lanes = d.groups ? pick_lanes(d.groups, d.mode == SUM_BITS ? std::max(1u, d.count / 2) : d.count) : 1;
     j.in = in; j.out = out; j.d = d;
-    j.nblocks = (u32)(((u64)d.groups * d.lanes + 63) / 64);
+    j.nblocks = blocks_for(d.groups, d.lanes);
     return j;
   };
   {
@@ -488,11 +560,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
     SumJobs<F> js;
     js.j[0] = make_job(pts, rows, dr); js.j[1] = make_job(pts, cols, dc); js.j[2] = js.j[1]; js.j[2].nblocks = 0;
-    if (F::WORDS == 24) {
-      // G2 (one resident wavefront per SIMD, so sharing a SIMD doubles every step): the two jobs share one
-      // launch, choose their lane counts jointly - the launch lasts as long as its longest chain,
-      // stretched by how many wavefronts each SIMD has to interleave.  (Measured on G1, where two
-      // wavefronts per SIMD interleave almost for free, the per-job choice above is better.)
+    if (G2 && F::LANES == 1) {
+      // single-lane G2 (one resident wavefront per SIMD, so sharing a SIMD doubles every step): the two jobs share
+      // one launch, choose their lane counts jointly - the launch lasts as long as its longest chain, stretched by
+      // how many wavefronts each SIMD has to interleave.  (With two wavefronts per SIMD - G1, K3-form G2 - they
+      // interleave almost for free and the per-job choice above is better.)
       const double simds = (double)c.num_cus * 4;
       double best = 1e30;
       u32 best_r = js.j[0].d.lanes, best_c = js.j[1].d.lanes;
@@ -503,8 +575,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
           const double cost = steps * std::max(1.0, waves / simds);
           if (cost < best) { best = cost; best_r = gr; best_c = gc; }
         }
-      js.j[0].d.lanes = best_r; js.j[0].nblocks = (u32)(((u64)dr.groups * best_r + 63) / 64);
-      js.j[1].d.lanes = best_c; js.j[1].nblocks = (u32)(((u64)dc.groups * best_c + 63) / 64);
+      js.j[0].d.lanes = best_r; js.j[0].nblocks = blocks_for(dr.groups, best_r);
+      js.j[1].d.lanes = best_c; js.j[1].nblocks = blocks_for(dc.groups, best_c);
     }
     hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
@@ -528,7 +600,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   }
   BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
   // results to pinned host memory
-  const size_t bits_bytes = (size_t)p.W * p.c * sizeof(XYZZ<F>);
+  const size_t bits_bytes = (size_t)p.W * p.c * sizeof(Pt);
   job.host_result_bytes = bits_bytes + sizeof(ErrFlags);
   if (job.host_result_bytes > job.res.pinned_bytes) return BH_ERR_INVALID_ARG;
   BH_HIP_CHECK(hipMemcpyAsync(job.host_result, bits, bits_bytes, hipMemcpyDeviceToHost, st));
@@ -677,12 +749,57 @@ static void generic_point_mul(void *r, const void *a, const void *k) {
   xyzz_to_affine(res, acc);
   memcpy(r, &res, sizeof res);
 }
+// [k] a with signed 4-bit windows: 8 precomputed multiples, 256 doublings, at most 64 additions (the plain
+// double-and-add above costs ~128 more additions); the serial tails of create_proof (prover.rs:326-354) and the
+// tiny-multiexp path run on the host, where this is ~2x faster
+template <class F>
+static void windowed_point_mul(void *r, const void *a, const u32 *k) {
+  Affine<F> base, res;
+  memcpy(&base, a, sizeof base);
+  u32 kw[9];
+  memcpy(kw, k, 32);
+  kw[8] = 0;
+  bool zero = true;
+  for (int i = 0; i < 8; i++) zero &= kw[i] == 0;
+  if (aff_is_identity(base) || zero) {
+    memset(r, 0, sizeof res);
+    return;
+  }
+  XYZZ<F> tab[8];   // (i + 1) * base
+  xyzz_from_affine(tab[0], base);
+  xyzz_dbl(tab[1], tab[0]);
+  for (int i = 2; i < 8; i++) xyzz_add(tab[i], tab[i - 1], tab[0]);
+  // signed digits d_j in [-8, 8], low to high with carry; 65 digits cover a 256-bit scalar + carry
+  int digits[65];
+  u32 carry = 0;
+  for (int j = 0; j < 65; j++) {
+    u32 v = (j < 64 ? (kw[j >> 3] >> ((j & 7) * 4)) & 15u : 0u) + carry;
+    carry = 0;
+    int d = (int)v;
+    if (v > 8) { d = (int)v - 16; carry = 1; }
+    digits[j] = d;
+  }
+  XYZZ<F> acc, t;
+  xyzz_set_identity(acc);
+  for (int j = 64; j >= 0; j--) {
+    for (int b = 0; b < 4; b++) { xyzz_dbl(t, acc); acc = t; }
+    const int d = digits[j];
+    if (d) {
+      XYZZ<F> q = tab[(d < 0 ? -d : d) - 1];
+      if (d < 0) F::neg(q.y, q.y);
+      xyzz_add(t, acc, q);
+      acc = t;
+    }
+  }
+  xyzz_to_affine(res, acc);
+  memcpy(r, &res, sizeof res);
+}
 // fast path: 64-bit-limb host arithmetic
 template <class FD> static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
   generic_point_add<typename HostOf<FD>::type>(r, a, b, n);
 }
 template <class FD> static void host_point_mul_t(void *r, const void *a, const u32 *k) {
-  generic_point_mul<typename HostOf<FD>::type>(r, a, k);
+  windowed_point_mul<typename HostOf<FD>::type>(r, a, k);
 }
 // the DEVICE headers compiled for the host (32-bit limbs): CPU-side unit tests of ff.cuh / ec.cuh
 template <class F> static void devhdr_point_add_t(void *r, const void *a, const void *b, u64 n) {
@@ -690,11 +807,15 @@ template <class F> static void devhdr_point_add_t(void *r, const void *a, const 
 }
 template <class F> static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) { generic_point_mul<F>(r, a, k); }
 
-#define BH_INSTANTIATE_MSM(SUFFIX, OPS)                                                                       \
+// OPS = the record format in memory (FpOps / Fp2Ops); KOPS = what the MSM kernels compute with; ALT = a second
+// kernel bundle selected by `ALT_FLAG` in bh_msm_opts.flags (the single-lane G2 kernels, kept for comparison)
+#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, ALT_FLAG)                                                  \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
                            const void *scalars_dev, u64 n, int fmt, const u64 *density_dev,                 \
                            const MsmOpts &opts, const WindowTable *table) {                                  \
-    return msm_enqueue<OPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);    \
+    if (opts.flags & (ALT_FLAG))                                                                              \
+      return msm_enqueue<ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table); \
+    return msm_enqueue<KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
   }                                                                                                           \
   int window_table_##SUFFIX(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {                           \
     return window_table_t<OPS>(table_dev, n, c, W, st);                                                       \

@@ -64,6 +64,9 @@ struct MsmJobImpl {
   JobResources res;
   int early_rc = BH_OK;               // immediate result (n == 0 etc.)
   bool trivial = false;
+  // a job answered on the host at issue time (a handful of terms, api.hip): the affine record to hand out
+  bool has_result = false;
+  alignas(16) unsigned char result[192];
   // inputs needed again by the (rare) error-resolution pass
   const void *scalars_dev = nullptr;
   const u64 *density_dev = nullptr;
@@ -100,6 +103,7 @@ int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int
 int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
 int test_point_add_g1(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 int test_point_add_g2(void *r, const void *a, const void *b, u64 n, hipStream_t st);
+int test_g2_k3(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n);   // msm_g2.hip
 // per-point status word of the uncompressed-point loader (api.hip decode kernel + point_check_kernel)
 enum PointStatus : u32 {
   PT_COMPRESSED = 1,        // compression flag set on an uncompressed point

@@ -91,6 +91,103 @@ def test_point_add_on_device(worker, group):
     assert out.shape[1] == w and not out[3].any() and not out[4].any()
 
 
+def test_g2_k3_group_law(worker):
+    """The lane-triple (K3) form of Fp2 the G2 MSM kernels compute in (csrc/fp2k3.cuh): general addition, mixed
+    addition and doubling of G2 points, including P + P, P + (-P) and the identity on either side, against the
+    oracle's group law.  70 points: more than one wavefront of 21 triples, and a ragged tail."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 70
+    A = cref.gen_bases(2, n, a=5, b=3)
+    B = cref.gen_bases(2, n, a=7, b=11)
+    B[0] = A[0]                                   # doubling through the addition paths
+    B[1] = 0                                      # + identity
+    A[2] = 0                                      # identity +
+    B[3] = cref.point_mul(2, A[3], Q - 1)         # P + (-P)
+    A[4] = 0
+    B[4] = 0
+    B[n - 1] = A[n - 1]
+    dA, dB = _dev(worker, A), _dev(worker, B)
+    outs = [np.zeros((n, 24), dtype=np.uint64) for _ in range(3)]
+    assert lib.bh_test_g2_k3_dev(worker.ctx, _p(outs[0]), _p(outs[1]), _p(outs[2]), dA, dB, n) == 0
+    want_add = np.stack([cref.point_add(2, A[i], B[i]) for i in range(n)])
+    want_dbl = np.stack([cref.point_add(2, A[i], A[i]) for i in range(n)])
+    assert np.array_equal(outs[0], want_add)
+    assert np.array_equal(outs[1], want_add)      # mixed addition: same sums (identity B leaves A)
+    assert np.array_equal(outs[2], want_dbl)
+    assert not outs[0][3].any() and not outs[0][4].any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_tiny_host_path_matches_pipeline(worker, group, n):
+    """Multiexps of at most 8 terms with host scalars are answered on the host (create_proof's `inputs`
+    multiexps): same result as the kernel pipeline (BH_MSM_NO_SMALL_PATH) and as the oracle, with and
+    without a density map / skip, zero and one scalars included; same error semantics."""
+    import bellman_amd
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+    from bellman_amd.multiexp import NO_SMALL_PATH
+
+    bases = cref.gen_bases(group, n + 3, a=31, b=7)
+    hb = bellman_amd.Bases(worker, group, bases)
+    sc = cref.random_fr(n, 500 + n)
+    sc[0] = cref.ints_to_arr([1], 4)[0]
+    if n > 2:
+        sc[1] = 0
+    for skip, dens in ((0, None), (2, None), (1, np.array([True, False, True, True, False, True, True, True][:n]))):
+        dm = bellman_amd.FullDensity() if dens is None else bellman_amd.DensityTracker(dens)
+        rc, want = cref.multiexp(group, bases, skip, None if dens is None else cref.density_bitmap(dens), sc)
+        assert rc == 0
+        for mont in (False, True):
+            s_in = cref.fr_to_mont(sc) if mont else sc
+            got = bellman_amd.multiexp(worker, hb, dm, s_in, skip=skip, mont=mont).wait()
+            ref = bellman_amd.multiexp(worker, hb, dm, s_in, skip=skip, mont=mont, flags=NO_SMALL_PATH).wait()
+            assert np.array_equal(got, want) and np.array_equal(ref, want), (group, n, skip, mont)
+    # errors: running out of bases, an identity under a non-zero scalar, and both (top window decides)
+    with pytest.raises(UnexpectedEof):
+        bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, skip=4).wait()
+    ib = bases.copy()
+    ib[n - 1] = 0
+    hib = bellman_amd.Bases(worker, group, ib)
+    big = sc.copy()
+    big[n - 1] = cref.ints_to_arr([Q - 1], 4)[0]          # non-zero top window
+    with pytest.raises(UnexpectedIdentity):
+        bellman_amd.multiexp(worker, hib, bellman_amd.FullDensity(), big).wait()
+    if n >= 3:
+        # both kinds of failure: n scalars over n - 1 bases (the last entry runs out) with an identity at n - 2.
+        # The reference reports its top window's first failure (multiexp.rs:295-300): the identity if that scalar
+        # has a non-zero top digit, else the EOF.
+        jb = bases[: n - 1].copy()
+        jb[n - 2] = 0
+        hjb = bellman_amd.Bases(worker, group, jb)
+        both = cref.random_fr(n, 77)
+        both[n - 2] = cref.ints_to_arr([Q - 1], 4)[0]
+        with pytest.raises(UnexpectedIdentity):
+            bellman_amd.multiexp(worker, hjb, bellman_amd.FullDensity(), both).wait()
+        both[n - 2] = cref.ints_to_arr([5], 4)[0]
+        with pytest.raises(UnexpectedEof):
+            bellman_amd.multiexp(worker, hjb, bellman_amd.FullDensity(), both).wait()
+        for sc2 in (both,):   # and the oracle agrees on the precedence
+            rc, _ = cref.multiexp(group, jb, 0, None, sc2)
+            assert rc == 2
+
+
+@pytest.mark.parametrize("n", [257, 5000])
+def test_msm_g2_single_lane_kernels_still_agree(worker, n):
+    """BH_MSM_G2_SINGLE_LANE: the one-lane-per-point G2 kernels (kept for comparison) == the default K3 kernels."""
+    import bellman_amd
+    from bellman_amd.multiexp import NO_TABLE
+
+    bases = cref.gen_bases(2, n, a=3, b=19)
+    sc = _scalars(n, 600 + n)
+    hb = bellman_amd.Bases(worker, 2, bases)
+    rc, want = cref.multiexp(2, bases, 0, None, sc)
+    assert rc == 0
+    for flags in (0, 16, NO_TABLE, 16 | NO_TABLE):
+        assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=flags).wait(), want), flags
+
+
 # ------------------------------------------------------------------------------ FFT
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 15, 16, 17, 18, 20])
 def test_fft_all_modes_bit_exact(worker, log_n):
