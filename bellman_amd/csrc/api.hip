@@ -203,12 +203,9 @@ int bh_ctx_trim(bh_ctx *ctx) {
   ctx->c.pool.release_all();
   {
     std::lock_guard<std::mutex> g(ctx->c.fft_mu);
-    for (auto &kv : ctx->c.fft_tables) {
-      if (kv.second.tw) (void)hipFree(kv.second.tw);
-      if (kv.second.coset) (void)hipFree(kv.second.coset);
-      if (kv.second.icoset) (void)hipFree(kv.second.icoset);
-    }
+    for (auto &kv : ctx->c.fft_tables) fft_tables_free(kv.second);
     ctx->c.fft_tables.clear();
+    fft_master_free(ctx->c);
   }
   return BH_OK;
 }
@@ -216,11 +213,8 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->c.device);
   (void)hipDeviceSynchronize();
-  for (auto &kv : ctx->c.fft_tables) {
-    if (kv.second.tw) (void)hipFree(kv.second.tw);
-    if (kv.second.coset) (void)hipFree(kv.second.coset);
-    if (kv.second.icoset) (void)hipFree(kv.second.icoset);
-  }
+  for (auto &kv : ctx->c.fft_tables) fft_tables_free(kv.second);
+  fft_master_free(ctx->c);
   ctx->c.pool.release_all();
   for (auto &r : ctx->c.job_pool) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
@@ -305,7 +299,7 @@ int bh_fft_fr_dev(bh_ctx *ctx, void *data_dev, uint32_t log_n, int mode, void *s
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   hipStream_t st = pick_stream(ctx, stream);
   void *scratch = nullptr;
-  if (log_n > 10) {
+  if (log_n > 11) {   // more than one pass (fft.hip NTT_MAX_R)
     scratch = ctx->c.pool.acquire(sizeof(fr_t) << log_n);
     if (!scratch) return BH_ERR_HIP;
   }
@@ -739,6 +733,14 @@ int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scal
 }
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fr_t *)r)[i], ((const fr_t *)a)[i], ((const fr_t *)b)[i]);
+}
+void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n) {
+  // the FFT's multiplier: second operand pre-sliced into 30-bit limbs (ff.cuh fe_to_bform / fe_mul_b)
+  for (size_t i = 0; i < n; i++) {
+    u32 B[9];
+    fe_to_bform<FrParams>(B, ((const fr_t *)b)[i]);
+    fe_mul_b<FrParams>(((fr_t *)r)[i], ((const fr_t *)a)[i], B);
+  }
 }
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);

@@ -79,11 +79,20 @@ struct JobResources {
   size_t pinned_bytes = 0;
 };
 
+// An Fr table entry pre-sliced for the multiplier (ff.cuh fe_mul_b): 9 limbs of 30 bits, padded to 48 bytes
+struct alignas(16) BTw {
+  u32 l[12];
+};
+// Per-size FFT tables (fft.hip), all in B form and two-level: entry e of a virtual n-entry table is
+// hi[e >> lb] * lo[e & (2^lb - 1)].  [0] forward, [1] inverse.
 struct FftTables {
-  fr_t *tw = nullptr;      // omega_n^i, i < n
-  fr_t *coset = nullptr;   // 7^i
-  fr_t *icoset = nullptr;  // 7^-i * n^-1
-  fr_t minv;               // n^-1 (Montgomery)
+  bool init = false;
+  uint32_t lb = 0;
+  BTw *tw_lo[2] = {nullptr, nullptr}, *tw_hi[2] = {nullptr, nullptr};   // omega_n^(+-e): inter-pass twiddles
+  BTw *coset_lo = nullptr, *coset_hi = nullptr;                           // 7^i
+  BTw *icoset_lo = nullptr, *icoset_hi = nullptr;                         // 7^-i / n
+  fr_t minv;                                                              // n^-1 (Montgomery)
+  BTw *minv_dev = nullptr;                                                // ... as a one-entry table
 };
 
 struct Context {
@@ -92,11 +101,17 @@ struct Context {
   DevicePool pool;
   std::mutex fft_mu;
   std::map<uint32_t, FftTables> fft_tables;  // keyed by log_n
+  BTw *fft_master[2] = {nullptr, nullptr};   // omega_2048^(+-i), i < 1024: in-tile twiddles of every pass
   int num_cus = 256;
   std::mutex job_mu;
   std::vector<JobResources> job_pool;
 };
 
+}  // namespace bh
+
+namespace bh {
+void fft_tables_free(FftTables &t);   // fft.hip
+void fft_master_free(Context &c);
 }  // namespace bh
 
 struct bh_ctx {

@@ -282,6 +282,33 @@ BH_HD void fe_mul(Fe<P> &r, const Fe<P> &a, const Fe<P> &b) {
   fe_mont_reduce30<P, CANONICAL>(r, c);
 }
 
+// The same product with the second operand PRE-SLICED ("B form": the L 30-bit limbs of b << SHIFT).  Table
+// entries that are only ever multiplied with - FFT twiddles, coset factors - are stored this way, which removes
+// the re-slicing of one operand from every product (about 12 % of an Fr product's instructions).
+template <class P>
+BH_HD void fe_to_bform(u32 *B, const Fe<P> &b) {
+  typedef Radix30<P> R;
+#pragma unroll
+  for (int i = 0; i < R::L; i++) B[i] = fe_limb30<P, R::SHIFT>(b, i);
+}
+template <class P, bool CANONICAL = true>
+BH_HD void fe_mul_b(Fe<P> &r, const Fe<P> &a, const u32 *B) {
+  typedef Radix30<P> R;
+  constexpr int L = R::L;
+  u32 A[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) A[i] = fe_limb30<P, 0>(a, i);
+  u64 c[2 * L];
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) c[k] = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+#pragma unroll
+    for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
+  }
+  fe_mont_reduce30<P, CANONICAL>(r, c);
+}
+
 // Also evaluated and rejected on the MI355X: the interleaved product-scanning form (retire each column
 // immediately; 70 instead of 97 VGPRs for the out-of-line call) - 24 % more 64-bit add/shift work,
 // 46 vs 57 G mul/s, and callers still do not reach three waves per SIMD.

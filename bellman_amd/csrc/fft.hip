@@ -9,39 +9,57 @@
 //   divide_by_z_on_coset (:139-151)          ->  the element-wise kernels at the bottom,
 //   plus the fused (a*b-c)*zinv pass used by create_proof's h block (prover.rs:232-236).
 //
-// Structure (MI355X-first): n = R_0 * R_1 * ... * R_{L-1} (R_p = 2^r_p <= 256, L <= 4).
-// Pass p transforms, for every already-fixed prefix, the R_p-point sub-FFT along stride M_p
-// entirely inside LDS (tile = R_p rows x C columns of 32-byte elements, 32 KiB), multiplies
-// by the inter-pass twiddle w_N^(j'*k) and writes back to the same positions (pass 0 moves the
-// data into a scratch vector, middle passes work in place there).  The last pass has no twiddle
-// and scatters the digit-reversed result to its natural position back in the caller's vector,
-// tiled over the FIRST digit so stores are contiguous 128-256-byte runs.
-// Inside a tile the sub-FFT is a radix-2 DIT over LDS with the tile's twiddles (w_R^i)
-// staged in LDS.  Work per pass: one 32-B read + one 32-B write per element.
+// Structure (MI355X-first): n = R_0 * ... * R_{L-1}, R_p = 2^r_p <= 2^11: ONE pass up to 2^11, TWO up to
+// 2^22 (the 2^20 / 2^22 domains of the proof sizes that matter: 64 B of algorithmic traffic per element become
+// 128 B of real traffic, not 192), three up to 2^31.  A pass gives every workgroup a tile of 2048 elements
+// (R rows x C columns; 72 KiB of LDS, two workgroups per CU so one tile's global loads/stores overlap the other's
+// butterflies) and performs all R-point sub-FFTs of the tile:
+//   * 8 elements per thread: radix-8 (three DIT stages) in registers between LDS exchanges, i.e. 4 LDS round
+//     trips for an 11-stage sub-FFT instead of 11; LDS is two 16-byte planes with one pad slot per 8 so that the
+//     stride-8m accesses of every step are bank-conflict free;
+//   * the first step of a pass has only the constant twiddles w_4, w_8^{1,2,3}: 5 multiplications per 8 points
+//     instead of 12;
+//   * twiddles are never gathered from an n-entry table.  In-tile twiddles come from ONE 1024-entry master table
+//     w_2048^i (48 KiB, cache resident, shared by every pass of every size); inter-pass twiddles w_n^e, the coset
+//     factors 7^i / 7^-i and 1/n come from two-level tables (e = e_hi*2^LB + e_lo: two multiplications, tables of
+//     about 2^(log_n/2) entries);
+//   * every table entry is stored PRE-SLICED for the multiplier ("B form": the nine 30-bit limbs of w << 14,
+//     ff.cuh), which removes the operand re-slicing of one side of every product.
+// Non-last passes read and write the same positions (pass 0 moves the data into a scratch vector); the last
+// pass scatters the digit-reversed result to natural order back into the caller's vector.  Workgroup -> tile
+// assignment is XCD-aware: tiles that share 128-byte lines (the narrow tiles of the 2^21 / 2^22 plans) go to the
+// same XCD back to back, so the other half of a line is an L2 hit instead of a second HBM fetch.
 #include "common.hpp"
 
 namespace bh {
 
 constexpr int NTT_THREADS = 256;
-constexpr int NTT_LOG_TILE = 10;       // 1024 Fr = 32 KiB of LDS per workgroup (4 workgroups / CU)
+constexpr int NTT_LOG_TILE = 11;                  // 2048 Fr per workgroup
+constexpr int NTT_TILE = 1 << NTT_LOG_TILE;
+constexpr int NTT_MAX_R = 11;                     // rows of a tile: sub-FFT size 2^r, r <= 11
+constexpr int NTT_PLANE = NTT_TILE + NTT_TILE / 8;   // padded slots per 16-byte plane
 
 struct NttPass {
   const fr_t *in;
   fr_t *out;
-  const fr_t *tw;     // w_n^i for i < n
-  const fr_t *pre;    // multiply input element i by pre[i]   (pass 0 only; may be null)
-  const fr_t *post;   // multiply output element k by post[k] (last pass only; may be null)
-  fr_t post_const;    // ... or by this constant when has_post_const
-  u32 has_post_const;
+  const BTw *master;   // w_2048^(+-i), i < 1024
+  const BTw *tw_lo;    // w_n^(+-i), i < 2^lb                 (inter-pass twiddles; null when L == 1)
+  const BTw *tw_hi;    // w_n^(+-i * 2^lb)
+  const BTw *pre_lo;   // first pass: multiply input element i by pre_hi[i >> lb] * pre_lo[i & mask] (null: none)
+  const BTw *pre_hi;
+  const BTw *post_lo;  // last pass: multiply output element k likewise (null: none)
+  const BTw *post_hi;
+  const BTw *post_const;   // ... or by this single entry (1/n of ifft; null: none)
+  u32 lb;             // low bits of the two-level tables
   u32 log_n;
   u32 s;              // bits consumed by earlier passes
   u32 r;              // radix bits of this pass
   u32 log_c;          // log2(columns per tile)
-  u32 inverse;        // use w^-e = w^(n-e)
   u32 is_last;
   u32 r0;             // radix bits of pass 0 (for the last pass' column dimension)
   u32 L;              // number of passes
-  u32 rmid[2];        // radix bits of the middle passes (1 .. L-2)
+  u32 r1;             // radix bits of pass 1 (L == 3: storage order of the middle digit)
+  u32 xcd_swizzle;    // tiles % 8 == 0: blockIdx -> tile so that neighbouring tiles share an XCD
 };
 
 __device__ __forceinline__ fr_t ld_fr(const fr_t *p) {
@@ -58,22 +76,100 @@ __device__ __forceinline__ void st_fr(fr_t *p, const fr_t &v) {
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// ---- the multiplier with a pre-sliced second operand ---------------------------------------------------------
+// x * w for a table entry w in B form.  Out of line (operands and result in VGPRs, the entry is fetched inside):
+// a radix-8 step has 12 of these, inlined they would not fit the instruction cache.
+__device__ __attribute__((noinline)) static fr_t fr_mul_tw(u32x4 a0, u32x4 a1, const BTw *w) {
+  fr_t a, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
+  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  const uint4 *q = reinterpret_cast<const uint4 *>(w);
+  const uint4 b0 = q[0], b1 = q[1], b2 = q[2];
+  const u32 B[9] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x};
+  fe_mul_b<FrParams>(r, a, B);
+  return r;
+}
+__device__ __forceinline__ fr_t mul_tw(const fr_t &a, const BTw *w) {
+  return fr_mul_tw(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w);
+}
+
+// ---- LDS tile: element `lin` (= col * R + position) lives in slot lin + lin/8 of two 16-byte planes -------------
+__device__ __forceinline__ fr_t tile_ld(const uint4 *p0, const uint4 *p1, u32 lin) {
+  const u32 a = lin + (lin >> 3);
+  const uint4 x = p0[a], y = p1[a];
+  fr_t v;
+  v.l[0] = x.x; v.l[1] = x.y; v.l[2] = x.z; v.l[3] = x.w;
+  v.l[4] = y.x; v.l[5] = y.y; v.l[6] = y.z; v.l[7] = y.w;
+  return v;
+}
+__device__ __forceinline__ void tile_st(uint4 *p0, uint4 *p1, u32 lin, const fr_t &v) {
+  const u32 a = lin + (lin >> 3);
+  p0[a] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  p1[a] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// G DIT stages [s, s + G) of every sub-FFT of the tile, in registers.  A task owns the 2^G positions
+//   pos_t = hi * 2^(s+G) + t * 2^s + lo   (t < 2^G)   of one column;
+// stage s + j pairs t with t + 2^j (bit j of t clear) under the twiddle w_R^(((t mod 2^j) * 2^s + lo) * R / 2^(s+j+1)),
+// which is entry ((t mod 2^j) * 2^s + lo) * (1024 >> (s + j)) of the master table w_2048^i.
+// FIRST (s == 0): lo == 0, so stage 0 has no multiplication at all and the others only the constants w_4, w_8^k.
+template <int G, bool FIRST>
+__device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 total, u32 r, u32 s, const BTw *master) {
+  constexpr int N = 1 << G;
+  const u32 m = 1u << s;
+  const u32 ntasks = total >> G;
+  const u32 hi_bits = r - s - G;
+  for (u32 task = tid; task < ntasks; task += NTT_THREADS) {
+    const u32 lo = FIRST ? 0u : (task & (m - 1));
+    const u32 rest = task >> s;
+    const u32 hi = rest & ((1u << hi_bits) - 1), col = rest >> hi_bits;
+    const u32 pos0 = (col << r) + (hi << (s + G)) + lo;
+    fr_t e[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) e[t] = tile_ld(p0, p1, pos0 + ((u32)t << s));
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+#pragma unroll
+      for (int t = 0; t < N; t++) {
+        if (t & (1 << j)) continue;
+        const int tl = t & ((1 << j) - 1);          // t mod 2^j
+        fr_t y = e[t + (1 << j)];
+        if (!(FIRST && tl == 0)) {                  // w^0 = 1: nothing to multiply
+          const u32 idx = ((u32)tl * m + lo) * (1024u >> (s + j));
+          y = mul_tw(y, master + idx);
+        }
+        fr_t u, v;
+        fe_add(u, e[t], y);
+        fe_sub(v, e[t], y);
+        e[t] = u;
+        e[t + (1 << j)] = v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < N; t++) tile_st(p0, p1, pos0 + ((u32)t << s), e[t]);
+  }
+}
+
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
-  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint4 plane0[NTT_PLANE];
+  __shared__ uint4 plane1[NTT_PLANE];
   const u32 R = 1u << a.r, C = 1u << a.log_c;
-  fr_t *tile = reinterpret_cast<fr_t *>(smem);   // [C][R]
-  fr_t *twl = tile + (size_t)R * C;              // [R/2] : w_R^i
   const u32 tid = threadIdx.x;
   const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
   const u64 n = (u64)1 << a.log_n;
 
+  // ---- which tile (XCD-aware: blocks b, b+8, b+16, ... run on one XCD and get consecutive tiles) ------------
+  u64 t = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const u32 per_xcd = gridDim.x >> 3;
+    t = (u64)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  }
   // ---- where is this tile? ---------------------------------------------------------------
   // non-last: element(row j, col c) at base + j*M + c            (M = n >> (s + r))
   // last:     element(row j, col c) at base + c*colstride + j    (rows contiguous)
   u64 base, in_row_stride, in_col_stride;
   u32 jp0 = 0;        // first column's j' (non-last passes)
   u64 out_base = 0, out_row_stride = 1, out_col_stride = 1;
-  const u64 t = blockIdx.x;
   if (!a.is_last) {
     const u32 logM = a.log_n - a.s - a.r;
     const u64 tiles_per_block = ((u64)1 << logM) >> a.log_c;
@@ -87,74 +183,65 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
     base = 0; in_row_stride = 1; in_col_stride = 0;
     out_base = 0; out_row_stride = 1; out_col_stride = 0;
   } else {
-    // columns = C consecutive values of the FIRST digit k0; middle digits fixed by `mid`
-    const u32 groups = (1u << a.r0) >> a.log_c;          // tiles per middle combination
+    // columns = C consecutive values of the FIRST digit k0; the middle digit (L == 3) is fixed by `mid`
+    const u32 groups = (1u << a.r0) >> a.log_c;          // tiles per middle value
     const u64 mid = t / groups;
     const u32 k00 = (u32)(t % groups) << a.log_c;
     const u64 M0 = n >> a.r0;
     base = (u64)k00 * M0 + (mid << a.r);
     in_row_stride = 1; in_col_stride = M0;
-    // output index = k0 + R0*(k1 + R1*(k2 ...)) ; storage order of `mid` is (k1, k2) MSB first
-    u64 rev = 0;
-    if (a.L == 3) rev = mid;
-    else if (a.L == 4) { const u64 k1 = mid >> a.rmid[1], k2 = mid & ((1u << a.rmid[1]) - 1); rev = k1 + (k2 << a.rmid[0]); }
-    out_base = k00 + (rev << a.r0);
+    // output index = k0 + R0*(k1 + R1*k2): `mid` is k1 (L == 3), the rows of this pass are the last digit
+    out_base = k00 + (mid << a.r0);
     out_row_stride = (u64)1 << (a.log_n - a.r);  // last digit is the most significant
     out_col_stride = 1;
   }
 
-  // ---- stage this tile's twiddles w_R^i = w_n^(i * n/R) into LDS ---------------------------
-  for (u32 i = tid; i < (R >> 1); i += NTT_THREADS) {
-    u32 e = i << (a.log_n - a.r);
-    if (a.inverse) e = (u32)((n - e) & n_mask);
-    twl[i] = ld_fr(a.tw + e);
-  }
   // ---- load (bit-reversed rows), optional pre-multiplication ------------------------------
   const u32 total = R << a.log_c;
+  const u32 lb_mask = (1u << a.lb) - 1;
   for (u32 e = tid; e < total; e += NTT_THREADS) {
     u32 row, col;
     if (!a.is_last) { row = e >> a.log_c; col = e & (C - 1); }   // consecutive lanes -> consecutive columns
     else { col = e >> a.r; row = e & (R - 1); }                  // consecutive lanes -> consecutive rows
     const u64 g = base + row * in_row_stride + col * in_col_stride;
     fr_t v = ld_fr(a.in + g);
-    if (a.pre) { fr_t p = ld_fr(a.pre + g); fe_mul(v, v, p); }
+    if (a.pre_lo) {
+      v = mul_tw(v, a.pre_hi + (u32)(g >> a.lb));
+      v = mul_tw(v, a.pre_lo + ((u32)g & lb_mask));
+    }
     const u32 rrow = a.r ? (__brev(row) >> (32 - a.r)) : 0;
-    tile[(size_t)col * R + rrow] = v;
+    tile_st(plane0, plane1, (col << a.r) + rrow, v);
   }
-  // ---- radix-2 DIT stages in LDS ------------------------------------------------------------
-  const u32 half = R >> 1;
-  for (u32 s = 0; s < a.r; s++) {
-    __syncthreads();
-    const u32 m = 1u << s;
-    for (u32 b = tid; b < (half << a.log_c); b += NTT_THREADS) {
-      const u32 col = b >> (a.r - 1), bb = b & (half - 1);
-      const u32 j = bb & (m - 1), k = bb >> s;
-      const u32 r1 = (k << (s + 1)) | j, r2 = r1 + m;
-      fr_t *p1 = tile + (size_t)col * R + r1, *p2 = tile + (size_t)col * R + r2;
-      fr_t x = *p1, y = *p2, w = twl[j << (a.r - 1 - s)];
-      fe_mul(y, y, w);
-      fr_t u, v;
-      fe_add(u, x, y);
-      fe_sub(v, x, y);
-      *p1 = u; *p2 = v;
+  // ---- the r DIT stages: radix-8 steps, then what is left (4 = 2 + 2 rather than 3 + 1) ---------------------
+  {
+    u32 s = 0, left = a.r;
+    bool first = true;
+    while (left) {
+      __syncthreads();
+      const u32 g = (left == 4) ? 2 : (left >= 3 ? 3 : left);
+      if (g == 3) { if (first) ntt_step<3, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<3, false>(plane0, plane1, tid, total, a.r, s, a.master); }
+      else if (g == 2) { if (first) ntt_step<2, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<2, false>(plane0, plane1, tid, total, a.r, s, a.master); }
+      else { if (first) ntt_step<1, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<1, false>(plane0, plane1, tid, total, a.r, s, a.master); }
+      s += g; left -= g; first = false;
     }
   }
   __syncthreads();
   // ---- store: inter-pass twiddle (non-last) or final scaling + digit-reversed position ------
   for (u32 e = tid; e < total; e += NTT_THREADS) {
     const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
-    fr_t v = tile[(size_t)col * R + row];
+    fr_t v = tile_ld(plane0, plane1, (col << a.r) + row);
     const u64 g = out_base + row * out_row_stride + col * out_col_stride;
     if (!a.is_last) {
-      u32 ex = (u32)((((u64)(jp0 + col) * row) << a.s) & n_mask);
-      if (a.inverse) ex = (u32)((n - ex) & n_mask);
-      fr_t w = ld_fr(a.tw + ex);
-      fe_mul(v, v, w);
-    } else if (a.post) {
-      fr_t w = ld_fr(a.post + g);
-      fe_mul(v, v, w);
-    } else if (a.has_post_const) {
-      fe_mul(v, v, a.post_const);
+      const u32 ex = (u32)((((u64)(jp0 + col) * row) << a.s) & n_mask);
+      if (ex) {   // w^0 = 1 (row 0, column 0 of the vector): skipped where the whole wavefront agrees
+        v = mul_tw(v, a.tw_hi + (ex >> a.lb));
+        v = mul_tw(v, a.tw_lo + (ex & lb_mask));
+      }
+    } else if (a.post_lo) {
+      v = mul_tw(v, a.post_hi + (u32)(g >> a.lb));
+      v = mul_tw(v, a.post_lo + ((u32)g & lb_mask));
+    } else if (a.post_const) {
+      v = mul_tw(v, a.post_const);
     }
     st_fr(a.out + g, v);
   }
@@ -176,6 +263,24 @@ __global__ void gen_powers_kernel(fr_t *out, u64 n, PowTable tab, int mul_into) 
   for (u64 i = i0; i < n && i < i0 + 16; i++) {
     if (mul_into) { fr_t v = ld_fr(out + i); fe_mul(v, v, acc); st_fr(out + i, v); }
     else st_fr(out + i, acc);
+    fe_mul(acc, acc, tab.p2[0]);
+  }
+}
+// the same powers as B-form table entries
+__global__ void gen_btw_kernel(BTw *out, u64 n, PowTable tab) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 i0 = t * 16;
+  if (i0 >= n) return;
+  fr_t acc = tab.scale;
+  for (int k = 0; k < 32; k++)
+    if ((i0 >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
+  for (u64 i = i0; i < n && i < i0 + 16; i++) {
+    BTw w;
+    fe_to_bform<FrParams>(w.l, acc);
+    uint4 *q = reinterpret_cast<uint4 *>(out + i);
+    q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+    q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+    q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
     fe_mul(acc, acc, tab.p2[0]);
   }
 }
@@ -245,72 +350,122 @@ static fr_t fr_pow_u64_host(const fr_t &a, u64 e) {
   return r;
 }
 
-static int launch_gen_powers(fr_t *out, u64 n, const fr_t &g, const fr_t &scale, int mul_into, hipStream_t st) {
+static PowTable make_pow_table(const fr_t &g, const fr_t &scale) {
   PowTable tab;
   tab.p2[0] = g;
   for (int k = 1; k < 32; k++) fe_sqr(tab.p2[k], tab.p2[k - 1]);
   tab.scale = scale;
+  return tab;
+}
+static int launch_gen_powers(fr_t *out, u64 n, const fr_t &g, const fr_t &scale, int mul_into, hipStream_t st) {
+  const PowTable tab = make_pow_table(g, scale);
   u64 threads = (n + 15) / 16;
   u32 blocks = (u32)((threads + 255) / 256);
   hipLaunchKernelGGL(gen_powers_kernel, dim3(blocks), dim3(256), 0, st, out, n, tab, mul_into);
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
+// allocates and fills a B-form table of scale * g^i, i < count
+static int make_btw_table(BTw **out, u64 count, const fr_t &g, const fr_t &scale, hipStream_t st) {
+  BH_HIP_CHECK(hipMalloc((void **)out, count * sizeof(BTw)));
+  const PowTable tab = make_pow_table(g, scale);
+  const u64 threads = (count + 15) / 16;
+  hipLaunchKernelGGL(gen_btw_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, *out, count, tab);
+  BH_HIP_CHECK(hipGetLastError());
+  return BH_OK;
+}
 
-static int get_tables(Context &c, uint32_t log_n, bool need_coset, bool need_icoset, hipStream_t st, FftTables *out) {
+void fft_tables_free(FftTables &t) {
+  BTw **all[] = {&t.tw_lo[0], &t.tw_lo[1], &t.tw_hi[0], &t.tw_hi[1], &t.coset_lo, &t.coset_hi, &t.icoset_lo, &t.icoset_hi,
+                 &t.minv_dev};
+  for (BTw **p : all) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+}
+void fft_master_free(Context &c) {
+  for (int d = 0; d < 2; d++) {
+    if (c.fft_master[d]) (void)hipFree(c.fft_master[d]);
+    c.fft_master[d] = nullptr;
+  }
+}
+
+// split log_n into 1-3 passes of <= 11 bits, as evenly as possible (largest first)
+static void plan_passes(uint32_t log_n, uint32_t *r, uint32_t *L) {
+  const uint32_t l = log_n <= (uint32_t)NTT_MAX_R ? 1 : (log_n + NTT_MAX_R - 1) / NTT_MAX_R;
+  *L = l;
+  const uint32_t q = log_n / l, rem = log_n % l;
+  for (uint32_t i = 0; i < l; i++) r[i] = q + (i < rem ? 1 : 0);
+}
+
+static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bool need_coset, bool need_icoset,
+                      hipStream_t st, FftTables *out, const BTw **master) {
   std::lock_guard<std::mutex> g(c.fft_mu);
-  FftTables &t = c.fft_tables[log_n];
-  const u64 n = (u64)1 << log_n;
   fr_t one;
   fe_one(one);
   bool generated = false;
-  if (!t.tw) {
-    generated = true;
-    BH_HIP_CHECK(hipMalloc((void **)&t.tw, n * sizeof(fr_t)));
-    int rc = launch_gen_powers(t.tw, n, fr_domain_omega_host(log_n), one, 0, st);
+  const int dir = inverse ? 1 : 0;
+  if (!c.fft_master[dir]) {   // w_2048^(+-i), i < 1024
+    fr_t w = fr_domain_omega_host(NTT_LOG_TILE);
+    if (inverse) fe_inv(w, w);
+    int rc = make_btw_table(&c.fft_master[dir], 1024, w, one, st);
     if (rc) return rc;
+    generated = true;
+  }
+  FftTables &t = c.fft_tables[log_n];
+  const u64 n = (u64)1 << log_n;
+  if (!t.init) {
+    t.init = true;
+    t.lb = (log_n + 1) / 2;
     fr_t nn = fr_from_u64_host(n);
     fe_inv(t.minv, nn);
-  }
-  if (need_coset && !t.coset) {
+    int rc = make_btw_table(&t.minv_dev, 1, one, t.minv, st);   // the single entry 1/n
+    if (rc) return rc;
     generated = true;
-    BH_HIP_CHECK(hipMalloc((void **)&t.coset, n * sizeof(fr_t)));
-    int rc = launch_gen_powers(t.coset, n, fr_from_u64_host(7), one, 0, st);  // MULTIPLICATIVE_GENERATOR
+  }
+  const u64 n_lo = (u64)1 << t.lb, n_hi = (u64)1 << (log_n - t.lb);
+  auto two_level = [&](BTw **lo, BTw **hi, const fr_t &base, const fr_t &scale) -> int {
+    int rc = make_btw_table(lo, n_lo, base, scale, st);
+    if (rc) return rc;
+    const fr_t step = fr_pow_u64_host(base, n_lo);
+    rc = make_btw_table(hi, n_hi, step, one, st);
+    generated = true;
+    return rc;
+  };
+  if (need_tw && !t.tw_lo[dir]) {
+    fr_t w = fr_domain_omega_host(log_n);
+    if (inverse) fe_inv(w, w);
+    int rc = two_level(&t.tw_lo[dir], &t.tw_hi[dir], w, one);
     if (rc) return rc;
   }
-  if (need_icoset && !t.icoset) {
-    generated = true;
-    BH_HIP_CHECK(hipMalloc((void **)&t.icoset, n * sizeof(fr_t)));
+  if (need_coset && !t.coset_lo) {
+    int rc = two_level(&t.coset_lo, &t.coset_hi, fr_from_u64_host(7), one);   // MULTIPLICATIVE_GENERATOR
+    if (rc) return rc;
+  }
+  if (need_icoset && !t.icoset_lo) {
     fr_t ginv;
     fe_inv(ginv, fr_from_u64_host(7));
-    int rc = launch_gen_powers(t.icoset, n, ginv, t.minv, 0, st);
+    int rc = two_level(&t.icoset_lo, &t.icoset_hi, ginv, t.minv);   // 7^-i / n
     if (rc) return rc;
   }
   // tables are generated on `st`; later users may be on other streams
   if (generated) BH_HIP_CHECK(hipStreamSynchronize(st));
   *out = t;
+  *master = c.fft_master[dir];
   return BH_OK;
 }
 
-// split log_n into <= 4 passes of <= 8 bits, as evenly as possible (largest first)
-static void plan_passes(uint32_t log_n, uint32_t *r, uint32_t *L) {
-  if (log_n <= (uint32_t)NTT_LOG_TILE) { *L = 1; r[0] = log_n; return; }
-  uint32_t l = (log_n + 7) / 8;
-  *L = l;
-  uint32_t q = log_n / l, rem = log_n % l;
-  for (uint32_t i = 0; i < l; i++) r[i] = q + (i < rem ? 1 : 0);
-}
-
 // data: device, 2^log_n Montgomery Fr, in place.  scratch: device, same size (ping-pong for the
-// digit-reversing last pass; may be null when log_n <= NTT_LOG_TILE).
+// digit-reversing last pass; may be null when log_n <= NTT_MAX_R).
 int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hipStream_t st) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
   const bool inverse = (mode == BH_IFFT || mode == BH_ICOSET_FFT);
-  FftTables tab;
-  int rc = get_tables(c, log_n, mode == BH_COSET_FFT, mode == BH_ICOSET_FFT, st, &tab);
-  if (rc) return rc;
-  uint32_t r[4] = {0, 0, 0, 0}, L = 1;
+  uint32_t r[3] = {0, 0, 0}, L = 1;
   plan_passes(log_n, r, &L);
+  FftTables tab;
+  const BTw *master = nullptr;
+  int rc = get_tables(c, log_n, inverse, L > 1, mode == BH_COSET_FFT, mode == BH_ICOSET_FFT, st, &tab, &master);
+  if (rc) return rc;
   uint32_t s = 0;
   for (uint32_t p = 0; p < L; p++) {
     NttPass a;
@@ -319,20 +474,23 @@ int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hip
     // last pass scratch -> data (digit-reversing scatter)
     a.in = (p == 0) ? data : scratch;
     a.out = (last) ? data : scratch;
-    a.tw = tab.tw;
-    a.pre = (p == 0 && mode == BH_COSET_FFT) ? tab.coset : nullptr;
-    a.post = (last && mode == BH_ICOSET_FFT) ? tab.icoset : nullptr;
-    a.post_const = tab.minv;
-    a.has_post_const = (last && mode == BH_IFFT) ? 1 : 0;
+    a.master = master;
+    a.tw_lo = tab.tw_lo[inverse ? 1 : 0];
+    a.tw_hi = tab.tw_hi[inverse ? 1 : 0];
+    const bool pre = (p == 0 && mode == BH_COSET_FFT), post = (last && mode == BH_ICOSET_FFT);
+    a.pre_lo = pre ? tab.coset_lo : nullptr;
+    a.pre_hi = pre ? tab.coset_hi : nullptr;
+    a.post_lo = post ? tab.icoset_lo : nullptr;
+    a.post_hi = post ? tab.icoset_hi : nullptr;
+    a.post_const = (last && mode == BH_IFFT) ? tab.minv_dev : nullptr;
+    a.lb = tab.lb;
     a.log_n = log_n;
     a.s = s;
     a.r = r[p];
-    a.inverse = inverse ? 1 : 0;
     a.is_last = last ? 1 : 0;
     a.r0 = r[0];
     a.L = L;
-    a.rmid[0] = r[1];
-    a.rmid[1] = r[2];
+    a.r1 = r[1];
     // tile columns: as many as fit 2048 elements, bounded by the extent of the column dimension
     uint32_t log_c = NTT_LOG_TILE - r[p];
     if (L == 1) log_c = 0;
@@ -340,8 +498,8 @@ int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hip
     else { uint32_t logM = log_n - s - r[p]; if (log_c > logM) log_c = logM; }
     a.log_c = log_c;
     const u64 tiles = ((u64)1 << log_n) >> (r[p] + log_c);
-    const size_t lds = ((size_t)(1u << (r[p] + log_c)) + (size_t)(1u << r[p]) / 2 + 1) * sizeof(fr_t);
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles), dim3(NTT_THREADS), lds, st, a);
+    a.xcd_swizzle = (tiles >= 64 && (tiles & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles), dim3(NTT_THREADS), 0, st, a);
     BH_HIP_CHECK(hipGetLastError());
     s += r[p];
   }

@@ -458,8 +458,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 npairs = (u64)p.Wd * n;
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nslots = (u64)p.W * p.chunks_per_window;
-  // serial walk bound: 4x the average number of chunks per bucket, at least 8
-  const u32 walk = std::max<u32>(8, 4 * ((p.n >> (p.c - 1)) / p.chunk + 1));
+  // serial walk bound: 4x the average number of chunks per bucket, at least 8, at most 32 - longer runs go to the
+  // workgroup-parallel merge (window-table plans with few buckets have runs of hundreds of chunks)
+  const u32 walk = std::min<u32>(32, std::max<u32>(8, 4 * ((p.n >> (p.c - 1)) / p.chunk + 1)));
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
   const u64 nwords = (n + 63) / 64;

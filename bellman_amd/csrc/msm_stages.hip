@@ -252,11 +252,13 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   return p;
 }
 
-// Window bits a table is built for (MI355X sweep, profiles/r1_tune_window_table.txt)
+// Window bits a table is built for.  All W = ceil(256/c) digits of a scalar land in ONE bucket set, so the sorted
+// stream has W*n entries over 2^(c-1) buckets: c is chosen so that a bucket holds a handful of entries (runs that
+// span a few chunks at most), which is 3-4 bits more than the classic plan uses for the same n.
 unsigned table_window_bits(u64 n_bases, bool g2) {
   (void)g2;
   const u32 lg = ilog2(n_bases ? n_bases : 1);
-  return lg <= 12 ? 8 : lg <= 16 ? 13 : 16;
+  return std::min(16u, std::max(8u, lg + 3));
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
@@ -275,7 +277,8 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   // K: a quarter of the average bucket (so a bucket spans a handful of chunks, folded by its owner lane
   // in the merge), at least the classic value, but never so large that the chip runs out of lanes
   const u32 lg = ilog2(p.n ? p.n : 1);
-  const u32 base_k = lg <= 11 ? 8 : lg <= 17 ? 16 : g2 ? 64 : 32;
+  // few entries: short chunks, the job is a chain of latency-bound steps and the chip is mostly idle
+  const u32 base_k = lg <= 15 ? 4 : lg <= 17 ? 8 : lg <= 19 ? 16 : g2 ? 64 : 32;
   const u64 avg = (u64)p.n >> (p.c - 1);
   const u64 lanes_wanted = (u64)num_cus * 4 * 64 * 2;   // two wavefronts per SIMD
   u64 k = std::max<u64>(base_k, avg / 4);

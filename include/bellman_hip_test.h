@@ -25,6 +25,7 @@ int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scal
 /* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
+void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n); /* b pre-sliced as the FFT tables are */
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
 void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */

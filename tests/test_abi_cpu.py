@@ -74,6 +74,11 @@ def test_host_field_mul_matches_oracle(lib):
     r = np.zeros_like(a)
     lib.bh_test_fr_mul_host(_p(r), _p(a), _p(b), 500)
     assert np.array_equal(r, cref.mul_assign(a, b))
+    a[0], b[1] = 0, 0
+    a[2] = b[2] = cref.ints_to_arr([bls.Q - 1], 4)[0]
+    r2 = np.zeros_like(a)
+    lib.bh_test_fr_mul_bform_host(_p(r2), _p(a), _p(b), 500)   # the FFT's multiplier: b pre-sliced (B form)
+    assert np.array_equal(r2, cref.mul_assign(a, b))
     rnd = random.Random(3)
     xs = [rnd.randrange(bls.P) for _ in range(100)] + [0, 1, bls.P - 1]
     ys = [rnd.randrange(bls.P) for _ in range(100)] + [bls.P - 1, bls.P - 1, bls.P - 1]

@@ -139,16 +139,25 @@ def test_fft_every_remaining_size_bit_exact(worker, log_n):
 
     n = 1 << log_n
     data = cref.random_fr(n, 300 + log_n)
-    threads = cref.lib().orc_max_threads() if log_n >= 16 else 8
+    # the restated parallel_fft pays n * P extra multiplications for P = 2^floor(log2 threads) (domain.rs:340-349):
+    # 16 threads keep the oracle in seconds at 2^25
+    threads = 16 if log_n >= 16 else 8
+    big = log_n >= 23
+    # above 2^22 only fft and icoset_fft are compared with the oracle; ifft and coset_fft are then pinned as the
+    # inverse maps of verified maps by the two round trips below (halves the oracle time of the 3-pass sizes)
     for mode, name in enumerate(("fft", "ifft", "coset_fft", "icoset_fft")):
+        if big and name in ("ifft", "coset_fft"):
+            continue
         d = bellman_amd.EvaluationDomain.from_coeffs(worker, data)
         getattr(d, name)()
         got = d.into_coeffs()
         assert np.array_equal(got, cref.fft(data, mode, threads=threads)), (log_n, name)
-    # icoset_fft(coset_fft(x)) == x on the device alone
     d = bellman_amd.EvaluationDomain.from_coeffs(worker, data)
     d.coset_fft()
     d.icoset_fft()
+    assert np.array_equal(d.as_ref(), data)
+    d.fft()
+    d.ifft()
     assert np.array_equal(d.into_coeffs(), data)
 
 

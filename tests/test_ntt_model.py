@@ -1,6 +1,7 @@
-"""The kernel's pass/tile decomposition (modelled in tests/models/ntt_model.py, which mirrors
-bellman_amd/csrc/fft.hip statement by statement) equals the restated serial_fft
-(src/domain.rs:272-314) for every pass count L = 1..4, forward / inverse / coset variants."""
+"""The kernel's pass / tile / register-step decomposition (modelled in tests/models/ntt_model.py, which mirrors
+bellman_amd/csrc/fft.hip statement by statement) equals the restated serial_fft (src/domain.rs:272-314) for
+every pass count L = 1..3, every stage-group pattern (radix 8 / 4 / 2 steps), forward / inverse / coset
+variants, with the tile shrunk so that the multi-pass plans are reachable at Python speed."""
 
 import random
 
@@ -9,47 +10,57 @@ import pytest
 from oracle.pyref.domain import EvaluationDomain
 from oracle.pyref.engines import Bls12, DummyEngine
 from oracle.pyref.multicore import Worker
-from tests.models.ntt_model import ntt_model, plan_passes
+from tests.models.ntt_model import ntt_model, plan_passes, step_groups
 
 
+def _check(F, vals, log_n, log_tile, max_r, threads, names=("fft", "ifft", "coset_fft", "icoset_fft")):
+    for name in names:
+        d = EvaluationDomain.from_coeffs(F, vals)
+        getattr(d, name)(Worker(1))
+        inverse = name in ("ifft", "icoset_fft")
+        kw = {}
+        if name == "coset_fft":
+            kw["pre_g"] = F.MULTIPLICATIVE_GENERATOR
+        if name == "icoset_fft":
+            kw["post_g"], kw["post_scale"] = d.geninv, d.minv
+        if name == "ifft":
+            kw["post_const"] = d.minv
+        got = ntt_model(vals, F.r, d.omega, log_n, inverse=inverse, log_tile=log_tile, max_r=max_r, threads=threads, **kw)
+        assert got == d.coeffs, (name, log_n, log_tile, max_r)
+
+
+# (log_tile, max_r, threads): the toy field F_64513 has 2-adicity 10 (domains up to 2^9) and the tile has to shrink for
+# two- and three-pass plans; threads < tasks exercises the task loop, threads > tasks the idle lanes
+@pytest.mark.parametrize("cfg", [(4, 4, 2), (5, 4, 4), (5, 5, 64), (6, 3, 8), (4, 2, 4), (7, 7, 16)])
 @pytest.mark.parametrize("log_n", range(0, 10))
-@pytest.mark.parametrize("cfg", [(10, 8), (3, 2), (4, 3), (5, 3)])
 def test_model_matches_serial_fft_toy_field(log_n, cfg):
-    log_tile, max_r = cfg
-    if len(plan_passes(log_n, log_tile, max_r)) > 4:
-        pytest.skip("more than 4 passes")
+    log_tile, max_r, threads = cfg
+    if len(plan_passes(log_n, max_r)) > 3:
+        pytest.skip("more than 3 passes")
     F = DummyEngine.Fr
     rnd = random.Random(log_n * 17 + log_tile)
     vals = [rnd.randrange(F.r) for _ in range(1 << log_n)]
-    for name, inverse in [("fft", False), ("ifft", True), ("coset_fft", False), ("icoset_fft", True)]:
-        d = EvaluationDomain.from_coeffs(F, vals)
-        getattr(d, name)(Worker(1))
-        n = 1 << log_n
-        g, ginv, minv = F.MULTIPLICATIVE_GENERATOR, d.geninv, d.minv
-        pre = [pow(g, i, F.r) for i in range(n)] if name == "coset_fft" else None
-        post = [pow(ginv, i, F.r) * minv % F.r for i in range(n)] if name == "icoset_fft" else None
-        pc = minv if name == "ifft" else None
-        got = ntt_model(vals, F.r, d.omega, log_n, inverse=inverse, pre=pre, post=post, post_const=pc,
-                        log_tile=log_tile, max_r=max_r)
-        assert got == d.coeffs, (name, log_n, cfg)
+    _check(F, vals, log_n, log_tile, max_r, threads)
 
 
-def test_model_real_plan_bls_2_12():
-    """One real-plan (tile 2^10, radix <= 2^8) two-pass case over BLS12-381 Fr."""
+@pytest.mark.parametrize("log_n", [11, 12, 13])
+def test_model_real_tile_bls(log_n):
+    """The real tile (2^11 elements, 256 threads, sub-FFTs up to 2^11) over BLS12-381 Fr: one pass at 2^11
+    (steps 3+3+3+2), two passes at 2^12 (6+6: 3+3) and 2^13 (7+6: 3+2+2 and 3+3)."""
     F = Bls12.Fr
-    rnd = random.Random(1)
-    log_n = 11
+    rnd = random.Random(log_n)
     vals = [rnd.randrange(F.r) for _ in range(1 << log_n)]
-    d = EvaluationDomain.from_coeffs(F, vals)
-    d.fft(Worker(1))
-    assert plan_passes(log_n) == [6, 5]
-    assert ntt_model(vals, F.r, d.omega, log_n) == d.coeffs
+    _check(F, vals, log_n, 11, 11, 256, names=("fft", "icoset_fft") if log_n > 11 else ("fft", "ifft", "coset_fft", "icoset_fft"))
 
 
 def test_plan_shapes():
-    assert plan_passes(10) == [10]
-    assert plan_passes(20) == [7, 7, 6]
-    assert plan_passes(22) == [8, 7, 7]
+    assert plan_passes(10) == [10] and plan_passes(11) == [11]
+    assert plan_passes(12) == [6, 6]
+    assert plan_passes(20) == [10, 10]
+    assert plan_passes(21) == [11, 10]
+    assert plan_passes(22) == [11, 11]            # two passes up to 2^22
+    assert plan_passes(23) == [8, 8, 7]
     assert plan_passes(24) == [8, 8, 8]
-    assert plan_passes(26) == [7, 7, 6, 6]
-    assert plan_passes(31) == [8, 8, 8, 7]
+    assert plan_passes(31) == [11, 10, 10]
+    assert step_groups(11) == [3, 3, 3, 2] and step_groups(10) == [3, 3, 2, 2] and step_groups(8) == [3, 3, 2]
+    assert step_groups(7) == [3, 2, 2] and step_groups(4) == [2, 2] and step_groups(1) == [1] and step_groups(0) == []
