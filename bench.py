@@ -279,10 +279,135 @@ def bench_fft(worker, lib, log_n=22, iters=10):
     return out
 
 
+def bench_msm_shape(worker, lib, group, log_n, iters=10):
+    """One more multiexp shape (device-resident inputs, bases registered once): G2 at the size it has inside a
+    2^20-constraint proof (2^19) and at 2^20; G1 at 2^16, the shape of the reference's own bench
+    (benches/slow.rs:14-44).  Median wall time of `iters` calls after 2 warm-ups."""
+    import bellman_amd
+
+    n = 1 << log_n
+    words = 12 if group == 1 else 24
+    gen = G1_GEN_MONT if group == 1 else G2_GEN_MONT
+    t = splitmix_scalars(n, 0xB45E5 + group)
+    dt, dout = worker.alloc(n * 32), worker.alloc(n * 8 * words)
+    worker.upload(dt, t)
+    assert lib.bh_fixed_base_mul_dev(worker.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+    worker.synchronize()
+    bases = bellman_amd.Bases.wrap_device(worker, group, dout, n)
+    sc = splitmix_scalars(n, 0x5CA1A + group)
+    worker.upload(dt, sc)
+    walls, stages = [], []
+    for it in range(iters + 2):
+        t0 = time.perf_counter()
+        _, ms = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=dt, n=n, timed=True).wait()
+        if it >= 2:
+            walls.append((time.perf_counter() - t0) * 1e3)
+            stages.append(ms)
+    bases.release()
+    worker.free(dt)
+    worker.free(dout)
+    med = float(np.median(walls))
+    st = np.median(np.array(stages), axis=0)
+    return {"group": "G%d" % group, "log_n": log_n, "ms_median": round(med, 4), "Mscalar_mul_per_s": round(n / med / 1e3, 3),
+            "device_ms": {"pipeline": round(float(st[0]), 4), "digits_sort": round(float(st[1]), 4),
+                          "bucket_accumulate": round(float(st[2]), 4), "merge_reduce": round(float(st[3]), 4)},
+            "samples": iters}
+
+
+def bench_mimc(worker, proofs=30, cpu_baseline=True):
+    """BASELINE config C1: groth16::create_proof on MiMC-322 (groth16/tests/mimc.rs: 646 constraints, m = 2^10),
+    through the C++ mirror of the circuit; CPU baseline = the C restatement of prover.rs:217-360 on the same
+    assignment (all host threads), whose proof the GPU proof must equal."""
+    import random
+
+    from bellman_amd import groth16 as pg
+    from oracle.pyref import bls12_381 as bls
+    from tests import circuits
+
+    rnd = random.Random(322)
+    cons = [rnd.randrange(bls.Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr = rnd.randrange(bls.Q), rnd.randrange(bls.Q)
+    r, s = rnd.randrange(bls.Q), rnd.randrange(bls.Q)
+    r1cs = pg.R1CS.from_demo(worker, 0, circuits.MIMC_ROUNDS, 0, cons)
+    params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+    walls = []
+    for i in range(proofs + 3):
+        t0 = time.perf_counter()
+        last = pg.create_proof_demo(params, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s)
+        if i >= 3:
+            walls.append((time.perf_counter() - t0) * 1e3)
+    med = float(np.median(walls))
+    out = {"workload": "groth16::create_proof, MiMC-322 (646 constraints, domain 2^10; BASELINE.json configs[0] on the GPU)",
+           "ms_median": round(med, 4), "proofs_per_s": round(1e3 / med, 2), "samples": proofs}
+    if cpu_baseline:
+        from oracle import cprover, cref
+        from oracle.pyref.core import INPUT, Variable
+        from oracle.pyref.prover import ProvingAssignment
+
+        pa = ProvingAssignment(bls.Q)
+        pa.alloc_input(lambda: 1)
+        circuits.mimc_circuit(xl, xr, cons)(pa)
+        for i in range(len(pa.input_assignment)):
+            pa.enforce(lambda lc, i=i: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
+        h, l, a, b1, b2 = (params.query(q) for q in ("h", "l", "a", "b_g1", "b_g2"))
+        vkr = params.vk()
+        vk = dict(alpha_g1=vkr[0], beta_g1=vkr[1], beta_g2=vkr[2], delta_g1=vkr[3], delta_g2=vkr[4])
+        threads = cref.lib().orc_max_threads()
+        best = None
+        for _ in range(3):
+            tc = {}
+            want = cprover.prove_assignment(pa.a, pa.b, pa.c, pa.input_assignment, pa.aux_assignment, list(pa.a_aux_density.bv),
+                                            list(pa.b_input_density.bv), list(pa.b_aux_density.bv), vk, h, l, a, b1, b2, r, s,
+                                            threads=threads, concurrent=True, timing=tc)
+            best = tc["total_s"] if best is None else min(best, tc["total_s"])
+        assert last.a.tobytes() == want[0].tobytes() and last.b.tobytes() == want[1].tobytes() and \
+            last.c.tobytes() == want[2].tobytes(), "GPU MiMC proof differs from the CPU oracle's"
+        out["cpu_baseline"] = {"value": round(1.0 / best, 2), "unit": "proofs/s", "cores": threads, "kind": "port",
+                               "sample": "best of 3 runs of the C restatement of prover.rs:217-360 on the same MiMC-322 assignment "
+                                         "(synthesis excluded); proof bit-identical to the GPU's", "seconds": round(best, 5)}
+    r1cs.release()
+    params.release()
+    return out
+
+
+def check_sharded_fold(worker, lib, world, rank, coll_dev, log_n_check=12):
+    """N > 1: the fold of the per-rank partial results of a base-sharded multiexp equals ONE multiexp over the
+    concatenation of all shards (computed on every rank from the same seeds), at a size where that is cheap.
+    The shards are made exactly like the timed ones (seed offset per rank)."""
+    import bellman_amd
+    from bellman_amd import sharding
+
+    n = 1 << log_n_check
+
+    def shard(rk):
+        return splitmix_scalars(n, 0x62656C6C6D616E + rk * 4 * n), splitmix_scalars(n, 0x5CA1A25 + rk * 4 * n)
+
+    def msm(t, sc):
+        m = t.shape[0]
+        dt, dout, ds = worker.alloc(m * 32), worker.alloc(m * 96), worker.alloc(m * 32)
+        worker.upload(dt, t)
+        worker.upload(ds, sc)
+        assert lib.bh_fixed_base_mul_dev(worker.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), dt, m, 0, dout, None) == 0
+        worker.synchronize()
+        b = bellman_amd.Bases.wrap_device(worker, 1, dout, m)
+        out = bellman_amd.multiexp(worker, b, bellman_amd.FullDensity(), None, scalars_dev=ds, n=m).wait()
+        b.release()
+        for d in (dt, dout, ds):
+            worker.free(d)
+        return out
+
+    t, sc = shard(rank)
+    folded = sharding.fold_partials(msm(t, sc), 1, device=coll_dev if coll_dev == "cuda" else None)
+    parts = [shard(rk) for rk in range(world)]
+    whole = msm(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+    assert np.array_equal(folded, whole), "fold of the sharded multiexp differs from the multiexp of the concatenated shards"
+    return "fold of %d shards of 2^%d terms == one multiexp of 2^%d x %d terms (checked on every rank)" % (world, log_n_check, log_n_check, world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,6 +415,8 @@ def main():
     ap.add_argument("--proof-log-n", type=int, default=20)
     ap.add_argument("--c5-log-n", type=int, default=26,
                     help="N > 1 only: total size of the extra sharded MSM of BASELINE configs[4] (0 = skip)")
+    ap.add_argument("--check-log-n", type=int, default=12,
+                    help="N > 1 only: per-rank size of the fold == concatenated-multiexp check")
     ap.add_argument("--timed-steps-only", action="store_true",
                     help="run only warm-up + the K timed steps (no overlapped / PCIe extras): the command profiled for "
                          "profiles/*kernel_stats.csv, so that rocprof's per-kernel average matches the live HIP-event figure")
@@ -358,8 +485,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     stage = np.zeros(4)
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         result, ms = step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         stage += np.array(ms)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -400,6 +530,9 @@ def main():
             bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), s_host).wait()
         pcie_value = n * max(1, min(args.steps, 5)) / (time.perf_counter() - th0) / 1e6
 
+    sharded_check = None
+    if distributed:
+        sharded_check = check_sharded_fold(worker, lib, world, rank, coll_dev, args.check_log_n)
     sharded_proof = None
     if distributed and not args.no_proof:
         sharded_proof = bench_create_proof_sharded(worker, args.proof_log_n, world, rank, coll_dev)
@@ -460,6 +593,11 @@ def main():
                 "sharding": "bases split across ranks, one 96-B all-gather per step" if distributed else "single GPU",
                 "device_ms": {"pipeline": round(float(stage[0]), 4), "digits_sort": round(float(stage[1]), 4),
                               "bucket_accumulate": round(acc_ms, 4), "merge_reduce": round(float(stage[3]), 4)},
+                "headline": "`value` = terms of all ranks / wall time of the K timed steps (mean, the driver's contract), scalars and "
+                            "bases RESIDENT in HBM - the state multiexp is called in inside create_proof, where the scalars are "
+                            "produced on the device; the PCIe-inclusive rate (32 MiB of host scalars per call) is the last field",
+                "ms_per_step_median": round(float(np.median(step_ms)), 4),
+                "value_at_median_step": round(world * n / float(np.median(step_ms)) / 1e3, 3),
                 "value_with_2_jobs_in_flight": round(pipelined_value, 3) if pipelined_value else None,
                 "value_per_gpu_with_host_scalars_pcie_inclusive": round(pcie_value, 3) if pcie_value else None,
             },
@@ -478,7 +616,11 @@ def main():
                 "alu": {"unit": "Tmad/s", "peak": 26.2,
                         "achieved": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
                         "frac": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
-                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273) v_mad_u64_u32"},
+                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273) v_mad_u64_u32",
+                        "peak_provenance": "v_mad_u64_u32 microbenchmark on this chip (tools/microbench_int.hip, "
+                                           "profiles/r1_microbench_int.txt) at its sustained clock; under the accumulate kernel the "
+                                           "SQ counters put the clock near 2.0 GHz (profiles/r1_pmc_valu.json), so the fraction is "
+                                           "against a peak measured at a higher clock (conservative)"},
             },
         }
         if not args.no_cpu_baseline and not distributed:   # rank 0 at N=1 only
@@ -504,11 +646,16 @@ def main():
                 "sample": "same 2^%d-term G1 MSM, 1 run, C restatement of bellman's rayon path "
                           "(c=%d, %d window tasks, %d host threads available)" % (args.log_n, c_ref, windows, threads),
             }
+        if sharded_check is not None:
+            out["sharded_fold_check"] = sharded_check
         if sharded_proof is not None:
             out["create_proof_sharded"] = sharded_proof
         if c5 is not None:
-            out["msm_2p26_sharded"] = c5
+            out["msm_c5_sharded"] = c5
         if not args.no_proof and not distributed:
+            out["msm_other_shapes"] = [bench_msm_shape(worker, lib, 2, 19), bench_msm_shape(worker, lib, 2, 20),
+                                       bench_msm_shape(worker, lib, 1, 16)]
+            out["create_proof_mimc"] = bench_mimc(worker, cpu_baseline=not args.no_cpu_baseline)
             out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of

@@ -1,0 +1,56 @@
+"""bench.py plumbing on one GPU, so that the first real multi-GPU run cannot fail on anything but the hardware:
+the N = 2 launch exactly as the driver does it (`python -m torch.distributed.run ... bench.py --gpus 2`), with
+BENCH_BACKEND=gloo so that both ranks can share GPU 0 (RCCL needs one device per rank), at small sizes; the JSON
+line must carry the contract's keys and the parity assertions of the sharded legs must have run.  N > 1 numbers
+themselves are NOT measured anywhere in this repository's own runs (one GPU per gpurun box)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _last_json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_contract_small():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--log-n", "12", "--no-proof"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = _last_json_line(r.stdout)
+    for k in CONTRACT_KEYS + ("cpu_baseline",):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "Mscalar-mul/s" and out["value"] > 0 and out["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"])
+    assert "workload" in out["config"] and "model" not in out["config"]
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "12",
+           "--proof-log-n", "10", "--c5-log-n", "13", "--check-log-n", "10"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    for k in CONTRACT_KEYS:
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    # the parity assertions of the N > 1 legs ran (they raise inside bench.py otherwise)
+    assert "== one multiexp" in out["sharded_fold_check"]
+    assert out["create_proof_sharded"]["scaling"] == "strong" and "identical to the single-GPU proof" in out["create_proof_sharded"]["workload"]
+    assert out["msm_c5_sharded"]["scaling"] == "strong" and out["msm_c5_sharded"]["value"] > 0
+    assert "cpu_baseline" not in out          # rank 0 at N = 1 only
