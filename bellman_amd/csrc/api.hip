@@ -150,13 +150,13 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
   }
   return BH_OK;
 }
-// Base vectors of up to 2^BELLMAN_HIP_TABLE_MAX_LOG2 points (default 12; 0 = never) get their window table at
+// Base vectors of up to 2^BELLMAN_HIP_TABLE_MAX_LOG2 points (default 16; 0 = never) get their window table at
 // registration: a multiexp over a few thousand terms is a chain of latency-bound steps, and with the table the
 // chain loses the 255-step doubling ladder over the windows (the CRS is registered once per circuit).
 static unsigned auto_table_max_log2() {
   static const unsigned v = [] {
     const char *e = getenv("BELLMAN_HIP_TABLE_MAX_LOG2");
-    if (!e || !*e) return 12u;
+    if (!e || !*e) return 16u;
     const long x = strtol(e, nullptr, 10);
     return (unsigned)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();

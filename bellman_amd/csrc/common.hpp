@@ -92,6 +92,7 @@ struct FftTables {
   BTw *coset_lo = nullptr, *coset_hi = nullptr;                           // 7^i
   BTw *icoset_lo = nullptr, *icoset_hi = nullptr;                         // 7^-i / n
   fr_t minv;                                                              // n^-1 (Montgomery)
+  fr_t zinv;                                                              // (7^n - 1)^-1: divide_by_z_on_coset
   BTw *minv_dev = nullptr;                                                // ... as a one-entry table
 };
 

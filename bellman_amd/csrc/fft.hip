@@ -350,6 +350,14 @@ static fr_t fr_pow_u64_host(const fr_t &a, u64 e) {
   return r;
 }
 
+static fr_t zinv_host(uint32_t log_n) {  // domain.rs:129-140: (7^m - 1)^-1
+  fr_t g = fr_from_u64_host(7), z = fr_pow_u64_host(g, (u64)1 << log_n), one, zi;
+  fe_one(one);
+  fe_sub(z, z, one);
+  fe_inv(zi, z);
+  return zi;
+}
+
 static PowTable make_pow_table(const fr_t &g, const fr_t &scale) {
   PowTable tab;
   tab.p2[0] = g;
@@ -419,6 +427,7 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     t.lb = (log_n + 1) / 2;
     fr_t nn = fr_from_u64_host(n);
     fe_inv(t.minv, nn);
+    t.zinv = zinv_host(log_n);   // ~800 host field products: computed once per domain size, not per proof
     int rc = make_btw_table(&t.minv_dev, 1, one, t.minv, st);   // the single entry 1/n
     if (rc) return rc;
     generated = true;
@@ -522,16 +531,20 @@ int fr_sub_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st) {
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
-static fr_t zinv_host(uint32_t log_n) {  // domain.rs:129-140: (7^m - 1)^-1
-  fr_t g = fr_from_u64_host(7), z = fr_pow_u64_host(g, (u64)1 << log_n), one, zi;
-  fe_one(one);
-  fe_sub(z, z, one);
-  fe_inv(zi, z);
-  return zi;
+static int cached_zinv(Context &c, uint32_t log_n, hipStream_t st, fr_t *out) {
+  FftTables tab;
+  const BTw *master = nullptr;
+  int rc = get_tables(c, log_n, false, false, false, false, st, &tab, &master);
+  if (rc) return rc;
+  *out = tab.zinv;
+  return BH_OK;
 }
 int fr_divide_by_z(Context &c, fr_t *a, uint32_t log_n, hipStream_t st) {
   u64 n = (u64)1 << log_n;
-  hipLaunchKernelGGL(fr_scale_kernel, dim3(ew_blocks(c, n)), dim3(256), 0, st, a, zinv_host(log_n), n);
+  fr_t zinv;
+  int rc = cached_zinv(c, log_n, st, &zinv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fr_scale_kernel, dim3(ew_blocks(c, n)), dim3(256), 0, st, a, zinv, n);
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
@@ -555,7 +568,9 @@ int h_poly_dev(Context &c, fr_t *a, fr_t *b, fr_t *cc, fr_t *scratch, uint32_t l
     if ((rc = ntt_run(c, v[i], scratch, log_n, BH_COSET_FFT, st))) return rc;
   }
   u64 n = (u64)1 << log_n;
-  hipLaunchKernelGGL(fr_quotient_kernel, dim3(ew_blocks(c, n)), dim3(256), 0, st, a, b, cc, zinv_host(log_n), n);
+  fr_t zinv;
+  if ((rc = cached_zinv(c, log_n, st, &zinv))) return rc;
+  hipLaunchKernelGGL(fr_quotient_kernel, dim3(ew_blocks(c, n)), dim3(256), 0, st, a, b, cc, zinv, n);
   BH_HIP_CHECK(hipGetLastError());
   return ntt_run(c, a, scratch, log_n, BH_ICOSET_FFT, st);
 }

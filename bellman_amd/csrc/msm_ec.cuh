@@ -201,27 +201,32 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
   }
 }
 
-// One 512-thread workgroup per long run: tail[l0] + sum of head[l0+1 .. l1].
-constexpr u32 LONG_THREADS = 512;
-template <class F>
-__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 *pairs, const u32 *zstart,
-                                                                      XYZZ<typename F::Mem> *pts,
-                                                                      const XYZZ<typename F::Mem> *head,
-                                                                      const XYZZ<typename F::Mem> *tail, u32 n, u32 c,
-                                                                      u32 K, u32 chunks_per_window,
-                                                                      const LongRun *long_runs, u32 max_long,
-                                                                      const ErrFlags *err) {
-  constexpr u32 PW = tree_per_wave<F>(), NWAVES = LONG_THREADS / 64, NWORK = workers_per_block<F>(LONG_THREADS, PW);
+// Runs that span more than a couple of chunks: tail[l0] + sum of head[l0+1 .. l1], one block per run.
+// THREADS = 64: one wavefront per run - the common medium case (the top window of the 13-bit plans, whose buckets
+// are several times fuller than the others: 8-16 chunks), no workgroup barrier on the way; runs longer than
+// BIG_RUN_CHUNKS are passed on (big_runs) to the THREADS = 512 instance - boolean-heavy witnesses put half the
+// scalars of window 0 into ONE bucket.
+constexpr u32 BIG_RUN_CHUNKS = 512;
+template <class F, u32 THREADS>
+__global__ __launch_bounds__(THREADS) void msm_merge_long_kernel(const u64 *pairs, const u32 *zstart,
+                                                                 XYZZ<typename F::Mem> *pts,
+                                                                 const XYZZ<typename F::Mem> *head,
+                                                                 const XYZZ<typename F::Mem> *tail, u32 n, u32 c,
+                                                                 u32 K, u32 chunks_per_window,
+                                                                 const LongRun *runs, u32 max_runs, LongRun *big_runs,
+                                                                 u32 max_big, ErrFlags *err) {
+  constexpr u32 PW = tree_per_wave<F>(), NWAVES = THREADS / 64, NWORK = workers_per_block<F>(THREADS, PW);
+  constexpr bool DEFER = (THREADS == 64);
   __shared__ XYZZ<F> wave_part[NWAVES][F::LANES];
   __shared__ u32 s_last;
-  u32 nlong = err->nlong;
-  if (nlong > max_long) nlong = max_long;
+  u32 nruns = DEFER ? err->nlong : err->nbig;
+  if (nruns > max_runs) nruns = max_runs;
   u32 wid, gid;
   const bool live = worker_index<F>(PW, wid, gid);   // idle lanes stay for the barriers
   const u32 wave = threadIdx.x >> 6, t_in_wave = wid - wave * PW;
   const u32 role = F::LANES == 1 ? 0u : k3_role();
-  for (u32 e = blockIdx.x; e < nlong; e += gridDim.x) {
-    const LongRun lr = long_runs[e];
+  for (u32 e = blockIdx.x; e < nruns; e += gridDim.x) {
+    const LongRun lr = runs[e];
     const u64 *src = pairs + (u64)lr.w * n;
     const u32 z = zstart[lr.w];
     if (threadIdx.x == 0) {   // last sorted position holding digit d -> last chunk of the run
@@ -230,10 +235,18 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
         const u32 mid = lo + ((hi - lo) >> 1);
         if ((u32)(src[mid] >> 32) <= lr.d) lo = mid + 1; else hi = mid;
       }
-      s_last = (lo - 1 - z) / K;
+      u32 last = (lo - 1 - z) / K;
+      if (DEFER && last - lr.lane > BIG_RUN_CHUNKS) {
+        const u32 slot = atomicAdd(&err->nbig, 1u);
+        if (slot < max_big) big_runs[slot] = lr;
+        last = 0xffffffffu;   // passed on
+      }
+      s_last = last;
     }
     __syncthreads();
     const u32 l1 = s_last;
+    __syncthreads();          // s_last is rewritten by the next iteration
+    if (l1 == 0xffffffffu) continue;
     const u64 slot0 = (u64)lr.w * chunks_per_window;
     XYZZ<F> acc;
     xyzz_set_identity(acc);
@@ -246,15 +259,17 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(const u64 
         acc = r;
       }
       group_reduce_points<F>(acc, PW, t_in_wave);
-      if (t_in_wave == 0) wave_part[wave][role] = acc;
+      if (NWAVES > 1 && t_in_wave == 0) wave_part[wave][role] = acc;
     }
-    __syncthreads();
-    if (wave == 0 && live) {
-      if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
-      group_reduce_points<F>(acc, NWAVES, t_in_wave);
-      if (t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
+    if (NWAVES > 1) {
+      __syncthreads();
+      if (wave == 0 && live) {
+        if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
+        group_reduce_points<F>(acc, NWAVES, t_in_wave);
+      }
     }
-    __syncthreads();
+    if (wave == 0 && live && t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
+    if (NWAVES > 1) __syncthreads();
   }
 }
 
@@ -458,10 +473,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 npairs = (u64)p.Wd * n;
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nslots = (u64)p.W * p.chunks_per_window;
-  // serial walk bound: 4x the average number of chunks per bucket, at least 8, at most 32 - longer runs go to the
-  // workgroup-parallel merge (window-table plans with few buckets have runs of hundreds of chunks)
-  const u32 walk = std::min<u32>(32, std::max<u32>(8, 4 * ((p.n >> (p.c - 1)) / p.chunk + 1)));
+  // the owner lane of a run folds at most `walk` following chunks itself; longer runs are queued for the
+  // wavefront-parallel merge (a chain of point additions costs ~20 us per link: 8-chunk runs, walked serially,
+  // were 0.24 ms of every 2^14-term multiexp), the longest of those for the workgroup-parallel one
+  const u32 walk = 2;
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
+  const u32 max_big = (u32)(nslots / (BIG_RUN_CHUNKS + 1) + 1);
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
   const u64 nwords = (n + 63) / 64;
   size_t off = 0;
@@ -473,7 +490,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_pairs_a = carve(npairs * 8), o_pairs_b = carve(npairs * 8);
   const size_t o_counts = carve(ncounts * 4), o_scan = carve(scan_tmp_elems(ncounts) * 4), o_zstart = carve((u64)p.W * 4);
   const size_t o_head = carve(nslots * sizeof(Pt)), o_tail = carve(nslots * sizeof(Pt));
-  const size_t o_long = carve((u64)max_long * sizeof(LongRun));
+  const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(LongRun));
   const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
   // per window: (c-1) bit sums U[w][p] followed by W plain totals T[w]
   const size_t o_bits = carve((u64)p.W * p.c * sizeof(Pt));
@@ -487,7 +504,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   b.counts = (u32 *)(ws + o_counts); b.scan_tmp = (u32 *)(ws + o_scan); b.zstart = (u32 *)(ws + o_zstart);
   b.word_prefix = density_dev ? (u32 *)(ws + o_prefix) : nullptr;
   Pt *pts = (Pt *)(ws + o_pts), *head = (Pt *)(ws + o_head), *tail = (Pt *)(ws + o_tail);
-  LongRun *long_runs = (LongRun *)(ws + o_long);
+  LongRun *long_runs = (LongRun *)(ws + o_long), *big_runs = (LongRun *)(ws + o_big);
   Pt *rowcol = (Pt *)(ws + o_rowcol), *bits = (Pt *)(ws + o_bits);
   ErrFlags *err = b.err;
   job.err_dev = err;
@@ -523,8 +540,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
                        p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_merge_long_kernel<F>, dim3(256), dim3(LONG_THREADS), 0, st, sorted, b.zstart, pts, head,
-                       tail, p.n, p.c, p.chunk, p.chunks_per_window, long_runs, max_long, err);
+    hipLaunchKernelGGL((msm_merge_long_kernel<F, 64>), dim3((u32)c.num_cus * 8), dim3(64), 0, st, sorted, b.zstart, pts,
+                       head, tail, p.n, p.c, p.chunk, p.chunks_per_window, long_runs, max_long, big_runs, max_big, err);
+    BH_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((msm_merge_long_kernel<F, 512>), dim3(256), dim3(512), 0, st, sorted, b.zstart, pts, head, tail,
+                       p.n, p.c, p.chunk, p.chunks_per_window, big_runs, max_big, (LongRun *)nullptr, 0u, err);
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
@@ -808,13 +828,15 @@ template <class F> static void devhdr_point_add_t(void *r, const void *a, const 
 }
 template <class F> static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) { generic_point_mul<F>(r, a, k); }
 
-// OPS = the record format in memory (FpOps / Fp2Ops); KOPS = what the MSM kernels compute with; ALT = a second
-// kernel bundle selected by `ALT_FLAG` in bh_msm_opts.flags (the single-lane G2 kernels, kept for comparison)
-#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, ALT_FLAG)                                                  \
+// OPS = the record format in memory (FpOps / Fp2Ops); KOPS / ALT = the two kernel bundles of the group: ALT runs
+// jobs of more than ALT_ABOVE terms; bh_msm_opts.flags KOPS_FLAG / ALT_FLAG force one of them
+#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, KOPS_FLAG, ALT_FLAG, ALT_ABOVE)                            \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
                            const void *scalars_dev, u64 n, int fmt, const u64 *density_dev,                 \
                            const MsmOpts &opts, const WindowTable *table) {                                  \
-    if (opts.flags & (ALT_FLAG))                                                                              \
+    /* the alternative bundle above ALT_ABOVE terms, or whenever a flag forces one of the two */             \
+    const bool alt = (opts.flags & (ALT_FLAG)) ? true : (opts.flags & (KOPS_FLAG)) ? false : n > (ALT_ABOVE);      \
+    if (alt)                                                                                                  \
       return msm_enqueue<ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table); \
     return msm_enqueue<KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
   }                                                                                                           \

@@ -229,7 +229,11 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   const u32 lg = ilog2(n ? n : 1);
   // re-swept after the field-arithmetic changes (profiles/r1_tune_small_sizes.txt, second table): the
   // cheaper additions moved every boundary down by 2-3 powers of two
-  int c = g2 ? (lg <= 12 ? 8 : lg <= 15 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : 16);
+  // G2 keeps c = 13 up to 2^18: its bucket reduction is two G2 additions per bucket and throughput-bound, 16 windows
+  // of 2^15 buckets cost 2.1 ms whatever n is - more than the 25 % extra accumulation of 20 windows below 2^19
+  // (profiles/r2_call2_*).  From 2^25 terms on the accumulation saved by 13 windows of 20 bits outweighs the
+  // 6.8 M-bucket reduction (2^24: 50 -> 40 ms accumulate for +9 ms of reduction and a third sort pass).
+  int c = g2 ? (lg <= 12 ? 8 : lg <= 18 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 24 ? 16 : 20);
   if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
@@ -257,8 +261,10 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
 // span a few chunks at most), which is 3-4 bits more than the classic plan uses for the same n.
 unsigned table_window_bits(u64 n_bases, bool g2) {
   (void)g2;
-  const u32 lg = ilog2(n_bases ? n_bases : 1);
-  return std::min(16u, std::max(8u, lg + 3));
+  // only window sizes whose top window is not a sliver (260 = 20 x 13, 256 = 16 x 16): a sliver puts the top digit of
+  // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/r2_call2_sizes_and_table_sweeps.txt:
+  // c = 12 and 14 are 1.5-2x slower than 13 at 2^10-2^14)
+  return ilog2(n_bases ? n_bases : 1) <= 11 ? 13 : 16;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
@@ -278,7 +284,7 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   // in the merge), at least the classic value, but never so large that the chip runs out of lanes
   const u32 lg = ilog2(p.n ? p.n : 1);
   // few entries: short chunks, the job is a chain of latency-bound steps and the chip is mostly idle
-  const u32 base_k = lg <= 15 ? 4 : lg <= 17 ? 8 : lg <= 19 ? 16 : g2 ? 64 : 32;
+  const u32 base_k = lg <= 20 ? 8 : lg <= 22 ? 16 : g2 ? 64 : 32;
   const u64 avg = (u64)p.n >> (p.c - 1);
   const u64 lanes_wanted = (u64)num_cus * 4 * 64 * 2;   // two wavefronts per SIMD
   u64 k = std::max<u64>(base_k, avg / 4);

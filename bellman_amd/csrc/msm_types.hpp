@@ -8,8 +8,9 @@ struct ErrFlags {       // device-side status word block
   u32 eof;              // a dense entry found the base cursor at/after the end (multiexp.rs:55-61,74-80)
   u32 ident;            // an identity base was consumed (multiexp.rs:63-65)
   u32 ident_top;        // ... in the reference's top window, before the first EOF entry
-  u32 nlong;            // number of long bucket runs queued for the workgroup-parallel merge
-  u32 pad[4];
+  u32 nlong;            // number of bucket runs queued for the wavefront-parallel merge
+  u32 nbig;             // ... of those, runs long enough to be passed on to the workgroup-parallel merge
+  u32 pad[3];
 };
 
 enum { SUM_STRIDED = 1, SUM_BITS = 2 };

@@ -190,7 +190,8 @@ typedef struct {
 #define BH_MSM_ACC_LDS 2u       /* ... in LDS */
 #define BH_MSM_NO_TABLE 4u      /* ignore a window table attached to the bases */
 #define BH_MSM_NO_SMALL_PATH 8u /* run the full pipeline even for a handful of terms */
-#define BH_MSM_G2_SINGLE_LANE 16u /* G2: one lane per point instead of the lane-triple (Karatsuba) form */
+#define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default above 2^15 terms) */
+#define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default up to 2^15 terms) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
                       size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
                       size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);

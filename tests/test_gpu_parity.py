@@ -184,7 +184,7 @@ def test_msm_g2_single_lane_kernels_still_agree(worker, n):
     hb = bellman_amd.Bases(worker, 2, bases)
     rc, want = cref.multiexp(2, bases, 0, None, sc)
     assert rc == 0
-    for flags in (0, 16, NO_TABLE, 16 | NO_TABLE):
+    for flags in (0, 16, 32, NO_TABLE, 16 | NO_TABLE, 32 | NO_TABLE):   # 16: one lane per point, 32: lane triples
         assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=flags).wait(), want), flags
 
 

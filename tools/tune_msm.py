@@ -40,9 +40,9 @@ def main():
             print("  window table c=%d: %s built in %.2f s" % (c, bases.table_info(), time.time() - t0), flush=True)
         for k in ks:
             best = None
-            for it in range(4):   # BH_ACC=1 / 2: force the register / LDS accumulator (bh_msm_opts.flags)
+            for it in range(4):   # BH_ACC=1 / 2: register / LDS accumulator; BH_FLAGS: any other bh_msm_opts.flags (4 no table, 16 / 32 G2 kernel bundle)
                 r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
-                                             window_bits=c, chunk=k, flags=int(os.environ.get('BH_ACC', '0'))).wait()
+                                             window_bits=c, chunk=k, flags=int(os.environ.get('BH_ACC', '0')) | int(os.environ.get('BH_FLAGS', '0'))).wait()
                 if best is None or ms[0] < best[0]:
                     best = ms
             if ref is None:
