@@ -18,7 +18,7 @@ EXPORTS = [
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
     "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_trim",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
-    "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev",
+    "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_msm_async_opts", "bh_msm_async_dev_opts",
     "bh_fixed_base_mul_dev",
@@ -83,6 +83,7 @@ def load():
     lib.bh_fr_distribute_powers_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.bh_h_poly_fr.argtypes = [vp, vp, vp, vp, sz, vp, c.POINTER(sz)]
     lib.bh_h_poly_fr_dev.argtypes = [vp, vp, vp, vp, u32, vp]
+    lib.bh_h_poly_fr_dev_on.argtypes = [vp, vp, vp, vp, vp, u32, vp]
     lib.bh_bases_register.argtypes = [vp, i32, vp, sz, sz, c.c_long, c.POINTER(vp)]
     lib.bh_bases_register_uncompressed.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]
     lib.bh_bases_wrap_dev.argtypes = [vp, i32, vp, sz, c.POINTER(vp)]

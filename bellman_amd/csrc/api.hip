@@ -344,6 +344,13 @@ int bh_fr_powers_dev(bh_ctx *ctx, void *out, size_t n, const void *g_host, const
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   return fr_gen_powers(ctx->c, (fr_t *)out, n, g, sc, pick_stream(ctx, stream));
 }
+int bh_h_poly_fr_dev_on(bh_ctx *ctx, void *a, void *b, void *c, void *scratch, uint32_t log_n, void *stream) {
+  // enqueue only: the caller owns `scratch` (2^log_n Fr; may be null up to 2^11) until the stream has drained
+  if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  if (!ctx || !a || !b || !c || (log_n > 11 && !scratch)) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return h_poly_dev(ctx->c, (fr_t *)a, (fr_t *)b, (fr_t *)c, (fr_t *)scratch, log_n, pick_stream(ctx, stream));
+}
 int bh_h_poly_fr_dev(bh_ctx *ctx, void *a, void *b, void *c, uint32_t log_n, void *stream) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));

@@ -201,6 +201,8 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   for (bh_msm_job **j : {&l_job, &a_in_job, &a_aux_job, &b1_in_job, &b1_aux_job, &b2_in_job, &b2_aux_job, &h_job}) jobs.track(j);
   // one multiexp over this part's slice of the scalars: `skip` advances by the number of bases the
   // skipped scalars would have consumed (all of them without a density map, the set bits with one)
+  DevBuf dscratch(ctx, log_m > 11 ? m * 32 : 32);   // FFT ping-pong vector of the h block
+  StreamDrain drain2{ps};                            // (drains before dscratch is released)
   auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
                    const uint64_t *dens_host, bh_msm_job **job, const void *scalars_host = nullptr) {
     const Slice sl = slice_of(n, part, parts);
@@ -215,35 +217,41 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
                            dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
   };
-  issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
-  // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
-  issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job, src.inputs);
-  issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
-  // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
-  issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job, src.inputs);
-  issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
-  issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job, src.inputs);
-  issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
-
-  // The seven multiexps above only need the assignments, so they are already running on their own
-  // streams while the h block below uploads a/b/c and runs its FFTs (the reference issues h first,
-  // prover.rs:221-245; the order of issue is unobservable, the order of waits is kept).
-  // h block (prover.rs:221-245): a, b, c stay in HBM; the quotient's coefficients are consumed by
-  // the H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass).
-  if (src.host) {
-    // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
-    const std::vector<Fr> *ev[3] = {&src.host->a, &src.host->b, &src.host->c};
-    void *dst[3] = {da.p, db.p, dc.p};
-    for (int i = 0; i < 3; i++) {
-      if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
-      check(bh_dev_upload_on(ctx, dst[i], ev[i]->data(), n_cons * 32, ps.st));
+  auto issue_seven = [&] {
+    issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
+    // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
+    issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job, src.inputs);
+    issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
+    // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
+    issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job, src.inputs);
+    issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
+    issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job, src.inputs);
+    issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
+  };
+  // h block (prover.rs:221-245), enqueue only: a, b, c stay in HBM; the quotient's coefficients are consumed by the
+  // H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass)
+  auto enqueue_h_block = [&] {
+    if (src.host) {
+      // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
+      const std::vector<Fr> *ev[3] = {&src.host->a, &src.host->b, &src.host->c};
+      void *dst[3] = {da.p, db.p, dc.p};
+      for (int i = 0; i < 3; i++) {
+        if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
+        check(bh_dev_upload_on(ctx, dst[i], ev[i]->data(), n_cons * 32, ps.st));
+      }
+    } else {
+      // a = A.w, b = B.w, c = C.w straight into the FFT buffers (prover.rs:19-55,105-145 on the device)
+      check(bh_r1cs_eval_dev(ctx, src.r1cs->handle, d_in.p, d_aux.p, da.p, db.p, dc.p, log_m, ps.st));
     }
-  } else {
-    // a = A.w, b = B.w, c = C.w straight into the FFT buffers (prover.rs:19-55,105-145 on the device)
-    check(bh_r1cs_eval_dev(ctx, src.r1cs->handle, d_in.p, d_aux.p, da.p, db.p, dc.p, log_m, ps.st));
-  }
-  BH_TRACE("7 multiexps issued; n_cons=%zu m=%zu a/b/c queued", n_cons, m);
-  check(bh_h_poly_fr_dev(ctx, da.p, db.p, dc.p, log_m, ps.st));   // synchronises ps.st before returning
+    check(bh_h_poly_fr_dev_on(ctx, da.p, db.p, dc.p, dscratch.p, log_m, ps.st));
+  };
+  // The seven multiexps that only need the assignments and the h block are independent: the order of issue is
+  // unobservable (the order of waits is kept, prover.rs:339-354).  Large proofs issue the multiexps first, so the
+  // GPU is busy while the host stages a/b/c; small proofs (a few launches of latency-bound kernels each) put the h
+  // block's dozen kernels at the head of the hardware queues instead of behind ~100 multiexp launches.
+  if (log_m <= 16) { enqueue_h_block(); issue_seven(); } else { issue_seven(); enqueue_h_block(); }
+  BH_TRACE("7 multiexps + h block issued; n_cons=%zu m=%zu", n_cons, m);
+  check(bh_stream_synchronize(ctx, ps.st));
   BH_TRACE("h poly done");
   const double t1 = now_ms();
   issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244

@@ -133,11 +133,30 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   if (saw_identity) atomicOr(&err->ident, 1u);
 }
 
-// Folds the partial sums of buckets that straddle chunk boundaries.  The lane whose chunk holds
-// the bucket's first entry owns the merge: tail[l] + head[l+1] + ... until the bucket ends.  Runs
-// longer than MERGE_WALK chunks (narrow top window, skewed scalars) are queued for
-// msm_merge_long_kernel so that no lane ever executes a long serial chain of point additions.
-// `walk` = chunks an owner folds serially (a few times the average run length).
+// Last chunk that holds a head partial of the run with digit d, given that the run continues from chunk `lane`
+// into chunk lane + 1: the last chunk whose FIRST entry has digit d.  Galloping + binary search over the chunk
+// starts (8-byte probes of the sorted stream): one or two probes for the usual two-chunk run.
+__device__ __forceinline__ u32 run_last_chunk(const u64 *src, u32 n, u32 z, u32 K, u32 lane, u32 d) {
+  const u32 nchunks = (u32)(((u64)(n - z) + K - 1) / K);
+  u32 lo = lane + 1, step = 1, hi;
+  for (;;) {
+    hi = lo + step;
+    if (hi >= nchunks) { hi = nchunks; break; }
+    if ((u32)(src[(u64)z + (u64)hi * K] >> 32) != d) break;
+    lo = hi;
+    step <<= 1;
+  }
+  while (hi - lo > 1) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if ((u32)(src[(u64)z + (u64)mid * K] >> 32) == d) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Folds the partial sums of buckets that straddle chunk boundaries.  The lane whose chunk holds the run's first
+// entry owns it: it finds the run's last chunk, folds tail[l0] + head[l0+1 .. l1] itself when that is at most
+// `walk` additions, and queues longer runs for msm_merge_runs_kernel so that no lane ever executes a long serial
+// chain of point additions (~20 us per link).
 template <class F>
 __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart,
                                                                XYZZ<typename F::Mem> *pts,
@@ -155,29 +174,22 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
   if (!v.tail_partial) return;
   if (v.head_partial && v.d_first == v.d_last) return;   // a middle piece of a long bucket
   const u32 d = v.d_last;
+  const u32 last = run_last_chunk(src, n, z, K, lane, d);
+  if (last - lane > walk) {
+    if (F::LANES == 1 || k3_role() == 0) {   // one entry per worker
+      const u32 slot = atomicAdd(&err->nlong, 1u);
+      if (slot < max_long) { LongRun lr = {w, lane, d, last}; long_runs[slot] = lr; }
+    }
+    return;
+  }
   const u64 slot0 = (u64)w * chunks_per_window;
   XYZZ<F> acc;
   load_xyzz<F>(acc, tail + slot0 + lane);
-  bool ended = false;
-  for (u32 j = lane + 1; j < chunks_per_window && j <= lane + walk; j++) {
-    ChunkView u;
-    if (!chunk_view(src, n, z, j, K, u) || u.d_first != d) { ended = true; break; }
+  for (u32 j = lane + 1; j <= last; j++) {
     XYZZ<F> o, r;
     load_xyzz<F>(o, head + slot0 + j);
     xyzz_add(r, acc, o);
     acc = r;
-    if (u.d_last != d || !u.tail_partial) { ended = true; break; }   // the bucket ended in chunk j
-  }
-  if (!ended && lane + walk + 1 < chunks_per_window) {
-    // still running after `walk` chunks: hand the whole run to the workgroup-parallel merge
-    ChunkView u;
-    if (chunk_view(src, n, z, lane + walk + 1, K, u) && u.d_first == d) {
-      if (F::LANES == 1 || k3_role() == 0) {   // one entry per worker
-        const u32 slot = atomicAdd(&err->nlong, 1u);
-        if (slot < max_long) { LongRun lr = {w, lane, d}; long_runs[slot] = lr; }
-      }
-      return;
-    }
   }
   store_xyzz<F>(&pts[((u64)w << (c - 1)) + d - 1], acc);
 }
@@ -201,25 +213,63 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
   }
 }
 
-// Runs that span more than a couple of chunks: tail[l0] + sum of head[l0+1 .. l1], one block per run.
-// THREADS = 64: one wavefront per run - the common medium case (the top window of the 13-bit plans, whose buckets
-// are several times fuller than the others: 8-16 chunks), no workgroup barrier on the way; runs longer than
-// BIG_RUN_CHUNKS are passed on (big_runs) to the THREADS = 512 instance - boolean-heavy witnesses put half the
-// scalars of window 0 into ONE bucket.
-constexpr u32 BIG_RUN_CHUNKS = 512;
-template <class F, u32 THREADS>
-__global__ __launch_bounds__(THREADS) void msm_merge_long_kernel(const u64 *pairs, const u32 *zstart,
-                                                                 XYZZ<typename F::Mem> *pts,
-                                                                 const XYZZ<typename F::Mem> *head,
-                                                                 const XYZZ<typename F::Mem> *tail, u32 n, u32 c,
-                                                                 u32 K, u32 chunks_per_window,
-                                                                 const LongRun *runs, u32 max_runs, LongRun *big_runs,
-                                                                 u32 max_big, ErrFlags *err) {
-  constexpr u32 PW = tree_per_wave<F>(), NWAVES = THREADS / 64, NWORK = workers_per_block<F>(THREADS, PW);
-  constexpr bool DEFER = (THREADS == 64);
+// Queued runs: tail[l0] + sum of head[l0+1 .. l1] by G workers per run (G a power of two chosen by the host,
+// PW / G runs per wavefront): every worker folds every G-th partial, then a shuffle tree.  The medium case this is
+// for: the top window of the 13-bit plans and the buckets of window-table plans, a few times fuller than a
+// chunk (8-16 chunks).  Runs longer than BIG_RUN_CHUNKS are passed on to the workgroup kernel below - boolean-
+// heavy witnesses put half the scalars of window 0 into ONE bucket.
+constexpr u32 BIG_RUN_CHUNKS = 128;
+template <class F>
+__global__ __launch_bounds__(64) void msm_merge_runs_kernel(XYZZ<typename F::Mem> *pts, const XYZZ<typename F::Mem> *head,
+                                                            const XYZZ<typename F::Mem> *tail, u32 c, u32 chunks_per_window,
+                                                            const LongRun *runs, u32 max_runs, LongRun *big_runs,
+                                                            u32 max_big, ErrFlags *err, u32 G) {
+  constexpr u32 PW = tree_per_wave<F>();
+  u32 nruns = err->nlong;
+  if (nruns > max_runs) nruns = max_runs;
+  u32 t, gid;
+  const bool live = worker_index<F>(PW, t, gid);   // one wavefront per block
+  const u32 per_wave = PW / G, r = t / G, k = t & (G - 1);
+  for (u32 base = blockIdx.x * per_wave; base < nruns; base += gridDim.x * per_wave) {
+    const u32 e = base + r;
+    bool valid = live && e < nruns;
+    LongRun lr = {0, 0, 0, 0};
+    if (valid) lr = runs[e];
+    if (valid && lr.last - lr.lane > BIG_RUN_CHUNKS) {
+      if (k == 0 && (F::LANES == 1 || k3_role() == 0)) {
+        const u32 slot = atomicAdd(&err->nbig, 1u);
+        if (slot < max_big) big_runs[slot] = lr;
+      }
+      valid = false;
+    }
+    const u64 slot0 = (u64)lr.w * chunks_per_window;
+    XYZZ<F> acc;
+    xyzz_set_identity(acc);
+    if (valid) {
+      if (k == 0) load_xyzz<F>(acc, tail + slot0 + lr.lane);
+      for (u32 j = lr.lane + 1 + k; j <= lr.last; j += G) {
+        XYZZ<F> o, s2;
+        load_xyzz<F>(o, head + slot0 + j);
+        xyzz_add(s2, acc, o);
+        acc = s2;
+      }
+    }
+    group_reduce_points<F>(acc, G, k);
+    if (valid && k == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
+  }
+}
+
+// One 512-thread workgroup per very long run.
+constexpr u32 LONG_THREADS = 512;
+template <class F>
+__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typename F::Mem> *pts,
+                                                                      const XYZZ<typename F::Mem> *head,
+                                                                      const XYZZ<typename F::Mem> *tail, u32 c,
+                                                                      u32 chunks_per_window, const LongRun *runs,
+                                                                      u32 max_runs, const ErrFlags *err) {
+  constexpr u32 PW = tree_per_wave<F>(), NWAVES = LONG_THREADS / 64, NWORK = workers_per_block<F>(LONG_THREADS, PW);
   __shared__ XYZZ<F> wave_part[NWAVES][F::LANES];
-  __shared__ u32 s_last;
-  u32 nruns = DEFER ? err->nlong : err->nbig;
+  u32 nruns = err->nbig;
   if (nruns > max_runs) nruns = max_runs;
   u32 wid, gid;
   const bool live = worker_index<F>(PW, wid, gid);   // idle lanes stay for the barriers
@@ -227,49 +277,27 @@ __global__ __launch_bounds__(THREADS) void msm_merge_long_kernel(const u64 *pair
   const u32 role = F::LANES == 1 ? 0u : k3_role();
   for (u32 e = blockIdx.x; e < nruns; e += gridDim.x) {
     const LongRun lr = runs[e];
-    const u64 *src = pairs + (u64)lr.w * n;
-    const u32 z = zstart[lr.w];
-    if (threadIdx.x == 0) {   // last sorted position holding digit d -> last chunk of the run
-      u32 lo = z + lr.lane * K, hi = n;   // first index with digit > d
-      while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        if ((u32)(src[mid] >> 32) <= lr.d) lo = mid + 1; else hi = mid;
-      }
-      u32 last = (lo - 1 - z) / K;
-      if (DEFER && last - lr.lane > BIG_RUN_CHUNKS) {
-        const u32 slot = atomicAdd(&err->nbig, 1u);
-        if (slot < max_big) big_runs[slot] = lr;
-        last = 0xffffffffu;   // passed on
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    const u32 l1 = s_last;
-    __syncthreads();          // s_last is rewritten by the next iteration
-    if (l1 == 0xffffffffu) continue;
     const u64 slot0 = (u64)lr.w * chunks_per_window;
     XYZZ<F> acc;
     xyzz_set_identity(acc);
     if (live) {
       if (wid == 0) load_xyzz<F>(acc, tail + slot0 + lr.lane);
-      for (u32 j = lr.lane + 1 + wid; j <= l1; j += NWORK) {
+      for (u32 j = lr.lane + 1 + wid; j <= lr.last; j += NWORK) {
         XYZZ<F> o, r;
         load_xyzz<F>(o, head + slot0 + j);
         xyzz_add(r, acc, o);
         acc = r;
       }
       group_reduce_points<F>(acc, PW, t_in_wave);
-      if (NWAVES > 1 && t_in_wave == 0) wave_part[wave][role] = acc;
+      if (t_in_wave == 0) wave_part[wave][role] = acc;
     }
-    if (NWAVES > 1) {
-      __syncthreads();
-      if (wave == 0 && live) {
-        if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
-        group_reduce_points<F>(acc, NWAVES, t_in_wave);
-      }
+    __syncthreads();
+    if (wave == 0 && live) {
+      if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
+      group_reduce_points<F>(acc, NWAVES, t_in_wave);
+      if (t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
     }
-    if (wave == 0 && live && t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
-    if (NWAVES > 1) __syncthreads();
+    __syncthreads();
   }
 }
 
@@ -473,10 +501,10 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 npairs = (u64)p.Wd * n;
   const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nslots = (u64)p.W * p.chunks_per_window;
-  // the owner lane of a run folds at most `walk` following chunks itself; longer runs are queued for the
-  // wavefront-parallel merge (a chain of point additions costs ~20 us per link: 8-chunk runs, walked serially,
-  // were 0.24 ms of every 2^14-term multiexp), the longest of those for the workgroup-parallel one
-  const u32 walk = 2;
+  // the owner lane of a run folds at most `walk` following chunks itself; longer runs are queued for
+  // msm_merge_runs_kernel (G workers per run), the longest of those for the workgroup kernel
+  const u32 walk = 4;
+  const u32 run_lanes = 8;   // G: 8-16 chunk runs become 1-2 serial additions + 3 tree levels
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
   const u32 max_big = (u32)(nslots / (BIG_RUN_CHUNKS + 1) + 1);
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
@@ -540,11 +568,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
                        p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((msm_merge_long_kernel<F, 64>), dim3((u32)c.num_cus * 8), dim3(64), 0, st, sorted, b.zstart, pts,
-                       head, tail, p.n, p.c, p.chunk, p.chunks_per_window, long_runs, max_long, big_runs, max_big, err);
+    hipLaunchKernelGGL(msm_merge_runs_kernel<F>, dim3((u32)c.num_cus * 4), dim3(64), 0, st, pts, head, tail, p.c,
+                       p.chunks_per_window, long_runs, max_long, big_runs, max_big, err, run_lanes);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((msm_merge_long_kernel<F, 512>), dim3(256), dim3(512), 0, st, sorted, b.zstart, pts, head, tail,
-                       p.n, p.c, p.chunk, p.chunks_per_window, big_runs, max_big, (LongRun *)nullptr, 0u, err);
+    hipLaunchKernelGGL(msm_merge_long_kernel<F>, dim3(256), dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
+                       p.chunks_per_window, big_runs, max_big, err);
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.

@@ -264,7 +264,8 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // only window sizes whose top window is not a sliver (260 = 20 x 13, 256 = 16 x 16): a sliver puts the top digit of
   // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/r2_call2_sizes_and_table_sweeps.txt:
   // c = 12 and 14 are 1.5-2x slower than 13 at 2^10-2^14)
-  return ilog2(n_bases ? n_bases : 1) <= 11 ? 13 : 16;
+  const u32 lg = ilog2(n_bases ? n_bases : 1);
+  return lg <= 11 ? 13 : lg <= 17 ? 16 : 20;   // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
@@ -280,15 +281,13 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   p.lo_bits = (p.c - 1) / 2;
   p.hi_bits = (p.c - 1) - p.lo_bits;
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
-  // K: a quarter of the average bucket (so a bucket spans a handful of chunks, folded by its owner lane
-  // in the merge), at least the classic value, but never so large that the chip runs out of lanes
+  // K: at least the average bucket, so that a typical run touches two chunks (one partial to fold) - shorter chunks
+  // turn EVERY bucket into a multi-chunk run and the merge into the dominant cost (profiles/r2_call3_*)
   const u32 lg = ilog2(p.n ? p.n : 1);
-  // few entries: short chunks, the job is a chain of latency-bound steps and the chip is mostly idle
   const u32 base_k = lg <= 20 ? 8 : lg <= 22 ? 16 : g2 ? 64 : 32;
   const u64 avg = (u64)p.n >> (p.c - 1);
-  const u64 lanes_wanted = (u64)num_cus * 4 * 64 * 2;   // two wavefronts per SIMD
-  u64 k = std::max<u64>(base_k, avg / 4);
-  k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_wanted));
+  (void)num_cus;
+  const u64 k = std::max<u64>(base_k, avg);
   p.chunk = forced_chunk ? forced_chunk : (u32)k;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;

@@ -24,8 +24,9 @@ struct SumDesc {
   u32 istride;     // STRIDED: element offset between consecutive inner indices
   u32 lanes;       // G: lanes cooperating on one output (power of two <= 64)
 };
-struct LongRun {   // a bucket whose entries span more than MERGE_WALK chunks
-  u32 w, lane, d;
+struct LongRun {   // a bucket run that spans more chunks than its owner lane folds itself
+  u32 w, lane, d;  // window, first chunk (holds the run's tail partial), digit
+  u32 last;        // last chunk with a head partial of the run
 };
 
 // per-job plan overrides (bh_msm_opts): zero = tuned default

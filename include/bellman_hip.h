@@ -103,6 +103,10 @@ int bh_h_poly_fr(bh_ctx *ctx, const void *a_host, const void *b_host, const void
                  size_t n_evals, void *h_out_host, size_t *h_len);
 /* device-resident variant: a,b,c are 2^log_n-element device vectors (clobbered); result in a */
 int bh_h_poly_fr_dev(bh_ctx *ctx, void *a_dev, void *b_dev, void *c_dev, uint32_t log_n, void *stream);
+/* the same, enqueue only (no synchronisation): `scratch_dev` = 2^log_n Fr of caller-owned workspace (may be NULL
+ * up to 2^11), which like a, b, c must stay valid until `stream` has drained */
+int bh_h_poly_fr_dev_on(bh_ctx *ctx, void *a_dev, void *b_dev, void *c_dev, void *scratch_dev, uint32_t log_n,
+                        void *stream);
 
 /* ---- bases: the `(Arc<Vec<G::Affine>>, usize)` SourceBuilder (src/multiexp.rs:45-86) --
  * Uploads `n` affine points once (the CRS is immutable and shared by every proof,

@@ -93,6 +93,7 @@ extern "C" {
     pub fn bh_fr_distribute_powers_dev(ctx: *mut BhCtx, a_dev: *mut c_void, n: usize, g_host: *const c_void, stream: *mut c_void) -> c_int;
     pub fn bh_h_poly_fr(ctx: *mut BhCtx, a_host: *const c_void, b_host: *const c_void, c_host: *const c_void, n_evals: usize, h_out_host: *mut c_void, h_len: *mut usize) -> c_int;
     pub fn bh_h_poly_fr_dev(ctx: *mut BhCtx, a_dev: *mut c_void, b_dev: *mut c_void, c_dev: *mut c_void, log_n: u32, stream: *mut c_void) -> c_int;
+    pub fn bh_h_poly_fr_dev_on(ctx: *mut BhCtx, a_dev: *mut c_void, b_dev: *mut c_void, c_dev: *mut c_void, scratch_dev: *mut c_void, log_n: u32, stream: *mut c_void) -> c_int;
     pub fn bh_bases_register(ctx: *mut BhCtx, group: c_int, host_points: *const c_void, n: usize, stride: usize, inf_offset: c_long, out: *mut *mut BhBases) -> c_int;
     pub fn bh_bases_register_uncompressed(ctx: *mut BhCtx, group: c_int, host_bytes: *const c_void, n: usize, out: *mut *mut BhBases) -> c_int;
     pub fn bh_bases_read_uncompressed(ctx: *mut BhCtx, group: c_int, host_bytes: *const c_void, n: usize, flags: c_uint, out: *mut *mut BhBases, bad_index: *mut usize) -> c_int;
