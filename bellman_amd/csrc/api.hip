@@ -150,17 +150,19 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
   }
   return BH_OK;
 }
-// Base vectors of up to 2^BELLMAN_HIP_TABLE_MAX_LOG2 points (default 16; 0 = never) get their window table at
-// registration: a multiexp over a few thousand terms is a chain of latency-bound steps, and with the table the
-// chain loses the 255-step doubling ladder over the windows (the CRS is registered once per circuit).
-static unsigned auto_table_max_log2() {
-  static const unsigned v = [] {
+// Base vectors of up to 2^16 (G1) / 2^15 (G2) points get their window table at registration
+// (BELLMAN_HIP_TABLE_MAX_LOG2 overrides both limits; 0 = never): a multiexp over a few thousand terms is a chain of
+// latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the windows and all but
+// one of its bucket reductions (the CRS is registered once per circuit).  Above those sizes the single bucket set's
+// deeper reduction tree and the table's cache footprint cost what the table saves (profiles/r2_call4_*).
+static unsigned auto_table_max_log2(int group) {
+  static const int v = [] {
     const char *e = getenv("BELLMAN_HIP_TABLE_MAX_LOG2");
-    if (!e || !*e) return 16u;
+    if (!e || !*e) return -1;
     const long x = strtol(e, nullptr, 10);
-    return (unsigned)(x < 0 ? 0 : x > 24 ? 24 : x);
+    return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();
-  return v;
+  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 16u : 15u);
 }
 static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
   bh_bases *b = new bh_bases{group, dev, n, owned};
@@ -170,7 +172,7 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
     delete b;
     return rc;
   }
-  const unsigned lg = auto_table_max_log2();
+  const unsigned lg = auto_table_max_log2(group);
   if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) (void)bh_bases_precompute(ctx, b, 0);   // best effort
   *out = b;
   return BH_OK;

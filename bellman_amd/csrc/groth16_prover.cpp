@@ -212,10 +212,12 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
       // answers them on the host instead of running a kernel pipeline per term
       check(bh_msm_async(ctx, bases, base_skip, (const char *)scalars_host + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
                          dens_host ? dens_host + sl.lo / 64 : nullptr, dens_host ? sl.hi - sl.lo : 0, job));
+      BH_TRACE("  multiexp of %zu terms answered on the host", sl.hi - sl.lo);
       return;
     }
     check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
                            dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
+    BH_TRACE("  multiexp of %zu terms issued", sl.hi - sl.lo);
   };
   auto issue_seven = [&] {
     issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
@@ -249,7 +251,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // unobservable (the order of waits is kept, prover.rs:339-354).  Large proofs issue the multiexps first, so the
   // GPU is busy while the host stages a/b/c; small proofs (a few launches of latency-bound kernels each) put the h
   // block's dozen kernels at the head of the hardware queues instead of behind ~100 multiexp launches.
-  if (log_m <= 16) { enqueue_h_block(); issue_seven(); } else { issue_seven(); enqueue_h_block(); }
+  if (log_m <= 16) { enqueue_h_block(); BH_TRACE("h block enqueued"); issue_seven(); } else { issue_seven(); enqueue_h_block(); }
   BH_TRACE("7 multiexps + h block issued; n_cons=%zu m=%zu", n_cons, m);
   check(bh_stream_synchronize(ctx, ps.st));
   BH_TRACE("h poly done");

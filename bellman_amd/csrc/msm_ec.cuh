@@ -511,8 +511,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 nwords = (n + 63) / 64;
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~size_t(255); return at; };
-  // zero-initialised region first: status words, then the buckets (all-zero XYZZ == identity)
-  const size_t o_err = carve(sizeof(ErrFlags));
+  // zero-initialised region first: status words, the result slots (so that both leave in ONE copy), then the buckets
+  // (all-zero XYZZ == identity)
+  const size_t bits_bytes = (size_t)p.W * p.c * sizeof(Pt);   // per window: (c-1) bit sums U[w][p], then W plain totals T[w]
+  const size_t o_err = carve(sizeof(ErrFlags));                // 256-byte slot
+  const size_t o_bits = carve(bits_bytes);
   const size_t o_pts = carve((u64)p.NB * sizeof(Pt));
   const size_t zero_bytes = off;
   const size_t o_pairs_a = carve(npairs * 8), o_pairs_b = carve(npairs * 8);
@@ -520,8 +523,6 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_head = carve(nslots * sizeof(Pt)), o_tail = carve(nslots * sizeof(Pt));
   const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(LongRun));
   const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
-  // per window: (c-1) bit sums U[w][p] followed by W plain totals T[w]
-  const size_t o_bits = carve((u64)p.W * p.c * sizeof(Pt));
   const size_t o_prefix = density_dev ? carve((nwords + 1) * 4) : 0;
   char *ws = (char *)c.pool.acquire(off);
   if (!ws) return BH_ERR_HIP;
@@ -539,14 +540,15 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   job.scalars_dev = scalars_dev; job.density_dev = density_dev; job.word_prefix = b.word_prefix;
   job.bases_dev = bases_dev; job.skip = skip; job.n_bases = n_bases; job.fmt = fmt;
 
-  BH_HIP_CHECK(hipEventRecord(job.ev_begin, st));
+  job.timed = (opts.flags & BH_MSM_STAGE_TIMES) != 0;
+  if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_begin, st));
   BH_HIP_CHECK(hipMemsetAsync(ws, 0, zero_bytes, st));
   const u64 *sorted = nullptr;
   {
     int rc = msm_run_stages(p, b, scalars_dev, fmt, density_dev, skip, n_bases, st, &sorted);
     if (rc) return rc;
   }
-  BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
+  if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
   // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
   {
     const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
@@ -564,7 +566,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                          tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
     }
     BH_HIP_CHECK(hipGetLastError());
-    BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
+    if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
     hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
                        p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
     BH_HIP_CHECK(hipGetLastError());
@@ -647,13 +649,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
   }
-  BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
-  // results to pinned host memory
-  const size_t bits_bytes = (size_t)p.W * p.c * sizeof(Pt);
-  job.host_result_bytes = bits_bytes + sizeof(ErrFlags);
+  if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
+  // status words + results to pinned host memory, one copy: [ErrFlags slot (256 B)][bit sums]
+  job.host_result_bytes = (o_bits - o_err) + bits_bytes;
   if (job.host_result_bytes > job.res.pinned_bytes) return BH_ERR_INVALID_ARG;
-  BH_HIP_CHECK(hipMemcpyAsync(job.host_result, bits, bits_bytes, hipMemcpyDeviceToHost, st));
-  BH_HIP_CHECK(hipMemcpyAsync((char *)job.host_result + bits_bytes, err, sizeof(ErrFlags), hipMemcpyDeviceToHost, st));
+  BH_HIP_CHECK(hipMemcpyAsync(job.host_result, ws + o_err, job.host_result_bytes, hipMemcpyDeviceToHost, st));
   return BH_OK;
 }
 
@@ -709,14 +709,17 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   if (hipStreamSynchronize(job.stream) != hipSuccess) rc = BH_ERR_HIP;
   if (rc == BH_OK) {
     const MsmPlan &p = job.plan;
-    const size_t bits_bytes = (size_t)p.W * p.c * sizeof(XYZZ<F>);
+    constexpr size_t ERR_SLOT = 256;   // the carve granularity of msm_enqueue
     ErrFlags ef;
-    memcpy(&ef, (char *)job.host_result + bits_bytes, sizeof ef);
+    memcpy(&ef, job.host_result, sizeof ef);
     if (ms) {  // [0] whole device pipeline, [1] digits+sort, [2] bucket accumulation, [3] reductions
-      (void)hipEventElapsedTime(&ms[0], job.ev_begin, job.ev_end);
-      (void)hipEventElapsedTime(&ms[1], job.ev_begin, job.ev_sorted);
-      (void)hipEventElapsedTime(&ms[2], job.ev_sorted, job.ev_accum);
-      (void)hipEventElapsedTime(&ms[3], job.ev_accum, job.ev_end);
+      ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+      if (job.timed) {
+        (void)hipEventElapsedTime(&ms[0], job.ev_begin, job.ev_end);
+        (void)hipEventElapsedTime(&ms[1], job.ev_begin, job.ev_sorted);
+        (void)hipEventElapsedTime(&ms[2], job.ev_sorted, job.ev_accum);
+        (void)hipEventElapsedTime(&ms[3], job.ev_accum, job.ev_end);
+      }
     }
     if (ef.eof && ef.ident) {
       // both kinds of failure exist: the reference reports the top window's first failure
@@ -735,7 +738,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     } else if (ef.ident) {
       rc = BH_ERR_UNEXPECTED_IDENTITY;
     } else {
-      msm_host_tail<F>(p, (const XYZZ<F> *)job.host_result, out_affine);
+      msm_host_tail<F>(p, (const XYZZ<F> *)((const char *)job.host_result + ERR_SLOT), out_affine);
     }
   }
   for (void *ptr : job.dev_allocs) c.pool.release(ptr);

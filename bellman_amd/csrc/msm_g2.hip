@@ -1,10 +1,10 @@
 // G2 (Fp2) instantiation of the MSM pipeline.  Two kernel bundles: the lane-triple K3 form (fp2k3.cuh) - a G2
-// addition with the latency and the register footprint of a G1 addition, 2x faster on the latency-bound jobs of up
-// to 2^15 terms - and one lane per point, which executes ~20 % fewer instructions per addition and wins once the
-// accumulation is throughput-bound (profiles/r2_call2_sizes_and_table_sweeps.txt: 2^19 accumulate 5.5 vs 6.6 ms).
+// addition with the latency and the register footprint of a G1 addition, up to 2x faster on the latency-bound jobs
+// of up to 2^17 terms - and one lane per point, which executes ~20 % fewer instructions per addition and wins once
+// the accumulation is throughput-bound (profiles/r2_call4_*: 2^17 3.5 vs 3.8 ms, 2^18 5.4 = 5.4, 2^19 9.3 vs 8.0).
 #include "msm_ec.cuh"
 namespace bh {
-BH_INSTANTIATE_MSM(g2, Fp2Ops, Fp2K3Ops, Fp2Ops, BH_MSM_G2_LANE_TRIPLES, BH_MSM_G2_SINGLE_LANE, (u64)1 << 15)
+BH_INSTANTIATE_MSM(g2, Fp2Ops, Fp2K3Ops, Fp2Ops, BH_MSM_G2_LANE_TRIPLES, BH_MSM_G2_SINGLE_LANE, ((u64)1 << 18) - 1)
 }
 
 // ---- test hook: the K3 group law on its own (tests/test_gpu_parity.py::test_g2_k3_group_law) -----------------

@@ -229,11 +229,12 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   const u32 lg = ilog2(n ? n : 1);
   // re-swept after the field-arithmetic changes (profiles/r1_tune_small_sizes.txt, second table): the
   // cheaper additions moved every boundary down by 2-3 powers of two
-  // G2 keeps c = 13 up to 2^18: its bucket reduction is two G2 additions per bucket and throughput-bound, 16 windows
-  // of 2^15 buckets cost 2.1 ms whatever n is - more than the 25 % extra accumulation of 20 windows below 2^19
-  // (profiles/r2_call2_*).  From 2^25 terms on the accumulation saved by 13 windows of 20 bits outweighs the
-  // 6.8 M-bucket reduction (2^24: 50 -> 40 ms accumulate for +9 ms of reduction and a third sort pass).
-  int c = g2 ? (lg <= 12 ? 8 : lg <= 18 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 24 ? 16 : 20);
+  // G2 keeps c = 13 up to 2^17: its bucket reduction is two G2 additions per bucket and throughput-bound, 16 windows
+  // of 2^15 buckets cost ~2 ms whatever n is - more than the 25 % extra accumulation of 20 windows below 2^18
+  // (profiles/r2_call4_*: 2^16 2.4 vs 3.0 ms, 2^17 3.5 vs 3.8, 2^18 5.4 = 5.4).  From 2^25 terms on the accumulation
+  // saved by 13 windows of 20 bits outweighs the 6.8 M-bucket reduction (2^24: 50 -> 40 ms accumulate for +9 ms of
+  // reduction and a third sort pass).
+  int c = g2 ? (lg <= 12 ? 8 : lg <= 17 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 24 ? 16 : 20);
   if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
@@ -247,7 +248,9 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
   // K entries per lane: 32 once the chip is full, fewer for small problems so that the serial chain
   // per lane shrinks instead of leaving SIMDs idle (same sweep)
-  p.chunk = forced_chunk ? forced_chunk : (lg <= 11 ? 8 : lg <= 17 ? 16 : g2 ? 64 : 32);   // G2: fewer, costlier partials
+  p.chunk = forced_chunk ? forced_chunk
+                         : g2 ? (lg <= 11 ? 8 : lg <= 15 ? 16 : lg <= 17 ? 32 : 64)   // G2: fewer, costlier partials
+                              : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
   // never let a typical bucket span many chunks: the chunk merge is serial per bucket
   if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, n >> (p.c - 1));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;

@@ -64,6 +64,7 @@ struct MsmJobImpl {
   void *host_result = nullptr;        // pinned (owned by `res`): W*c XYZZ + ErrFlags
   size_t host_result_bytes = 0;
   JobResources res;
+  bool timed = false;                 // stage events recorded (BH_MSM_STAGE_TIMES)
   int early_rc = BH_OK;               // immediate result (n == 0 etc.)
   bool trivial = false;
   // a job answered on the host at issue time (a handful of terms, api.hip): the affine record to hand out

@@ -170,7 +170,7 @@ class MsmOpts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_uint32), ("chunk", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
 
 
-ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH = 1, 2, 4, 8
+ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES = 1, 2, 4, 8, 16, 32, 64
 
 
 def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,
@@ -189,7 +189,7 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
         words = density_map.words()
     job = ctypes.c_void_p()
     fmt = 1 if mont else 0
-    opts = MsmOpts(window_bits, chunk, flags)
+    opts = MsmOpts(window_bits, chunk, flags | (STAGE_TIMES if timed else 0))
     po = ctypes.cast(ctypes.pointer(opts), ctypes.c_void_p)
     if scalars_dev is None:
         sc = np.ascontiguousarray(exponents, dtype=np.uint64).reshape(-1, 4)

@@ -170,11 +170,11 @@ int bh_msm_async_dev(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void
                      size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
                      size_t density_len, bh_msm_job **job);
 int bh_msm_wait(bh_msm_job *job, void *out_affine);
-/* device time of the job's kernels in milliseconds (hipEvents on the job's stream); valid
- * after bh_msm_wait's return value has been observed via bh_msm_wait_timed */
+/* device time of the job's kernels in milliseconds (hipEvents on the job's stream; needs BH_MSM_STAGE_TIMES) */
 int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms);
 /* as above with per-stage device times (hipEvents on the job's stream), milliseconds:
- * [0] whole pipeline  [1] digits + radix sort + task list  [2] bucket accumulation  [3] reductions */
+ * [0] whole pipeline  [1] digits + radix sort + task list  [2] bucket accumulation  [3] reductions;
+ * zeros unless the job was issued with BH_MSM_STAGE_TIMES in bh_msm_opts.flags */
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4);
 /* r[i] = a[i] + b[i] for affine records on the HOST - used to fold the per-GPU partial results of
  * a base-sharded MSM after the all-gather, and g_a/g_b/g_c in create_proof. */
@@ -194,8 +194,9 @@ typedef struct {
 #define BH_MSM_ACC_LDS 2u       /* ... in LDS */
 #define BH_MSM_NO_TABLE 4u      /* ignore a window table attached to the bases */
 #define BH_MSM_NO_SMALL_PATH 8u /* run the full pipeline even for a handful of terms */
-#define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default above 2^15 terms) */
-#define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default up to 2^15 terms) */
+#define BH_MSM_STAGE_TIMES 64u  /* record the per-stage HIP events bh_msm_wait_profile reports (4 extra API calls) */
+#define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default from 2^18 terms) */
+#define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^18 terms) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
                       size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
                       size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
