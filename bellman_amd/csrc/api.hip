@@ -150,7 +150,7 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
   }
   return BH_OK;
 }
-// Base vectors of up to 2^16 (G1) / 2^15 (G2) points get their window table at registration
+// Base vectors of up to 2^16 (G1) / 2^22 (G2) points get their window table at registration
 // (BELLMAN_HIP_TABLE_MAX_LOG2 overrides both limits; 0 = never): a multiexp over a few thousand terms is a chain of
 // latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the windows and all but
 // one of its bucket reductions (the CRS is registered once per circuit).  Above those sizes the single bucket set's
@@ -162,7 +162,7 @@ static unsigned auto_table_max_log2(int group) {
     const long x = strtol(e, nullptr, 10);
     return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();
-  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 16u : 15u);
+  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 16u : 22u);
 }
 static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
   bh_bases *b = new bh_bases{group, dev, n, owned};
@@ -224,6 +224,8 @@ void bh_ctx_destroy(bh_ctx *ctx) {
     if (r.stream) (void)hipStreamDestroy(r.stream);
   }
   ctx->c.job_pool.clear();
+  for (hipStream_t st : ctx->c.stream_pool) (void)hipStreamDestroy(st);
+  ctx->c.stream_pool.clear();
   if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }
@@ -262,15 +264,27 @@ int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes) {
   return BH_OK;
 }
 int bh_stream_create(bh_ctx *ctx, void **stream) {
+  // recycled through the context: hipStreamCreate / Destroy cost about a millisecond together, which was a third of
+  // a MiMC-sized proof (one stream per proof, groth16_prover.cpp)
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  {
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    if (!ctx->c.stream_pool.empty()) {
+      *stream = (void *)ctx->c.stream_pool.back();
+      ctx->c.stream_pool.pop_back();
+      return BH_OK;
+    }
+  }
   hipStream_t st = nullptr;
   BH_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   *stream = (void *)st;
   return BH_OK;
 }
 int bh_stream_destroy(bh_ctx *ctx, void *stream) {
-  (void)ctx;
-  if (stream) BH_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  // the caller has synchronised the stream; it goes back to the pool (destroyed with the context)
+  if (!stream) return BH_OK;
+  std::lock_guard<std::mutex> g(ctx->c.job_mu);
+  ctx->c.stream_pool.push_back((hipStream_t)stream);
   return BH_OK;
 }
 int bh_stream_synchronize(bh_ctx *ctx, void *stream) {

@@ -106,6 +106,7 @@ struct Context {
   int num_cus = 256;
   std::mutex job_mu;
   std::vector<JobResources> job_pool;
+  std::vector<hipStream_t> stream_pool;   // bh_stream_create / destroy recycle streams (creation costs ~1 ms)
 };
 
 }  // namespace bh

@@ -475,12 +475,15 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // ============================================================================================
 // host orchestration
 // ============================================================================================
-// F = the ops bundle the kernels compute with (FpOps for G1; Fp2K3Ops, or single-lane Fp2Ops, for G2);
-// records in memory are Affine / XYZZ over F::Mem.
-template <class F>
+// F = the ops bundle the accumulation computes with (FpOps for G1; Fp2K3Ops, or single-lane Fp2Ops, for G2), FR the
+// bundle of the merge and reduction kernels; records in memory are Affine / XYZZ over F::Mem == FR::Mem, so the two
+// can differ: a big G2 job accumulates one lane per point (throughput) and reduces a window table's 2^15 buckets in
+// lane triples (latency).
+template <class F, class FR>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
                        u64 n, int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
   typedef typename F::Mem M;
+  static_assert(sizeof(typename FR::Mem::T) == sizeof(typename M::T), "both bundles work on the same records");
   typedef XYZZ<M> Pt;
   constexpr bool G2 = (M::WORDS == 24);
   Context &c = *job.ctx;
@@ -567,20 +570,22 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     }
     BH_HIP_CHECK(hipGetLastError());
     if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
-    hipLaunchKernelGGL(msm_merge_chunks_kernel<F>, grid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
+    const u32 rwpb = workers_per_block<FR>(128, default_per_wave<FR>());
+    const dim3 rgrid((p.chunks_per_window + rwpb - 1) / rwpb, p.W);
+    hipLaunchKernelGGL(msm_merge_chunks_kernel<FR>, rgrid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
                        p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_merge_runs_kernel<F>, dim3((u32)c.num_cus * 4), dim3(64), 0, st, pts, head, tail, p.c,
+    hipLaunchKernelGGL(msm_merge_runs_kernel<FR>, dim3((u32)c.num_cus * 4), dim3(64), 0, st, pts, head, tail, p.c,
                        p.chunks_per_window, long_runs, max_long, big_runs, max_big, err, run_lanes);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_merge_long_kernel<F>, dim3(256), dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
+    hipLaunchKernelGGL(msm_merge_long_kernel<FR>, dim3(256), dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
                        p.chunks_per_window, big_runs, max_big, err);
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
   // G workers per output chosen so that each launch is about one wavefront per SIMD.
   Pt *rows = rowcol, *cols = rowcol + (u64)p.W * H;
-  constexpr u32 PW = tree_per_wave<F>();   // workers per one-wavefront block of the sum kernel
+  constexpr u32 PW = tree_per_wave<FR>();   // workers per one-wavefront block of the sum kernel
   // workers per output: minimise (serial adds per worker + tree depth) x (waves per SIMD, at least 1);
   // these kernels are latency-bound chains of point additions, not throughput-bound.
   auto pick_lanes = [&](u32 groups, u32 count) {
@@ -598,7 +603,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   };
   auto blocks_for = [&](u32 groups, u32 lanes) { return (u32)(((u64)groups * lanes + PW - 1) / PW); };
   auto make_job = [&](const Pt *in, Pt *out, SumDesc d) {
-    SumJob<F> j;
+    SumJob<FR> j;
     d.lanes = d.groups ? pick_lanes(d.groups, d.mode == SUM_BITS ? std::max(1u, d.count / 2) : d.count) : 1;
     j.in = in; j.out = out; j.d = d;
     j.nblocks = blocks_for(d.groups, d.lanes);
@@ -609,9 +614,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     SumDesc dr, dc;
     dr.mode = SUM_STRIDED; dr.groups = p.W * H; dr.count = Lw; dr.inner = H; dr.stride = 1; dr.istride = Lw; dr.group_shift = cb;
     dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
-    SumJobs<F> js;
+    SumJobs<FR> js;
     js.j[0] = make_job(pts, rows, dr); js.j[1] = make_job(pts, cols, dc); js.j[2] = js.j[1]; js.j[2].nblocks = 0;
-    if (G2 && F::LANES == 1) {
+    if (G2 && FR::LANES == 1) {
       // single-lane G2 (one resident wavefront per SIMD, so sharing a SIMD doubles every step): the two jobs share
       // one launch, choose their lane counts jointly - the launch lasts as long as its longest chain, stretched by
       // how many wavefronts each SIMD has to interleave.  (With two wavefronts per SIMD - G1, K3-form G2 - they
@@ -629,7 +634,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       js.j[0].d.lanes = best_r; js.j[0].nblocks = blocks_for(dr.groups, best_r);
       js.j[1].d.lanes = best_c; js.j[1].nblocks = blocks_for(dc.groups, best_c);
     }
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
+    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
     // sum_idx (idx+1) B[idx] = sum_p 2^p U[p] + T, idx = hi*2^l + lo:
     //   U[w][p], p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi),
@@ -646,7 +651,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     js.j[0] = make_job(cols, bits, bl);
     js.j[1] = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
     js.j[2] = make_job(t_from_cols ? cols : rows, bits + (u64)p.W * cb, bt);
-    hipLaunchKernelGGL(msm_sum_kernel<F>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
+    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
   }
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
@@ -859,17 +864,26 @@ template <class F> static void devhdr_point_add_t(void *r, const void *a, const 
 }
 template <class F> static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) { generic_point_mul<F>(r, a, k); }
 
-// OPS = the record format in memory (FpOps / Fp2Ops); KOPS / ALT = the two kernel bundles of the group: ALT runs
-// jobs of more than ALT_ABOVE terms; bh_msm_opts.flags KOPS_FLAG / ALT_FLAG force one of them
-#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, KOPS_FLAG, ALT_FLAG, ALT_ABOVE)                            \
+// OPS = the record format in memory (FpOps / Fp2Ops); KOPS / ALT = the two kernel bundles of the group.  The
+// accumulation runs ALT on jobs of more than ALT_ABOVE terms; merge + reduction run ALT when the plan has more than
+// ALT_RED_ABOVE buckets (throughput-bound); bh_msm_opts.flags KOPS_FLAG / ALT_FLAG force one bundle for both.
+#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, KOPS_FLAG, ALT_FLAG, ALT_ABOVE, ALT_RED_ABOVE)             \
   int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
                            const void *scalars_dev, u64 n, int fmt, const u64 *density_dev,                 \
                            const MsmOpts &opts, const WindowTable *table) {                                  \
-    /* the alternative bundle above ALT_ABOVE terms, or whenever a flag forces one of the two */             \
-    const bool alt = (opts.flags & (ALT_FLAG)) ? true : (opts.flags & (KOPS_FLAG)) ? false : n > (ALT_ABOVE);      \
-    if (alt)                                                                                                  \
-      return msm_enqueue<ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table); \
-    return msm_enqueue<KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
+    const bool force_alt = (opts.flags & (ALT_FLAG)) != 0, force_k = !force_alt && (opts.flags & (KOPS_FLAG)) != 0; \
+    const bool with_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c);  \
+    const MsmPlan pl = with_table ? make_table_plan(n, *table, opts.chunk, OPS::WORDS == 24, 256)             \
+                                  : make_plan(n, opts.c, opts.chunk, OPS::WORDS == 24);                       \
+    const bool acc_alt = force_alt ? true : force_k ? false : n > (ALT_ABOVE);                                \
+    const bool red_alt = force_alt ? true : force_k ? false : (u64)pl.NB > (ALT_RED_ABOVE);                   \
+    if (acc_alt && red_alt)                                                                                   \
+      return msm_enqueue<ALT, ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
+    if (acc_alt)                                                                                              \
+      return msm_enqueue<ALT, KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);  \
+    if (red_alt)                                                                                              \
+      return msm_enqueue<KOPS, ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);  \
+    return msm_enqueue<KOPS, KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
   }                                                                                                           \
   int window_table_##SUFFIX(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {                           \
     return window_table_t<OPS>(table_dev, n, c, W, st);                                                       \

@@ -2,9 +2,11 @@
 // addition with the latency and the register footprint of a G1 addition, up to 2x faster on the latency-bound jobs
 // of up to 2^17 terms - and one lane per point, which executes ~20 % fewer instructions per addition and wins once
 // the accumulation is throughput-bound (profiles/r2_call4_*: 2^17 3.5 vs 3.8 ms, 2^18 5.4 = 5.4, 2^19 9.3 vs 8.0).
+// The merge + reduction kernels choose separately, by bucket count: the 2^15 buckets of a window-table plan are
+// reduced in lane triples whatever the job size, the 2^19 of a classic 16-window plan one lane per point.
 #include "msm_ec.cuh"
 namespace bh {
-BH_INSTANTIATE_MSM(g2, Fp2Ops, Fp2K3Ops, Fp2Ops, BH_MSM_G2_LANE_TRIPLES, BH_MSM_G2_SINGLE_LANE, ((u64)1 << 18) - 1)
+BH_INSTANTIATE_MSM(g2, Fp2Ops, Fp2K3Ops, Fp2Ops, BH_MSM_G2_LANE_TRIPLES, BH_MSM_G2_SINGLE_LANE, ((u64)1 << 18) - 1, (u64)1 << 17)
 }
 
 // ---- test hook: the K3 group law on its own (tests/test_gpu_parity.py::test_g2_k3_group_law) -----------------

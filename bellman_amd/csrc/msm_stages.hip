@@ -263,12 +263,12 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
 // stream has W*n entries over 2^(c-1) buckets: c is chosen so that a bucket holds a handful of entries (runs that
 // span a few chunks at most), which is 3-4 bits more than the classic plan uses for the same n.
 unsigned table_window_bits(u64 n_bases, bool g2) {
-  (void)g2;
   // only window sizes whose top window is not a sliver (260 = 20 x 13, 256 = 16 x 16): a sliver puts the top digit of
   // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/r2_call2_sizes_and_table_sweeps.txt:
   // c = 12 and 14 are 1.5-2x slower than 13 at 2^10-2^14)
   const u32 lg = ilog2(n_bases ? n_bases : 1);
-  return lg <= 11 ? 13 : lg <= 17 ? 16 : 20;   // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20
+  // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20.  G2 stays at 16: its bucket reduction is the expensive part
+  return lg <= 11 ? 13 : (g2 || lg <= 17) ? 16 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
@@ -289,8 +289,11 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   const u32 lg = ilog2(p.n ? p.n : 1);
   const u32 base_k = lg <= 20 ? 8 : lg <= 22 ? 16 : g2 ? 64 : 32;
   const u64 avg = (u64)p.n >> (p.c - 1);
-  (void)num_cus;
-  const u64 k = std::max<u64>(base_k, avg);
+  // ... but never so long that the chip runs out of lanes (one wavefront per SIMD for the register-heavy
+  // one-lane-per-point G2 accumulation, two otherwise); runs of 2-4 chunks are still folded by their owner lane
+  const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2);
+  u64 k = std::max<u64>(base_k, avg);
+  k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_min));
   p.chunk = forced_chunk ? forced_chunk : (u32)k;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
