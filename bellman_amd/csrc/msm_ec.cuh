@@ -320,24 +320,30 @@ template <class F>
 struct SumJobs {
   SumJob<F> j[3];
 };
+// A block carries 64 workers: one wavefront of single lanes, or FOUR wavefronts of 16 lane triples (K3) - so that a
+// K3 reduction can also put up to 64 workers on one output (the tree then crosses wavefronts through LDS); with 16
+// the 256-element column sums of a window table's 2^15 buckets were 16 + 4 additions deep.
 template <class F>
-__global__ __launch_bounds__(64, F::LANES == 3 ? 2 : 1) void msm_sum_kernel(SumJobs<F> jobs) {
+constexpr u32 sum_block_threads() { return F::LANES == 3 ? 256u : 64u; }
+template <class F>
+__global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void msm_sum_kernel(SumJobs<F> jobs) {
   u32 blk = blockIdx.x;
   u32 which = 0;
   if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
   const SumDesc d = jobs.j[which].d;
   const XYZZ<typename F::Mem> *in = jobs.j[which].in;
   XYZZ<typename F::Mem> *out = jobs.j[which].out;
-  constexpr u32 PW = tree_per_wave<F>();
+  constexpr u32 PW = tree_per_wave<F>(), NWAVES = sum_block_threads<F>() / 64, WPB = PW * NWAVES;   // WPB == 64
   u32 t, gid;
-  const bool live = worker_index<F>(PW, t, gid);   // one wavefront per block: t = worker inside the wavefront
+  const bool live = worker_index<F>(PW, t, gid);   // t = worker inside the block
   const u32 G = d.lanes;
-  const u32 g = (blk * PW + t) / G;
+  const u32 g = (blk * WPB + t) / G;
   const u32 sub = t & (G - 1);
   // single-lane G2: partial sums live in LDS slots (an XYZZ<Fp2> accumulator is 96 VGPRs) and the tree reads
   // the partner's slot directly; G1 and K3-form G2 keep registers + shuffles
   constexpr bool LDS_ACC = (F::LANES == 1 && F::WORDS == 24);
   __shared__ XYZZ<F> lds_acc[LDS_ACC ? 64 : 1];
+  __shared__ XYZZ<F> wave_part[NWAVES > 1 ? NWAVES : 1][F::LANES];
   XYZZ<F> reg_acc;
   XYZZ<F> &acc = LDS_ACC ? lds_acc[threadIdx.x] : reg_acc;
   xyzz_set_identity(acc);
@@ -371,8 +377,19 @@ __global__ __launch_bounds__(64, F::LANES == 3 ? 2 : 1) void msm_sum_kernel(SumJ
         lds_acc[threadIdx.x] = r;
       }
     }
-  } else {
+  } else if (NWAVES == 1 || G <= PW) {
     group_reduce_points<F>(acc, G, sub);
+  } else {
+    // the group spans G / PW wavefronts: tree inside each wavefront, partials through LDS, tree over the partials
+    const u32 wave = threadIdx.x >> 6, t_in_wave = t - wave * PW, role = F::LANES == 1 ? 0u : k3_role();
+    group_reduce_points<F>(acc, PW, t_in_wave);
+    if (live && t_in_wave == 0) wave_part[wave][role] = acc;
+    __syncthreads();
+    const u32 wpg = G / PW;                       // wavefronts per group (2 or 4); the group's first wavefront folds
+    if ((wave & (wpg - 1)) == 0) {
+      if (live && t_in_wave < wpg) acc = wave_part[wave + t_in_wave][role]; else xyzz_set_identity(acc);
+      group_reduce_points<F>(acc, wpg, t_in_wave);
+    }
   }
   if (live && sub == 0 && g < d.groups) store_xyzz<F>(&out[g], acc);
 }
@@ -585,18 +602,21 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
   // G workers per output chosen so that each launch is about one wavefront per SIMD.
   Pt *rows = rowcol, *cols = rowcol + (u64)p.W * H;
-  constexpr u32 PW = tree_per_wave<FR>();   // workers per one-wavefront block of the sum kernel
+  constexpr u32 PW = 64;   // workers per block of the sum kernel (one wavefront, or four wavefronts of 16 lane triples)
   // workers per output: minimise (serial adds per worker + tree depth) x (waves per SIMD, at least 1);
   // these kernels are latency-bound chains of point additions, not throughput-bound.
   auto pick_lanes = [&](u32 groups, u32 count) {
-    const double simds = (double)c.num_cus * 4;
+    // wavefront slots: two resident wavefronts per SIMD interleave almost for free (G1, lane triples); the
+    // register-heavy one-lane-per-point G2 kernels have one.  A block of lane triples is four wavefronts.
+    const double slots = (double)c.num_cus * 4 * ((G2 && FR::LANES == 1) ? 1 : 2);
+    const double waves_per_block = FR::LANES == 3 ? 4.0 : 1.0;
     u32 best = 1;
     double best_cost = 1e30;
     for (u32 g = 1, lg = 0; g <= PW; g <<= 1, lg++) {
       if (g > count && g > 1) break;
       const double steps = (double)((count + g - 1) / g) + lg;
-      const double waves = (double)groups * g / (double)PW;
-      const double cost = steps * std::max(1.0, waves / simds);
+      const double waves = (double)groups * g / (double)PW * waves_per_block;
+      const double cost = steps * std::max(1.0, waves / slots);
       if (cost < best_cost) { best_cost = cost; best = g; }
     }
     return best;
@@ -634,7 +654,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       js.j[0].d.lanes = best_r; js.j[0].nblocks = blocks_for(dr.groups, best_r);
       js.j[1].d.lanes = best_c; js.j[1].nblocks = blocks_for(dc.groups, best_c);
     }
-    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(64), 0, st, js);
+    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(sum_block_threads<FR>()), 0, st, js);
     BH_HIP_CHECK(hipGetLastError());
     // sum_idx (idx+1) B[idx] = sum_p 2^p U[p] + T, idx = hi*2^l + lo:
     //   U[w][p], p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi),
@@ -651,7 +671,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     js.j[0] = make_job(cols, bits, bl);
     js.j[1] = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
     js.j[2] = make_job(t_from_cols ? cols : rows, bits + (u64)p.W * cb, bt);
-    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
+    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(sum_block_threads<FR>()), 0,
+                       st, js);
     BH_HIP_CHECK(hipGetLastError());
   }
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
