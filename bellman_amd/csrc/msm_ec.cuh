@@ -614,7 +614,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     double best_cost = 1e30;
     for (u32 g = 1, lg = 0; g <= PW; g <<= 1, lg++) {
       if (g > count && g > 1) break;
-      const double steps = (double)((count + g - 1) / g) + lg;
+      // a lane-triple group wider than one wavefront pays two barriers and an LDS round trip (measured: ~2 additions)
+      const double steps = (double)((count + g - 1) / g) + lg + ((FR::LANES == 3 && g > 16) ? 2.0 : 0.0);
       const double waves = (double)groups * g / (double)PW * waves_per_block;
       const double cost = steps * std::max(1.0, waves / slots);
       if (cost < best_cost) { best_cost = cost; best = g; }
