@@ -221,6 +221,8 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   for (auto &r : ctx->c.job_pool) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
     if (r.pinned) (void)hipHostFree(r.pinned);
+    if (r.hp_event) (void)hipEventDestroy(r.hp_event);
+    if (r.hp_stream) (void)hipStreamDestroy(r.hp_stream);
     if (r.stream) (void)hipStreamDestroy(r.stream);
   }
   ctx->c.job_pool.clear();

@@ -75,6 +75,10 @@ class DevicePool {
 struct JobResources {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // optional (BELLMAN_HIP_REDUCE_PRIORITY=1): the latency-bound merge / reduction kernels of the job on a
+  // high-priority stream, ordered after the accumulation by an event
+  hipStream_t hp_stream = nullptr;
+  hipEvent_t hp_event = nullptr;
   void *pinned = nullptr;          // host-pinned landing buffer for the job's result
   size_t pinned_bytes = 0;
 };

@@ -24,6 +24,7 @@
 //                  sums of those vectors and the plain window totals -> W*c points.
 //   6. tail        result = sum_w 2^(c*w) (sum_p 2^p U[w][p] + T[w]): a 256-step double-and-add,
 //                  inherently serial -> host, 64-bit limbs (host_fp.hpp).
+#include <stdlib.h>
 #include <string.h>
 
 #include "msm_types.hpp"
@@ -60,6 +61,16 @@ MsmJobImpl *msm_job_new(Context *ctx, int group) {
     j->res.pinned_bytes = JOB_PINNED_BYTES;
     if (!ok) { delete j; return nullptr; }
   }
+  static const bool reduce_priority = [] { const char *e = getenv("BELLMAN_HIP_REDUCE_PRIORITY"); return e && *e == '1'; }();
+  if (reduce_priority && !j->res.hp_stream) {
+    int lo = 0, hi = 0;   // numerically lower = higher priority
+    bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&j->res.hp_stream, hipStreamNonBlocking, hi) == hipSuccess &&
+              hipEventCreateWithFlags(&j->res.hp_event, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete j; return nullptr; }
+  }
+  j->hp_stream = reduce_priority ? j->res.hp_stream : nullptr;
+  j->hp_event = j->res.hp_event;
   j->stream = j->res.stream;
   j->ev_begin = j->res.ev[0]; j->ev_sorted = j->res.ev[1]; j->ev_accum = j->res.ev[2]; j->ev_end = j->res.ev[3];
   j->host_result = j->res.pinned;

@@ -587,6 +587,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     }
     BH_HIP_CHECK(hipGetLastError());
     if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
+    if (job.hp_stream) {   // the rest of the job (latency-bound chains) runs on the high-priority stream
+      BH_HIP_CHECK(hipEventRecord(job.hp_event, st));
+      BH_HIP_CHECK(hipStreamWaitEvent(job.hp_stream, job.hp_event, 0));
+      st = job.hp_stream;
+    }
     const u32 rwpb = workers_per_block<FR>(128, default_per_wave<FR>());
     const dim3 rgrid((p.chunks_per_window + rwpb - 1) / rwpb, p.W);
     hipLaunchKernelGGL(msm_merge_chunks_kernel<FR>, rgrid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
@@ -734,6 +739,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     return job.early_rc;
   }
   if (hipStreamSynchronize(job.stream) != hipSuccess) rc = BH_ERR_HIP;
+  if (job.hp_stream && hipStreamSynchronize(job.hp_stream) != hipSuccess) rc = BH_ERR_HIP;
   if (rc == BH_OK) {
     const MsmPlan &p = job.plan;
     constexpr size_t ERR_SLOT = 256;   // the carve granularity of msm_enqueue

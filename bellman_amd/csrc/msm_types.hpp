@@ -57,6 +57,8 @@ struct MsmJobImpl {
   Context *ctx = nullptr;
   int group = BH_G1;
   hipStream_t stream = nullptr;
+  hipStream_t hp_stream = nullptr;     // high-priority stream of the merge / reduction phase (null: same stream)
+  hipEvent_t hp_event = nullptr;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_sorted = nullptr, ev_accum = nullptr;   // stage boundaries (profiling)
   MsmPlan plan;

@@ -333,8 +333,11 @@ def _scalars(n, seed, special=True):
 @pytest.mark.parametrize("group", [1, 2])
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 100, 1000, 4113, 1 << 14])
 def test_msm_full_density_matches_oracle(worker, group, n):
-    """Appendix A 1,2,3,4,5,7,9 (n < 32 / >= 32 window rule boundary included)."""
+    """Appendix A 1,2,3,4,5,7,9 (n < 32 / >= 32 window rule boundary included).  Every size runs through the default
+    plan (window table for vectors this small, host path for a handful of terms) AND through the classic
+    W-window pipeline (NO_TABLE | NO_SMALL_PATH)."""
     import bellman_amd
+    from bellman_amd.multiexp import NO_SMALL_PATH, NO_TABLE
 
     if group == 2 and n > 5000:
         pytest.skip("G2 large case covered by test_msm_g2_2_14")
@@ -347,6 +350,8 @@ def test_msm_full_density_matches_oracle(worker, group, n):
     rc, want = cref.multiexp(group, bases, 0, None, sc)
     assert rc == 0
     assert np.array_equal(got, want)
+    classic = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=NO_TABLE | NO_SMALL_PATH).wait()
+    assert np.array_equal(classic, want)
 
 
 def test_msm_g2_2_14(worker):
@@ -629,12 +634,14 @@ def test_msm_fuzz_random_shapes(worker, seed):
             bases[5] = bases[4]
         c = int(rnd.choice([0, 2, 3, 4, 7, 8, 11, 13, 16]))
         K = int(rnd.choice([0, 1, 2, 5, 8, 16, 33, 1000]))
+        # 4 = classic W-window plan instead of the window table; 16 / 32 = G2 kernel bundle; 8 = no host path
+        flags = int(rnd.choice([0, 4, 8, 12])) | (int(rnd.choice([0, 16, 32])) if group == 2 else 0)
         hb = bellman_amd.Bases(worker, group, bases)
         dm = bellman_amd.FullDensity() if dens is None else bellman_amd.DensityTracker(dens)
-        got = bellman_amd.multiexp(worker, hb, dm, sc, skip=skip, window_bits=c, chunk=K).wait()
+        got = bellman_amd.multiexp(worker, hb, dm, sc, skip=skip, window_bits=c, chunk=K, flags=flags).wait()
         rc, want = cref.multiexp(group, bases, skip, None if dens is None else cref.density_bitmap(dens), sc)
         assert rc == 0
-        assert np.array_equal(got, want), (group, n, mode, c, K, skip, dens is not None)
+        assert np.array_equal(got, want), (group, n, mode, c, K, skip, dens is not None, flags)
 
 
 @pytest.mark.parametrize("group", [1, 2])
