@@ -123,7 +123,67 @@ BH_HD void xyzz_dbl_affine(XYZZ<F> &r, const Affine<F> &p) {
   F::sub(r.y, t, u);
 }
 
-// madd-2008-s: acc += affine q  (q must not be the identity; callers check)
+// madd-2008-s: acc += affine q  (q must not be the identity; callers check).
+// `prefetch` is called exactly once on every path, at the point after which no out-of-line call follows: every
+// non-kernel function starts with s_waitcnt vmcnt(0) (the AMDGPU calling convention cannot track the caller's
+// loads), so a load issued before ANY product call is waited for at that call - software prefetching across
+// calls is impossible.  The last product of the formula is therefore an INLINE copy of the multiplier
+// (F::mul_tail); loads issued by `prefetch` right before it have that whole product (1.2 us G1, 3.5 us G2) to land.
+// Pins the order "v is computed -> what follows": the products are pure functions, so without it the compiler sinks
+// the calls before `prefetch` below it (and hoists the loads above them).
+template <class T>
+BH_HD void order_after(T &v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  u32 *w = reinterpret_cast<u32 *>(&v);
+  __asm__ volatile("" : "+v"(w[0]), "+v"(w[sizeof(T) / 4 - 1]) : : "memory");   // a word of every Fp component
+#else
+  (void)v;
+#endif
+}
+template <class F, class PF>
+BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
+  typedef typename F::T T;
+  if (xyzz_is_identity(acc)) {
+    acc.x = q.x;
+    acc.y = q.y;
+    F::one(acc.zz);
+    F::one(acc.zzz);
+    prefetch();
+    return;
+  }
+  T p, r, pp, ppp, qq, t;
+  F::mul(p, q.x, acc.zz);
+  F::sub(p, p, acc.x);     // P = U2 - X1
+  F::mul(r, q.y, acc.zzz);
+  F::sub(r, r, acc.y);     // R = S2 - Y1
+  if (F::is_zero(p)) {
+    if (F::is_zero(r)) {
+      xyzz_dbl_affine(acc, q);  // same point
+    } else {
+      xyzz_set_identity(acc);   // opposite points
+    }
+    prefetch();
+    return;
+  }
+  // ordered so that at most four temporaries are live at once (PP and PPP die early): the G2
+  // instantiation is register-bound
+  F::sqr(pp, p);
+  F::mul(ppp, p, pp);                 // p dead
+  F::mul(qq, acc.x, pp);              // Q = X1*PP
+  F::mul(acc.zz, acc.zz, pp);         // ZZ3 = ZZ1*PP          (pp dead)
+  F::mul(acc.zzz, acc.zzz, ppp);      // ZZZ3 = ZZZ1*PPP
+  F::sqr(t, r);
+  F::sub(t, t, ppp);
+  F::sub(t, t, qq);
+  F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
+  F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
+  F::sub(qq, qq, t);
+  acc.x = t;
+  order_after(ppp);
+  prefetch();
+  F::mul_tail(qq, r, qq);             // R*(Q - X3)            (r dead); inline, see above
+  F::sub(acc.y, qq, ppp);
+}
 template <class F>
 BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
   typedef typename F::T T;
@@ -147,8 +207,6 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
     }
     return;
   }
-  // ordered so that at most four temporaries are live at once (PP and PPP die early): the G2
-  // instantiation is register-bound
   F::sqr(pp, p);
   F::mul(ppp, p, pp);                 // p dead
   F::mul(qq, acc.x, pp);              // Q = X1*PP

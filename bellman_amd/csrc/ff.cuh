@@ -532,6 +532,8 @@ struct FpOps {
   BH_HD static void canon(T &r) { fpl_canon(r, r); }
   BH_HD static void mul(T &r, const T &a, const T &b) { r = fp_mul_call(a, b); }
   BH_HD static void sqr(T &r, const T &a) { r = fp_sqr_call(a); }
+  // the same product INLINE (no call): for the one place where loads are in flight across it (ec.cuh, xyzz_madd)
+  BH_HD static void mul_tail(T &r, const T &a, const T &b) { fe_mul<FpParams, false>(r, a, b); }
   BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
     T one2;
     fe_one(r);
@@ -578,6 +580,17 @@ struct Fp2Ops {
     fpl_add(t2, a.c0, a.c1);
     fpl_add(t3, b.c0, b.c1);
     t2 = fp_mul_call(t2, t3);
+    fpl_sub(t2, t2, t0);
+    fpl_sub(r.c1, t2, t1);
+    fpl_sub(r.c0, t0, t1);
+  }
+  BH_HD static void mul_tail(T &r, const T &a, const T &b) {   // Karatsuba on the inline Fp product
+    fp_t t0, t1, t2, t3;
+    fe_mul<FpParams, false>(t0, a.c0, b.c0);
+    fe_mul<FpParams, false>(t1, a.c1, b.c1);
+    fpl_add(t2, a.c0, a.c1);
+    fpl_add(t3, b.c0, b.c1);
+    fe_mul<FpParams, false>(t2, t2, t3);
     fpl_sub(t2, t2, t0);
     fpl_sub(r.c1, t2, t1);
     fpl_sub(r.c0, t0, t1);

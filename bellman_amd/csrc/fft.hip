@@ -77,20 +77,45 @@ __device__ __forceinline__ void st_fr(fr_t *p, const fr_t &v) {
 }
 
 // ---- the multiplier with a pre-sliced second operand ---------------------------------------------------------
-// x * w for a table entry w in B form.  Out of line (operands and result in VGPRs, the entry is fetched inside):
-// a radix-8 step has 12 of these, inlined they would not fit the instruction cache.
-__device__ __attribute__((noinline)) static fr_t fr_mul_tw(u32x4 a0, u32x4 a1, const BTw *w) {
+// x * w for a table entry w in B form.  Out of line: a radix-8 step has 12 of these, inlined they would not fit the
+// instruction cache.  The entry used to be fetched inside - an L2-latency load in front of EVERY product that the
+// two wavefronts of a SIMD could not hide (23 % of the wave time, profiles/r2_call10_pmc_fft.json) - and a load
+// issued by the caller before the call would be waited for at the callee's first instruction (every non-kernel
+// function starts with s_waitcnt vmcnt(0)).  So the products are chained: a call receives its own entry IN
+// REGISTERS and the address of the NEXT product's entry, issues that load first, multiplies while it is in flight
+// and hands the loaded entry back with the result.
+struct TwReg {   // a table entry in registers: the nine 30-bit limbs
+  u32x4 a, b;
+  u32 c;
+};
+typedef u32 u32x20 __attribute__((ext_vector_type(20)));   // 8 result words, 9 entry words, 3 unused
+__device__ __forceinline__ TwReg tw_load(const BTw *w) {
+  const u32x4 *q = reinterpret_cast<const u32x4 *>(w);
+  TwReg t;
+  t.a = q[0]; t.b = q[1]; t.c = w->l[8];
+  return t;
+}
+__device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1, u32 w2, const BTw *next) {
+  const TwReg n = tw_load(next);
   fr_t a, r;
   a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
   a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
-  const uint4 *q = reinterpret_cast<const uint4 *>(w);
-  const uint4 b0 = q[0], b1 = q[1], b2 = q[2];
-  const u32 B[9] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x};
+  const u32 B[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2};
   fe_mul_b<FrParams>(r, a, B);
-  return r;
+  u32x20 o;
+  o[0] = r.l[0]; o[1] = r.l[1]; o[2] = r.l[2]; o[3] = r.l[3]; o[4] = r.l[4]; o[5] = r.l[5]; o[6] = r.l[6]; o[7] = r.l[7];
+  o[8] = n.a.x; o[9] = n.a.y; o[10] = n.a.z; o[11] = n.a.w; o[12] = n.b.x; o[13] = n.b.y; o[14] = n.b.z; o[15] = n.b.w;
+  o[16] = n.c; o[17] = 0; o[18] = 0; o[19] = 0;
+  return o;
 }
-__device__ __forceinline__ fr_t mul_tw(const fr_t &a, const BTw *w) {
-  return fr_mul_tw(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w);
+// a <- a * cur, cur <- *next
+__device__ __forceinline__ void mul_tw(fr_t &a, TwReg &cur, const BTw *next) {
+  const u32x20 o = fr_mul_tw(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, cur.a, cur.b, cur.c, next);
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.l[i] = o[i];
+  cur.a = u32x4{o[8], o[9], o[10], o[11]};
+  cur.b = u32x4{o[12], o[13], o[14], o[15]};
+  cur.c = o[16];
 }
 
 // ---- LDS tile: element `lin` (= col * R + position) lives in slot lin + lin/8 of two 16-byte planes -------------
@@ -113,6 +138,18 @@ __device__ __forceinline__ void tile_st(uint4 *p0, uint4 *p1, u32 lin, const fr_
 // stage s + j pairs t with t + 2^j (bit j of t clear) under the twiddle w_R^(((t mod 2^j) * 2^s + lo) * R / 2^(s+j+1)),
 // which is entry ((t mod 2^j) * 2^s + lo) * (1024 >> (s + j)) of the master table w_2048^i.
 // FIRST (s == 0): lo == 0, so stage 0 has no multiplication at all and the others only the constants w_4, w_8^k.
+// call order of a task's products: stage j ascending, then t ascending over the t with bit j clear
+template <int G, bool FIRST>
+__device__ __forceinline__ constexpr bool step_has_mul(int j, int t) {
+  return !(t & (1 << j)) && !(FIRST && (t & ((1 << j) - 1)) == 0);
+}
+template <int G, bool FIRST>
+__device__ __forceinline__ constexpr int step_next_mul(int j, int t) {   // (j' << 8 | t') of the product after (j, t); -1: none
+  for (int jj = j; jj < G; jj++)
+    for (int tt = (jj == j ? t + 1 : 0); tt < (1 << G); tt++)
+      if (step_has_mul<G, FIRST>(jj, tt)) return (jj << 8) | tt;
+  return -1;
+}
 template <int G, bool FIRST>
 __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 total, u32 r, u32 s, const BTw *master) {
   constexpr int N = 1 << G;
@@ -124,6 +161,11 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
     const u32 rest = task >> s;
     const u32 hi = rest & ((1u << hi_bits) - 1), col = rest >> hi_bits;
     const u32 pos0 = (col << r) + (hi << (s + G)) + lo;
+    auto tw_at = [&](int j, int t) { return master + ((u32)(t & ((1 << j) - 1)) * m + lo) * (1024u >> (s + j)); };
+    // the task's first entry travels with the LDS reads; each product fetches the next one's (fr_mul_tw)
+    constexpr int first_mul = step_next_mul<G, FIRST>(0, -1);
+    TwReg cur;
+    if (first_mul >= 0) cur = tw_load(tw_at(first_mul >> 8, first_mul & 255));
     fr_t e[N];
 #pragma unroll
     for (int t = 0; t < N; t++) e[t] = tile_ld(p0, p1, pos0 + ((u32)t << s));
@@ -132,11 +174,10 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
 #pragma unroll
       for (int t = 0; t < N; t++) {
         if (t & (1 << j)) continue;
-        const int tl = t & ((1 << j) - 1);          // t mod 2^j
         fr_t y = e[t + (1 << j)];
-        if (!(FIRST && tl == 0)) {                  // w^0 = 1: nothing to multiply
-          const u32 idx = ((u32)tl * m + lo) * (1024u >> (s + j));
-          y = mul_tw(y, master + idx);
+        if (step_has_mul<G, FIRST>(j, t)) {         // w^0 = 1 (FIRST, t mod 2^j == 0): nothing to multiply
+          const int nx = step_next_mul<G, FIRST>(j, t);
+          mul_tw(y, cur, nx >= 0 ? tw_at(nx >> 8, nx & 255) : master);
         }
         fr_t u, v;
         fe_add(u, e[t], y);
@@ -199,18 +240,45 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
   // ---- load (bit-reversed rows), optional pre-multiplication ------------------------------
   const u32 total = R << a.log_c;
   const u32 lb_mask = (1u << a.lb) - 1;
-  for (u32 e = tid; e < total; e += NTT_THREADS) {
-    u32 row, col;
-    if (!a.is_last) { row = e >> a.log_c; col = e & (C - 1); }   // consecutive lanes -> consecutive columns
-    else { col = e >> a.r; row = e & (R - 1); }                  // consecutive lanes -> consecutive rows
-    const u64 g = base + row * in_row_stride + col * in_col_stride;
-    fr_t v = ld_fr(a.in + g);
-    if (a.pre_lo) {
-      v = mul_tw(v, a.pre_hi + (u32)(g >> a.lb));
-      v = mul_tw(v, a.pre_lo + ((u32)g & lb_mask));
+  // All of a thread's loads are issued before anything else happens: a loop of "load, wait, multiply, store to LDS"
+  // exposed the full memory latency once per element (8 times per tile, a third of the kernel's time).
+  constexpr int PER = NTT_TILE / NTT_THREADS;   // elements per thread
+  {
+    fr_t v[PER];
+    u64 gi[PER];
+    u32 slot[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const u32 e = tid + (u32)i * NTT_THREADS;
+      u32 row, col;
+      if (!a.is_last) { row = e >> a.log_c; col = e & (C - 1); }   // consecutive lanes -> consecutive columns
+      else { col = e >> a.r; row = e & (R - 1); }                  // consecutive lanes -> consecutive rows
+      gi[i] = base + row * in_row_stride + col * in_col_stride;
+      const u32 rrow = a.r ? (__brev(row) >> (32 - a.r)) : 0;
+      slot[i] = (col << a.r) + rrow;
+      if (e < total) v[i] = ld_fr(a.in + gi[i]);
     }
-    const u32 rrow = a.r ? (__brev(row) >> (32 - a.r)) : 0;
-    tile_st(plane0, plane1, (col << a.r) + rrow, v);
+    if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
+      const BTw *ph[PER], *pl[PER];
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        const bool live = tid + (u32)i * NTT_THREADS < total;
+        ph[i] = a.pre_hi + (live ? (u32)(gi[i] >> a.lb) : 0u);
+        pl[i] = a.pre_lo + (live ? ((u32)gi[i] & lb_mask) : 0u);
+      }
+      TwReg cur = tw_load(ph[0]);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        if (tid + (u32)i * NTT_THREADS < total) {
+          mul_tw(v[i], cur, pl[i]);
+          mul_tw(v[i], cur, i + 1 < PER ? ph[i + 1] : a.pre_hi);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      if (tid + (u32)i * NTT_THREADS < total) tile_st(plane0, plane1, slot[i], v[i]);
+    }
   }
   // ---- the r DIT stages: radix-8 steps, then what is left (4 = 2 + 2 rather than 3 + 1) ---------------------
   {
@@ -227,23 +295,49 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
   }
   __syncthreads();
   // ---- store: inter-pass twiddle (non-last) or final scaling + digit-reversed position ------
-  for (u32 e = tid; e < total; e += NTT_THREADS) {
-    const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
-    fr_t v = tile_ld(plane0, plane1, (col << a.r) + row);
-    const u64 g = out_base + row * out_row_stride + col * out_col_stride;
-    if (!a.is_last) {
-      const u32 ex = (u32)((((u64)(jp0 + col) * row) << a.s) & n_mask);
-      if (ex) {   // w^0 = 1 (row 0, column 0 of the vector): skipped where the whole wavefront agrees
-        v = mul_tw(v, a.tw_hi + (ex >> a.lb));
-        v = mul_tw(v, a.tw_lo + (ex & lb_mask));
-      }
-    } else if (a.post_lo) {
-      v = mul_tw(v, a.post_hi + (u32)(g >> a.lb));
-      v = mul_tw(v, a.post_lo + ((u32)g & lb_mask));
-    } else if (a.post_const) {
-      v = mul_tw(v, a.post_const);
+  // every product first, every store last: stores count in vmcnt and each out-of-line product starts with
+  // s_waitcnt vmcnt(0), so a store followed by the next element's product waited for the store to land
+  {
+    fr_t v[PER];
+    u64 gi[PER];
+    const BTw *ph[PER], *pl[PER];
+    // the two-level table a pass multiplies its outputs with: inter-pass twiddles w_n^ex (not the last pass; ex = 0
+    // gives hi[0] * lo[0] = 1 * 1, exact in Montgomery form), or the coset / 1/n scaling of the last pass
+    const BTw *hi_tab = !a.is_last ? a.tw_hi : a.post_hi, *lo_tab = !a.is_last ? a.tw_lo : a.post_lo;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const u32 e = tid + (u32)i * NTT_THREADS;
+      const bool live = e < total;
+      const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
+      if (live) v[i] = tile_ld(plane0, plane1, (col << a.r) + row);
+      const u64 g = out_base + row * out_row_stride + col * out_col_stride;
+      gi[i] = g;
+      u32 ex = 0;
+      if (live) ex = !a.is_last ? (u32)((((u64)(jp0 + col) * row) << a.s) & n_mask) : (u32)g;
+      ph[i] = hi_tab + (ex >> a.lb);
+      pl[i] = lo_tab + (ex & lb_mask);
     }
-    st_fr(a.out + g, v);
+    if (hi_tab) {
+      TwReg cur = tw_load(ph[0]);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        if (tid + (u32)i * NTT_THREADS < total) {
+          mul_tw(v[i], cur, pl[i]);
+          mul_tw(v[i], cur, i + 1 < PER ? ph[i + 1] : hi_tab);
+        }
+      }
+    } else if (a.is_last && a.post_const) {
+      TwReg cur = tw_load(a.post_const);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        if (tid + (u32)i * NTT_THREADS < total) mul_tw(v[i], cur, a.post_const);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const u32 e = tid + (u32)i * NTT_THREADS;
+      if (e < total) st_fr(a.out + gi[i], v[i]);
+    }
   }
 }
 

@@ -113,6 +113,8 @@ struct Fp2K3Ops {
 
   __device__ __forceinline__ static void mul(T &r, const T &a, const T &b);
   __device__ __forceinline__ static void sqr(T &r, const T &a);
+  // lane triples run where the job is latency-bound and two wavefronts share a SIMD: no inline copy of the product
+  __device__ __forceinline__ static void mul_tail(T &r, const T &a, const T &b) { mul(r, a, b); }
   __device__ __forceinline__ static void curve_b(T &r) {   // 4(1 + u) = (4, 4, 8)
     FpOps::curve_b(r);
     if (k3_role() == 2) fpl_add(r, r, r);

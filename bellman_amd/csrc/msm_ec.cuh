@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 
 #include "fp2k3.cuh"
@@ -115,19 +116,57 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   xyzz_set_identity(acc);
   u32 cur = v.d_first;
   bool saw_identity = false;
-  for (u32 p = v.begin; p < v.end; p++) {
-    const u64 e = src[p];
-    const u32 d = (u32)(e >> 32);
-    if (d != cur) {   // bucket `cur` ends inside this chunk
-      store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
-      xyzz_set_identity(acc);
-      cur = d;
-    }
+  // Software pipeline (one lane per G2 point only: the kernels that fit two wavefronts per SIMD would lose the second
+  // one to the extra live registers, and the second wavefront already covers their loads): the entry two steps
+  // ahead and the base point one step ahead are loaded by `prefetch`, which xyzz_madd calls right before its last
+  // (inline) product - the only stretch of an iteration without an out-of-line call, i.e. without a forced
+  // s_waitcnt vmcnt(0) (ec.cuh).  With one resident wavefront per SIMD the two dependent loads of an iteration were
+  // 21 % of the kernel's time (profiles/r2_call8_pmc_g2_accumulate.json).
+  constexpr bool PIPELINED = F::LANES == 1 && F::WORDS == 24;
+  if constexpr (PIPELINED) {
+    u64 e = src[v.begin];
+    u64 e1 = v.begin + 1 < v.end ? src[v.begin + 1] : 0;
     Affine<F> q;
     load_affine<F>(q, bases + ((u32)e & 0x7fffffffu));
-    if (aff_is_identity(q)) { saw_identity = true; continue; }
-    if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
-    xyzz_madd(acc, q);
+    for (u32 p = v.begin; p < v.end; p++) {
+      const u32 d = (u32)(e >> 32);
+      if (d != cur) {   // bucket `cur` ends inside this chunk
+        store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
+        xyzz_set_identity(acc);
+        cur = d;
+      }
+      Affine<F> qn = q;
+      u64 e2 = 0;
+      auto prefetch = [&]() {
+        if (p + 1 < v.end) load_affine<F>(qn, bases + ((u32)e1 & 0x7fffffffu));
+        if (p + 2 < v.end) e2 = src[p + 2];
+      };
+      if (aff_is_identity(q)) {
+        saw_identity = true;
+        prefetch();
+      } else {
+        if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
+        xyzz_madd(acc, q, prefetch);
+      }
+      q = qn;
+      e = e1;
+      e1 = e2;
+    }
+  } else {
+    for (u32 p = v.begin; p < v.end; p++) {
+      const u64 e = src[p];
+      const u32 d = (u32)(e >> 32);
+      if (d != cur) {   // bucket `cur` ends inside this chunk
+        store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
+        xyzz_set_identity(acc);
+        cur = d;
+      }
+      Affine<F> q;
+      load_affine<F>(q, bases + ((u32)e & 0x7fffffffu));
+      if (aff_is_identity(q)) { saw_identity = true; continue; }
+      if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
+      xyzz_madd(acc, q);
+    }
   }
   store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : v.tail_partial ? &tail[slot] : &bucket[cur], acc);
   if (saw_identity) atomicOr(&err->ident, 1u);
@@ -394,6 +433,18 @@ __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void
   if (live && sub == 0 && g < d.groups) store_xyzz<F>(&out[g], acc);
 }
 
+// Resident wavefronts per SIMD the lane cost model assumes for the reduction kernels: [0] G1, [1] G2 one lane per
+// point, [2] G2 lane triples.  One each: a second resident wavefront does NOT interleave for free in these mad-bound
+// chains (profiles/r2_call8_slots.txt: G1 2^17-2^20 reduce 0.73-0.99 ms with 1, 0.92-1.19 ms with 2; G2 within noise).
+// BELLMAN_HIP_SUM_SLOTS="a,b,c" overrides for sweeps.
+inline double sum_slot_factor(int kind) {
+  static const std::array<double, 3> f = [] {
+    std::array<double, 3> v = {1.0, 1.0, 1.0};
+    if (const char *e = getenv("BELLMAN_HIP_SUM_SLOTS")) sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);
+    return v;
+  }();
+  return f[kind];
+}
 // ============================================================================================
 // fixed-base scalar multiplication (fixture generation) and test hooks
 // ============================================================================================
@@ -611,9 +662,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // workers per output: minimise (serial adds per worker + tree depth) x (waves per SIMD, at least 1);
   // these kernels are latency-bound chains of point additions, not throughput-bound.
   auto pick_lanes = [&](u32 groups, u32 count) {
-    // wavefront slots: two resident wavefronts per SIMD interleave almost for free (G1, lane triples); the
-    // register-heavy one-lane-per-point G2 kernels have one.  A block of lane triples is four wavefronts.
-    const double slots = (double)c.num_cus * 4 * ((G2 && FR::LANES == 1) ? 1 : 2);
+    // wavefront slots per SIMD the launch may fill before a step stretches (sum_slot_factor); a block of lane
+    // triples is four wavefronts
+    const double slots = (double)c.num_cus * 4 * sum_slot_factor(G2 ? (FR::LANES == 1 ? 1 : 2) : 0);
     const double waves_per_block = FR::LANES == 3 ? 4.0 : 1.0;
     u32 best = 1;
     double best_cost = 1e30;

@@ -231,10 +231,10 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   // cheaper additions moved every boundary down by 2-3 powers of two
   // G2 keeps c = 13 up to 2^17: its bucket reduction is two G2 additions per bucket and throughput-bound, 16 windows
   // of 2^15 buckets cost ~2 ms whatever n is - more than the 25 % extra accumulation of 20 windows below 2^18
-  // (profiles/r2_call4_*: 2^16 2.4 vs 3.0 ms, 2^17 3.5 vs 3.8, 2^18 5.4 = 5.4).  From 2^25 terms on the accumulation
-  // saved by 13 windows of 20 bits outweighs the 6.8 M-bucket reduction (2^24: 50 -> 40 ms accumulate for +9 ms of
-  // reduction and a third sort pass).
-  int c = g2 ? (lg <= 12 ? 8 : lg <= 17 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 24 ? 16 : 20);
+  // (profiles/r2_call4_*: 2^16 2.4 vs 3.0 ms, 2^17 3.5 vs 3.8, 2^18 5.4 = 5.4).  From 2^24 terms on the accumulation
+  // saved by 13 windows of 20 bits outweighs the 6.8 M-bucket reduction (profiles/r2_call8_c20.txt, 2^24: accumulate
+  // 47.6 -> 37.9 ms for +5.2 ms of reduction and a third sort pass; 2^23: 28.6 vs 29.4 ms, no gain).
+  int c = g2 ? (lg <= 12 ? 8 : lg <= 17 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 23 ? 16 : 20);
   if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
   p.c = (u32)c;
   // Signed c-bit digits d in [-(2^(c-1)-1), 2^(c-1)]: bucket index |d|-1 < 2^(c-1), the sign is
@@ -252,7 +252,9 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
                          : g2 ? (lg <= 11 ? 8 : lg <= 15 ? 16 : lg <= 17 ? 32 : 64)   // G2: fewer, costlier partials
                               : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
   // never let a typical bucket span many chunks: the chunk merge is serial per bucket
-  if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, n >> (p.c - 1));
+  // (c = 20: twice the average run - every chunk partial is a 192-byte record written, read and merged, and there
+  // are 6.8 M buckets to merge into; 2^24: reduce 8.4 -> 6.1 ms)
+  if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, (n >> (p.c - 1)) << (p.c >= 20 ? 1 : 0));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
   p.nd = p.n; p.Wd = p.W; p.base_stride = 0;

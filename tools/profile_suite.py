@@ -5,6 +5,7 @@ statistics of a run belong to exactly one configuration).
   python tools/profile_suite.py fft <log_n> [iters]                       fft, ifft, coset_fft, icoset_fft
   python tools/profile_suite.py mimc [iters]                              create_proof on MiMC-322 (config C1)
   python tools/profile_suite.py sizes <group> <lo> <hi>                   per-stage device ms for 2^lo..2^hi
+  python tools/profile_suite.py proof [log_n] [iters] [threads]           create_proof, chain circuit, R1CS resident
 
 Prints host-side timings; run it under `rocprofv3 --kernel-trace --stats` for the per-kernel view."""
 import ctypes
@@ -136,5 +137,42 @@ def run_mimc(args):
           (walls[len(walls) // 2], walls[0], *med), flush=True)
 
 
+def run_proof(args):
+    """create_proof on the 2^log_n chain circuit with the constraint matrices resident in HBM: single-stream latency
+    (per-phase host ms) and throughput with `threads` host threads on one context."""
+    log_n = int(args[0]) if args else 20
+    iters = int(args[1]) if len(args) > 1 else 5
+    threads = int(args[2]) if len(args) > 2 else 12
+    from concurrent.futures import ThreadPoolExecutor
+    from bellman_amd import groth16 as pg
+
+    w = bellman_amd.Worker(0)
+    rounds, seed = (1 << log_n) - 3, 2020
+    r1cs = pg.R1CS.from_demo(w, 1, rounds, seed)
+    params = pg.Parameters.generate(w, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+    walls, tms = [], []
+    for it in range(iters + 2):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, seed, [987654321 + it], None, 0xABCDEF0123 + it, 0x123456789AB, tm)
+        wall = (time.perf_counter() - t0) * 1e3
+        if it >= 2:
+            walls.append(wall)
+            tms.append(tm)
+    walls.sort()
+    med = [sorted(t[i] for t in tms)[len(tms) // 2] for i in range(4)]
+
+    def one(i):
+        pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, seed, [1234567 + i], None, 0x55AA + i, 0x77, None)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(one, range(threads * 3)))
+    conc = threads * 3 / (time.perf_counter() - t0)
+    print("create_proof 2^%d (R1CS resident) REDUCE_PRIORITY=%s: wall median %.2f ms (min %.2f); host ms [witness %.2f, issue+h %.2f, "
+          "h multiexp + waits %.2f, total %.2f]; %d threads: %.2f proofs/s" %
+          (log_n, os.environ.get("BELLMAN_HIP_REDUCE_PRIORITY", "0"), walls[len(walls) // 2], walls[0], *med, threads, conc), flush=True)
+
+
 if __name__ == "__main__":
-    {"msm": run_msm, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes}[sys.argv[1]](sys.argv[2:])
+    {"msm": run_msm, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes, "proof": run_proof}[sys.argv[1]](sys.argv[2:])
