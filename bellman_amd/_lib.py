@@ -48,6 +48,9 @@ def load():
             "libbellman_hip.so not built (run `make -C bellman_amd/csrc`); "
             "bellman_amd has no CPU fallback"
         )
+    # more hardware queues than the runtime's 4: a proof runs 6-7 job streams at once (see api.hip); must be in the
+    # environment before the process' first HIP call
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, sz, u32, i32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_int
