@@ -269,8 +269,12 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/r2_call2_sizes_and_table_sweeps.txt:
   // c = 12 and 14 are 1.5-2x slower than 13 at 2^10-2^14)
   const u32 lg = ilog2(n_bases ? n_bases : 1);
-  // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20.  G2 stays at 16: its bucket reduction is the expensive part
-  return lg <= 11 ? 13 : (g2 || lg <= 17) ? 16 : 20;
+  // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20.  G2 stays at 16 above 2^15: its bucket reduction is the expensive
+  // part.  13 again around 2^15-2^16, where the 2^15-bucket set of c = 16 is reduced by a launch that no longer
+  // fills the chip (profiles/r2_call15_table_bits.txt: G1 2^15 0.79 vs 0.90 ms, 2^16 0.96 vs 1.03; G2 2^15 1.64 vs 1.74)
+  if (lg <= 11) return 13;
+  if (g2) return lg == 15 ? 13 : 16;
+  return (lg == 15 || lg == 16) ? 13 : lg <= 17 ? 16 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
