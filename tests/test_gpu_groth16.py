@@ -200,3 +200,53 @@ def test_golden_fixtures_on_device(worker):
         assert cref.arr_to_ints(cref.fr_from_mont(arr[:n_cons])) == ints(asg[name]), name
     for which, name in enumerate(("a_aux_density", "b_input_density", "b_aux_density")):
         assert list(r1cs.density(which)[0]) == asg[name], name
+
+
+def test_concurrent_proofs_and_multiexps_from_host_threads(worker):
+    """One context, many host threads (the Worker is shared; a proving service drives it this way,
+    bench.py's `proofs_per_s_concurrent`): 8 threads x 6 MiMC-322 proofs with the same witness and r, s must all
+    equal the single-threaded proof (which test_mimc_322_config_c1 pins to the oracle), while 4 more threads keep
+    multiexps of other sizes in flight on the same context and check their own results."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import bellman_amd
+    from bellman_amd import groth16 as pg
+
+    rnd = random.Random(323)
+    cons = [rnd.randrange(Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr = rnd.randrange(Q), rnd.randrange(Q)
+    r, s = rnd.randrange(Q), rnd.randrange(Q)
+    r1cs = pg.R1CS.from_demo(worker, 0, circuits.MIMC_ROUNDS, 0, cons)
+    p = generate_parameters(CBls12, circuits.mimc_circuit(0, 0, cons), CBls12.G1.gen, CBls12.G2.gen, **TOXIC)
+    params = _product_params(worker, p)
+    want = pg.create_proof_demo(params, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s)
+    want_r = pg.create_proof_demo_r1cs(params, r1cs, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s)
+    assert _same(want_r, want.a, want.b, want.c)
+
+    msm_cases = []
+    for i, (g, n) in enumerate([(1, 1500), (2, 700), (1, 40000), (2, 9000)]):
+        bases = cref.gen_bases(g, n, a=i + 2, b=5)
+        sc = cref.random_fr(n, 900 + i)
+        msm_cases.append((bellman_amd.Bases(worker, g, bases), sc, cref.multiexp(g, bases, 0, None, sc)[1]))
+
+    def prove(i):
+        for k in range(6):
+            if (i + k) & 1:
+                got = pg.create_proof_demo(params, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s)
+            else:
+                got = pg.create_proof_demo_r1cs(params, r1cs, 0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons, r, s)
+            assert _same(got, want.a, want.b, want.c), (i, k)
+        return True
+
+    def msm(i):
+        hb, sc, expect = msm_cases[i]
+        for _ in range(8):
+            jobs = [bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc) for _ in range(2)]
+            for j in jobs:
+                assert np.array_equal(j.wait(), expect), i
+        return True
+
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        futs = [ex.submit(prove, i) for i in range(8)] + [ex.submit(msm, i) for i in range(4)]
+        assert all(f.result() for f in futs)
+    r1cs.release()
