@@ -71,3 +71,42 @@ def main():
 
 
 main()
+
+
+def write_summary(tag):
+    """profiles/<tag>_summary.md from the files main() wrote."""
+    prof = os.path.join(ROOT, "profiles")
+    d = json.load(open(os.path.join(prof, tag + "_bench.json")))
+    cp = d["create_proof"]; r = cp["with_r1cs_resident_in_hbm"]; mm = d["create_proof_mimc"]; rf = d["roofline"]; dm = d["config"]["device_ms"]
+    pmc = json.load(open(os.path.join(prof, tag + "_pmc_accumulate.json")))
+    tests = [ln for ln in open(os.path.join(prof, tag + "_gputests.txt")) if " passed" in ln]
+    L = []
+    A = L.append
+    A("# Round 2, final run on one MI355X (tools/gpu_final.sh, summarised by tools/summarize_final.py)\n")
+    A("`pytest tests -m gpu`: %s (`%s_gputests.txt`); `__graft_entry__.smoke()`: ok.\n" % (tests[-1].strip() if tests else "?", tag))
+    A("## bench.py (default flags; `%s_bench.json`)\n" % tag)
+    A("| item | value |\n|---|---|")
+    A("| `value` (G1 MSM 2^20, inputs resident in HBM, mean of %d steps) | %.1f M scalar-mul/s, %.3f ms per step (median %.3f ms) |" % (d["steps"], d["value"], d["ms_per_step"], d["config"]["ms_per_step_median"]))
+    A("| device stages (HIP events inside the library) | pipeline %.2f = digits+sort %.2f + accumulate %.2f + merge/reduce %.2f ms |" % (dm["pipeline"], dm["digits_sort"], dm["bucket_accumulate"], dm["merge_reduce"]))
+    A("| two jobs in flight / host scalars (PCIe inclusive) | %.1f / %.1f M scalar-mul/s |" % (d["config"]["value_with_2_jobs_in_flight"], d["config"]["value_per_gpu_with_host_scalars_pcie_inclusive"]))
+    A("| roofline (HBM) | %.1f GB/s algorithmic of 8000 = %.4f; traffic per launch %.2f GB read-corrected (upper bound) / %.2f GB uncorrected vs 0.134 GB algorithmic (`%s_pmc_accumulate.json`) |" % (rf["achieved"], rf["frac"], pmc["traffic_bytes_upper"] / 1e9, pmc["traffic_bytes_lower"] / 1e9, tag))
+    A("| roofline (integer ALU) | %.2f T mad/s of %.1f measured peak = %.3f |" % (rf["alu"]["achieved"], rf["alu"]["peak"], rf["alu"]["frac"]))
+    A("| CPU baseline (C restatement, %d window tasks) | %.2f M scalar-mul/s |" % (d["cpu_baseline"]["cores"], d["cpu_baseline"]["value"]))
+    for s in d["msm_other_shapes"]:
+        A("| %s MSM 2^%d | %.2f ms wall median (device %.2f: sort %.2f, accumulate %.2f, reduce %.2f) |" % (s["group"], s["log_n"], s["ms_median"], s["device_ms"]["pipeline"], s["device_ms"]["digits_sort"], s["device_ms"]["bucket_accumulate"], s["device_ms"]["merge_reduce"]))
+    A("| create_proof MiMC-322 (C1) | %.2f ms median of %d (%.0f proofs/s); CPU restatement on %d threads: %.1f proofs/s |" % (mm["ms_median"], mm["samples"], mm["proofs_per_s"], mm["cpu_baseline"]["cores"], mm["cpu_baseline"]["value"]))
+    f = d["fft"]
+    A("| FFT 2^22 (C3) fft / ifft / coset_fft / icoset_fft | %.3f / %.3f / %.3f / %.3f ms = %.0f / %.0f / %.0f / %.0f GB/s algorithmic |" % tuple([f[k]["ms"] for k in ("fft", "ifft", "coset_fft", "icoset_fft")] + [f[k]["algorithmic_GBps"] for k in ("fft", "ifft", "coset_fft", "icoset_fft")]))
+    A("| create_proof 2^20 constraints (C4), host synthesis as in the reference | %.2f proofs/s (%.1f ms: synthesis %.1f, issue %.1f, waits %.1f); 12 host threads: %.1f proofs/s |" % (cp["proofs_per_s"], cp["ms_total"], cp["ms_host_synthesis"], cp["ms_issue_7_multiexps_then_h_block_incl_uploads"], cp["ms_h_multiexp_and_waits"], cp["proofs_per_s_concurrent"]))
+    A("| ... constraint matrices resident in HBM | %.2f proofs/s (%.1f ms: witness %.1f, issue %.1f, waits %.1f); 12 host threads: %.1f proofs/s |" % (r["proofs_per_s"], r["ms_total"], r["ms_host_witness"], r["ms_issue_7_multiexps_then_h_block_incl_uploads"], r["ms_h_multiexp_and_waits"], r["proofs_per_s_concurrent"]))
+    A("| ... CPU restatement of the prover, %d host threads | %.4f proofs/s (%.2f s) |" % (cp["cpu_baseline"]["cores"], cp["cpu_baseline"]["value"], cp["cpu_baseline"]["seconds"]))
+    A("\n## Per-size tables (`%s_sizes.txt`, tools/profile_suite.py sizes), FFT (`%s_fft.txt`), MiMC (`%s_mimc.txt`)\n" % (tag, tag, tag))
+    A("```\n" + open(os.path.join(prof, tag + "_sizes.txt")).read() + open(os.path.join(prof, tag + "_fft.txt")).read() + open(os.path.join(prof, tag + "_mimc.txt")).read() + "```\n")
+    extra = os.path.join(prof, tag + "_targets.md")
+    if os.path.exists(extra):
+        A(open(extra).read())
+    open(os.path.join(prof, tag + "_summary.md"), "w").write("\n".join(L) + "\n")
+
+
+if len(sys.argv) > 2:
+    write_summary(sys.argv[2])
