@@ -272,7 +272,9 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20.  G2 stays at 16 above 2^15: its bucket reduction is the expensive
   // part.  13 again around 2^15-2^16, where the 2^15-bucket set of c = 16 is reduced by a launch that no longer
   // fills the chip (profiles/r2_call15_table_bits.txt: G1 2^15 0.79 vs 0.90 ms, 2^16 0.96 vs 1.03; G2 2^15 1.64 vs 1.74)
-  if (lg <= 11) return 13;
+  // tiny G2 vectors: 32 rows of 8 bits - 128 buckets instead of 4096 mostly empty ones, a shorter reduction chain
+  // (profiles/r2_call19_table_bits_tiny.txt: 2^9 0.65 vs 0.80 ms, 2^10 0.72 vs 0.81, 2^11 0.85 vs 0.91; G1: no difference)
+  if (lg <= 11) return g2 ? 8 : 13;
   if (g2) return lg == 15 ? 13 : 16;
   return (lg == 15 || lg == 16) ? 13 : lg <= 17 ? 16 : 20;
 }

@@ -645,7 +645,7 @@ def test_msm_fuzz_random_shapes(worker, seed):
 
 
 @pytest.mark.parametrize("group", [1, 2])
-@pytest.mark.parametrize("n,cbits", [(1, 0), (2, 3), (37, 0), (1000, 5), (1000, 0), (5000, 11), (1 << 14, 0), (1 << 14, 16)])
+@pytest.mark.parametrize("n,cbits", [(1, 0), (2, 3), (37, 0), (1000, 5), (1000, 0), (1000, 8), (5000, 11), (1 << 14, 0), (1 << 14, 16)])
 def test_multiexp_with_window_table(worker, group, n, cbits):
     """bh_bases_precompute: all windows into one bucket set via the stored multiples 2^(c*j) P -
     the same group element as without the table and as the oracle, with skip and a density map."""
