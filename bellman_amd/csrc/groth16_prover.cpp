@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <memory>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -219,16 +220,19 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
                            dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
     BH_TRACE("  multiexp of %zu terms issued", sl.hi - sl.lo);
   };
-  auto issue_seven = [&] {
+  auto issue_seven = [&](bool longest_first) {
+    // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
+    // (small proofs: the G2 multiexp is the longest job, and the host needs ~0.2 ms to enqueue each job's ~20 launches:
+    //  what is issued last finishes last)
+    if (longest_first) issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
     issue(params.l, 0, d_aux.p, n_aux, nullptr, nullptr, &l_job);
     // get_a(num_inputs, _) -> ((a,0),(a,num_inputs))            groth16/src/lib.rs:451-457
     issue(params.a, 0, d_in.p, n_in, nullptr, nullptr, &a_in_job, src.inputs);
     issue(params.a, n_in, d_aux.p, n_aux, dens_a_aux, hw_a_aux, &a_aux_job);
-    // get_b_g1/g2(b_input_density_total, _) -> ((b,0),(b,total))   groth16/src/lib.rs:459-473
     issue(params.b_g1, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b1_in_job, src.inputs);
     issue(params.b_g1, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b1_aux_job);
     issue(params.b_g2, 0, d_in.p, n_in, dens_b_in, hw_b_in, &b2_in_job, src.inputs);
-    issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
+    if (!longest_first) issue(params.b_g2, b_in_total, d_aux.p, n_aux, dens_b_aux, hw_b_aux, &b2_aux_job);
   };
   // h block (prover.rs:221-245), enqueue only: a, b, c stay in HBM; the quotient's coefficients are consumed by the
   // H multiexp straight from device memory (no host round trip, no serial Fr -> Exponent pass)
@@ -251,12 +255,37 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // unobservable (the order of waits is kept, prover.rs:339-354).  Large proofs issue the multiexps first, so the
   // GPU is busy while the host stages a/b/c; small proofs (a few launches of latency-bound kernels each) put the h
   // block's dozen kernels at the head of the hardware queues instead of behind ~100 multiexp launches.
-  if (log_m <= 16) { enqueue_h_block(); BH_TRACE("h block enqueued"); issue_seven(); } else { issue_seven(); enqueue_h_block(); }
-  BH_TRACE("7 multiexps + h block issued; n_cons=%zu m=%zu", n_cons, m);
-  check(bh_stream_synchronize(ctx, ps.st));
-  BH_TRACE("h poly done");
-  const double t1 = now_ms();
-  issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
+  // A small proof is bound by the HOST: every job is ~20 kernel launches, ~0.2 ms of API time, and the H multiexp can
+  // only be issued once the h block has run (profiles/r2_call21_mimc_timeline.txt: five jobs issued one after the other,
+  // the last at 0.97 ms of a 1.62 ms GPU span).  So the seven assignment multiexps are enqueued by a helper thread while
+  // this one enqueues the h block, waits for it and issues H.
+  double t1;
+  if (log_m <= 16) {
+    std::exception_ptr helper_error;
+    std::thread helper([&] {
+      try { issue_seven(true); } catch (...) { helper_error = std::current_exception(); }
+    });
+    try {
+      enqueue_h_block();
+      BH_TRACE("h block enqueued");
+      check(bh_stream_synchronize(ctx, ps.st));
+      t1 = now_ms();
+      issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
+    } catch (...) {
+      helper.join();
+      throw;
+    }
+    helper.join();
+    if (helper_error) std::rethrow_exception(helper_error);
+  } else {
+    issue_seven(false);
+    enqueue_h_block();
+    BH_TRACE("7 multiexps + h block issued; n_cons=%zu m=%zu", n_cons, m);
+    check(bh_stream_synchronize(ctx, ps.st));
+    BH_TRACE("h poly done");
+    t1 = now_ms();
+    issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
+  }
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);
   if (while_running) (*while_running)();

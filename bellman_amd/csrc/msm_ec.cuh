@@ -575,7 +575,20 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // the owner lane of a run folds at most `walk` following chunks itself; longer runs are queued for
   // msm_merge_runs_kernel (G workers per run), the longest of those for the workgroup kernel
   const u32 walk = 4;
-  const u32 run_lanes = 8;   // G: 8-16 chunk runs become 1-2 serial additions + 3 tree levels
+  // G workers per queued run: 8-16 chunk runs become 1-2 serial additions + 3 tree levels; when the AVERAGE run is
+  // much longer than that (window tables over tiny vectors: 32 n entries in 128 buckets, chunks of 8) more workers
+  // shorten the chain as long as the launch still fits the chip
+  u32 run_lanes = 8;
+  {
+    const double avg_chunks = (double)p.n / (double)p.nb / (double)p.chunk;   // per window: n sorted entries, nb buckets
+    double best_cost = 1e30;
+    for (u32 g = 8, lg = 3; g <= tree_per_wave<FR>(); g <<= 1, lg++) {
+      const double steps = std::ceil(std::max(1.0, avg_chunks) / g) + lg;
+      const double waves = (double)p.NB * g / (double)tree_per_wave<FR>();
+      const double cost = steps * std::max(1.0, waves / ((double)c.num_cus * 4));
+      if (cost < best_cost) { best_cost = cost; run_lanes = g; }
+    }
+  }
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
   const u32 max_big = (u32)(nslots / (BIG_RUN_CHUNKS + 1) + 1);
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
