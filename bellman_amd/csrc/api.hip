@@ -34,6 +34,7 @@ void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
 int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
                     u32 *zstart_out);
 void host_point_mul(int group, void *r, const void *a, const void *k);
+void host_point_lincomb(int group, void *r, const void *pts, const void *scalars, u64 n);
 void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n);
 void devhdr_point_mul(int group, void *r, const void *a, const void *k);
 
@@ -812,5 +813,8 @@ void bh_test_fr_inv_host(void *r, const void *a, size_t n) {
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { devhdr_point_add(group, r, a, b, n); }
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { devhdr_point_mul(group, r, a, k); }
 void bh_point_mul(int group, void *r, const void *a, const void *k_canonical) { host_point_mul(group, r, a, k_canonical); }
+void bh_point_lincomb(int group, void *r, const void *points, const void *scalars_canonical, size_t n) {
+  host_point_lincomb(group, r, points, scalars_canonical, n);
+}
 
 }  // extern "C"

@@ -333,21 +333,28 @@ static ProofBlinding blind_terms(const Parameters &params, const Fr &r, const Fr
 }
 // prover.rs:339-360: fold the multiexp results in
 static Proof finish_proof(const ProofBlinding &b, const MsmSums &m, const Fr &r, const Fr &s) {
-  G1Affine g_a = b.g_a, g_c = b.g_c;
-  G2Affine g_b = b.g_b;
-  G1Affine a_answer = add_pts(BH_G1, m.a_in, m.a_aux);                          // :339-343
-  g_a = add_pts(BH_G1, g_a, a_answer);
-  a_answer = mul_pt(BH_G1, a_answer, s);
-  g_c = add_pts(BH_G1, g_c, a_answer);
-  G1Affine b1_answer = add_pts(BH_G1, m.b1_in, m.b1_aux);                       // :345-354
-  G2Affine b2_answer = add_pts(BH_G2, m.b2_in, m.b2_aux);
-  g_b = add_pts(BH_G2, g_b, b2_answer);
-  b1_answer = mul_pt(BH_G1, b1_answer, r);
-  g_c = add_pts(BH_G1, g_c, b1_answer);
-  g_c = add_pts(BH_G1, g_c, m.h);
-  g_c = add_pts(BH_G1, g_c, m.l);
+  // g_a = blind + a_answer; g_b = blind + b_g2_answer; g_c = blind + [s] a_answer + [r] b_g1_answer + h + l with
+  // a_answer = a_inputs + a_aux etc. - each as ONE host linear combination (shared doubling chain, one inversion)
+  const uint64_t one[4] = {1, 0, 0, 0};
+  uint64_t rc[4], sc[4];
+  r.to_canonical(rc);
+  s.to_canonical(sc);
   Proof p;
-  p.a = g_a; p.b = g_b; p.c = g_c;
+  {
+    const G1Affine pts[3] = {b.g_a, m.a_in, m.a_aux};                                              // :339-343
+    bh_point_lincomb(BH_G1, &p.a, pts, nullptr, 3);
+  }
+  {
+    const G2Affine pts[3] = {b.g_b, m.b2_in, m.b2_aux};                                            // :347-350
+    bh_point_lincomb(BH_G2, &p.b, pts, nullptr, 3);
+  }
+  {
+    const G1Affine pts[7] = {b.g_c, m.a_in, m.a_aux, m.b1_in, m.b1_aux, m.h, m.l};                 // :342, 351-354
+    uint64_t ks[7][4];
+    const uint64_t *src[7] = {one, sc, sc, rc, rc, one, one};
+    for (int i = 0; i < 7; i++) memcpy(ks[i], src[i], 32);
+    bh_point_lincomb(BH_G1, &p.c, pts, ks, 7);
+  }
   return p;
 }
 Proof assemble_proof(const Parameters &params, const MsmSums &m, const Fr &r, const Fr &s) {
@@ -364,14 +371,22 @@ void MsmSums::add(const MsmSums &o) {
 static Proof prove_core(const AssignmentSource &src, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   const double t0 = now_ms();
   MsmSums sums;
-  // the five scalar multiplications that involve only the verifying key, r and s (prover.rs:326-338) run on the
-  // host while the multiexps run on the GPU; a failure there (identity delta) is reported after the jobs drain
+  // the five scalar multiplications that involve only the verifying key, r and s (prover.rs:326-338; ~0.9 ms of host
+  // arithmetic) run on their own host thread from the start, beside the enqueueing of the multiexps and the GPU
+  // work: for a small proof they are as long as everything else together.  A failure there (identity delta) is
+  // reported after the jobs drain.
   ProofBlinding blind;
   std::exception_ptr blind_err;
-  const std::function<void()> overlap = [&] {
+  std::thread blind_thread([&] {
     try { blind = blind_terms(params, r, s); } catch (...) { blind_err = std::current_exception(); }
-  };
-  msm_sums(src, params, 0, 1, sums, tm, &overlap);
+  });
+  try {
+    msm_sums(src, params, 0, 1, sums, tm, nullptr);
+  } catch (...) {
+    blind_thread.join();
+    throw;
+  }
+  blind_thread.join();
   if (blind_err) std::rethrow_exception(blind_err);
   Proof p = finish_proof(blind, sums, r, s);
   if (tm) tm->total_ms = (float)(now_ms() - t0);

@@ -144,6 +144,9 @@ void host_point_add(int group, void *r, const void *a, const void *b, u64 n) {
 void host_point_mul(int group, void *r, const void *a, const void *k) {
   if (group == BH_G1) host_point_mul_g1(r, a, k); else host_point_mul_g2(r, a, k);
 }
+void host_point_lincomb(int group, void *r, const void *pts, const void *scalars, u64 n) {
+  if (group == BH_G1) host_point_lincomb_g1(r, pts, scalars, n); else host_point_lincomb_g2(r, pts, scalars, n);
+}
 void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n) {
   if (group == BH_G1) devhdr_point_add_g1(r, a, b, n); else devhdr_point_add_g2(r, a, b, n);
 }

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 #include <array>
 #include <cmath>
 
@@ -943,7 +944,67 @@ static void windowed_point_mul(void *r, const void *a, const u32 *k) {
   xyzz_to_affine(res, acc);
   memcpy(r, &res, sizeof res);
 }
+// sum_i [k_i] P_i on the host with ONE doubling chain (Straus, signed 4-bit windows per term) and one final inversion:
+// the tail of create_proof folds g_c = ... + [s] a_answer + [r] b1_answer + h + l (prover.rs:339-354) - as separate
+// scalar multiplications and affine additions that was two doubling chains and nine inversions.  Scalars equal to one
+// cost a single addition.
+template <class F>
+static void point_lincomb(void *r, const void *pts, const u32 *scalars, u64 n) {
+  struct Term {
+    XYZZ<F> tab[8];
+    int digits[65];
+  };
+  std::vector<Term> terms;
+  std::vector<Affine<F>> ones;
+  terms.reserve(n);
+  for (u64 i = 0; i < n; i++) {
+    Affine<F> base;
+    memcpy(&base, (const char *)pts + i * sizeof base, sizeof base);
+    u32 kw[9];
+    if (scalars) memcpy(kw, scalars + 8 * i, 32); else { memset(kw, 0, 32); kw[0] = 1; }
+    kw[8] = 0;
+    bool zero = true, one = kw[0] == 1;
+    for (int j = 0; j < 8; j++) { zero &= kw[j] == 0; if (j) one &= kw[j] == 0; }
+    if (aff_is_identity(base) || zero) continue;
+    if (one) { ones.push_back(base); continue; }
+    terms.emplace_back();
+    Term &t = terms.back();
+    xyzz_from_affine(t.tab[0], base);
+    xyzz_dbl(t.tab[1], t.tab[0]);
+    for (int j = 2; j < 8; j++) xyzz_add(t.tab[j], t.tab[j - 1], t.tab[0]);
+    u32 carry = 0;
+    for (int j = 0; j < 65; j++) {
+      u32 v = (j < 64 ? (kw[j >> 3] >> ((j & 7) * 4)) & 15u : 0u) + carry;
+      carry = 0;
+      int d = (int)v;
+      if (v > 8) { d = (int)v - 16; carry = 1; }
+      t.digits[j] = d;
+    }
+  }
+  XYZZ<F> acc, tmp;
+  xyzz_set_identity(acc);
+  if (!terms.empty()) {
+    for (int j = 64; j >= 0; j--) {
+      if (!xyzz_is_identity(acc)) for (int b = 0; b < 4; b++) { xyzz_dbl(tmp, acc); acc = tmp; }
+      for (Term &t : terms) {
+        const int d = t.digits[j];
+        if (!d) continue;
+        XYZZ<F> q = t.tab[(d < 0 ? -d : d) - 1];
+        if (d < 0) F::neg(q.y, q.y);
+        xyzz_add(tmp, acc, q);
+        acc = tmp;
+      }
+    }
+  }
+  for (const Affine<F> &b : ones) xyzz_madd(acc, b);
+  Affine<F> res;
+  xyzz_to_affine(res, acc);
+  memcpy(r, &res, sizeof res);
+}
 // fast path: 64-bit-limb host arithmetic
+template <class FD> static void host_point_lincomb_t(void *r, const void *pts, const u32 *scalars, u64 n) {
+  point_lincomb<typename HostOf<FD>::type>(r, pts, scalars, n);
+}
 template <class FD> static void host_point_add_t(void *r, const void *a, const void *b, u64 n) {
   generic_point_add<typename HostOf<FD>::type>(r, a, b, n);
 }
@@ -998,6 +1059,9 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
   }                                                                                                           \
   void host_point_mul_##SUFFIX(void *r, const void *a, const void *k) {                                       \
     host_point_mul_t<OPS>(r, a, (const u32 *)k);                                                              \
+  }                                                                                                           \
+  void host_point_lincomb_##SUFFIX(void *r, const void *pts, const void *scalars, u64 n) {                    \
+    host_point_lincomb_t<OPS>(r, pts, (const u32 *)scalars, n);                                               \
   }                                                                                                           \
   void devhdr_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n) {                              \
     devhdr_point_add_t<OPS>(r, a, b, n);                                                                      \

@@ -132,6 +132,8 @@ void host_point_add_g1(void *r, const void *a, const void *b, u64 n);
 void host_point_add_g2(void *r, const void *a, const void *b, u64 n);
 void host_point_mul_g1(void *r, const void *a, const void *k);
 void host_point_mul_g2(void *r, const void *a, const void *k);
+void host_point_lincomb_g1(void *r, const void *pts, const void *scalars, u64 n);
+void host_point_lincomb_g2(void *r, const void *pts, const void *scalars, u64 n);
 void devhdr_point_add_g1(void *r, const void *a, const void *b, u64 n);
 void devhdr_point_add_g2(void *r, const void *a, const void *b, u64 n);
 void devhdr_point_mul_g1(void *r, const void *a, const void *k);

@@ -20,7 +20,10 @@ INPUT, AUX = 0, 1
 
 
 def fr_to_mont_array(vals):
-    """ints in [0,q) -> [n,4] uint64 Montgomery limbs (the bytes of bls12_381::Scalar)."""
+    """ints in [0,q) -> [n,4] uint64 Montgomery limbs (the bytes of bls12_381::Scalar).  An [n,4] uint64 array is
+    taken as already converted (callers that prove many times convert their constants once)."""
+    if isinstance(vals, np.ndarray) and vals.dtype == np.uint64 and vals.ndim == 2 and vals.shape[1] == 4:
+        return np.ascontiguousarray(vals)
     out = np.zeros((len(vals), 4), dtype=np.uint64)
     for i, v in enumerate(vals):
         m = (v % Q) * _R % Q
@@ -285,8 +288,9 @@ def create_random_proof(circuit, params, rng=None, r1cs=None):
 def create_proof_demo(params, kind, size, seed, witness, constants, r, s, timings=None):
     """create_proof on one of the C++ demo circuits (groth16_capi.cpp): 0 = MiMCDemo, 1 = chain."""
     lib = _lib.load()
-    wit = fr_to_mont_array(list(witness))
-    con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+    wit = fr_to_mont_array(witness if isinstance(witness, np.ndarray) else list(witness))
+    con = fr_to_mont_array(constants if isinstance(constants, np.ndarray) else list(constants)) if constants is not None \
+        else np.zeros((1, 4), dtype=np.uint64)
     rs = fr_to_mont_array([r, s])
     out = np.zeros(48, dtype=np.uint64)
     tm = (ctypes.c_float * 4)()
@@ -483,8 +487,9 @@ def create_proof_r1cs(circuit, r1cs, params, r, s, timings=None):
 
 def create_proof_demo_r1cs(params, r1cs, kind, size, seed, witness, constants, r, s, timings=None):
     lib = _lib.load()
-    wit = fr_to_mont_array(list(witness))
-    con = fr_to_mont_array(list(constants)) if constants is not None else np.zeros((1, 4), dtype=np.uint64)
+    wit = fr_to_mont_array(witness if isinstance(witness, np.ndarray) else list(witness))
+    con = fr_to_mont_array(constants if isinstance(constants, np.ndarray) else list(constants)) if constants is not None \
+        else np.zeros((1, 4), dtype=np.uint64)
     rs = fr_to_mont_array([r, s])
     out = np.zeros(48, dtype=np.uint64)
     tm = (ctypes.c_float * 4)()

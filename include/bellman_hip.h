@@ -182,6 +182,10 @@ void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);
 /* r = [k] a on the HOST, k = 32-byte canonical little-endian scalar: the five single scalar
  * multiplications of create_proof (groth16/src/prover.rs:326-338, 342, 351) */
 void bh_point_mul(int group, void *r, const void *a, const void *k_canonical);
+/* r = sum_i [k_i] points[i] on the HOST (n affine records, n x 32-byte canonical scalars; scalars = NULL: all ones) with
+ * one shared doubling chain and one inversion: g_c = ... + [s] a_answer + [r] b1_answer + h + l of create_proof
+ * (groth16/src/prover.rs:339-354) in one call */
+void bh_point_lincomb(int group, void *r, const void *points, const void *scalars_canonical, size_t n);
 /* Per-job plan overrides (experiments, tests, tuning sweeps): NULL or all-zero = the tuned defaults.
  * They travel with the job, so concurrent jobs on one context never see each other's settings.  The
  * result is the same group element whatever the plan. */

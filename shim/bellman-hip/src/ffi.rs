@@ -111,6 +111,7 @@ extern "C" {
     pub fn bh_msm_wait_profile(job: *mut BhMsmJob, out_affine: *mut c_void, stage_ms4: *mut f32) -> c_int;
     pub fn bh_point_add(group: c_int, r: *mut c_void, a: *const c_void, b: *const c_void, n: usize);
     pub fn bh_point_mul(group: c_int, r: *mut c_void, a: *const c_void, k_canonical: *const c_void);
+    pub fn bh_point_lincomb(group: c_int, r: *mut c_void, points: *const c_void, scalars_canonical: *const c_void, n: usize);
     pub fn bh_msm_async_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_host: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
     pub fn bh_msm_async_dev_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_dev: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words_dev: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
     pub fn bh_fixed_base_mul_dev(ctx: *mut BhCtx, group: c_int, base_affine_host: *const c_void, scalars_dev: *const c_void, n: usize, scalar_fmt: c_int, out_dev: *mut c_void, stream: *mut c_void) -> c_int;

@@ -145,6 +145,34 @@ def test_fast_host_group_ops_match_oracle(lib, group):
         assert np.array_equal(o, cref.point_mul(group, A[5], k))
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_host_linear_combination_matches_oracle(lib, group):
+    """bh_point_lincomb (the tail of create_proof, prover.rs:339-354, in one shared doubling chain): every kind of term -
+    scalar 0, 1, small, q - 1, random; an identity point; P and -P cancelling; all-ones (scalars = NULL); empty."""
+    w = 12 if group == 1 else 24
+    rnd = random.Random(77 + group)
+    P = cref.gen_bases(group, 9, a=21, b=6)
+    P[6] = 0                                            # the identity as a term
+    P[8] = cref.point_mul(group, P[7], bls.Q - 1)       # -P[7]
+    ks = [0, 1, 5, bls.Q - 1, rnd.randrange(bls.Q), rnd.randrange(bls.Q), rnd.randrange(bls.Q), 9, 9]
+    ka = np.array([cref.int_to_limbs(k, 4) for k in ks], dtype=np.uint64)
+    want = np.zeros(w, dtype=np.uint64)
+    for i, k in enumerate(ks):
+        want = cref.point_add(group, want, cref.point_mul(group, P[i], k))
+    out = np.ones(w, dtype=np.uint64)
+    lib.bh_point_lincomb(group, _p(out), _p(P), _p(ka), len(ks))
+    assert np.array_equal(out, want)
+    plain = np.zeros(w, dtype=np.uint64)
+    for i in range(len(ks)):
+        plain = cref.point_add(group, plain, P[i])
+    lib.bh_point_lincomb(group, _p(out), _p(P), None, len(ks))
+    assert np.array_equal(out, plain)
+    lib.bh_point_lincomb(group, _p(out), _p(P), _p(ka), 0)
+    assert not out.any()
+    lib.bh_point_lincomb(group, _p(out), _p(P[7:9]), _p(ka[7:9]), 2)   # 9 P - 9 P
+    assert not out.any()
+
+
 def test_host_group_ops_accept_unaligned_buffers(lib):
     """Regression (first GPU prover run): caller records are only 8-byte aligned in general."""
     A = cref.gen_bases(1, 2, a=3, b=1)
