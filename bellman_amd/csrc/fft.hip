@@ -42,6 +42,8 @@ constexpr int NTT_PLANE = NTT_TILE + NTT_TILE / 8;   // padded slots per 16-byte
 struct NttPass {
   const fr_t *in;
   fr_t *out;
+  const fr_t *in_y[2];   // blockIdx.y = 1, 2: further vectors transformed by the same launch (single-pass sizes only)
+  fr_t *out_y[2];
   const BTw *master;   // w_2048^(+-i), i < 1024
   const BTw *tw_lo;    // w_n^(+-i), i < 2^lb                 (inter-pass twiddles; null when L == 1)
   const BTw *tw_hi;    // w_n^(+-i * 2^lb)
@@ -196,6 +198,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
   __shared__ uint4 plane1[NTT_PLANE];
   const u32 R = 1u << a.r, C = 1u << a.log_c;
   const u32 tid = threadIdx.x;
+  const fr_t *vin = blockIdx.y == 0 ? a.in : a.in_y[blockIdx.y - 1];
+  fr_t *vout = blockIdx.y == 0 ? a.out : a.out_y[blockIdx.y - 1];
   const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
   const u64 n = (u64)1 << a.log_n;
 
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
       gi[i] = base + row * in_row_stride + col * in_col_stride;
       const u32 rrow = a.r ? (__brev(row) >> (32 - a.r)) : 0;
       slot[i] = (col << a.r) + rrow;
-      if (e < total) v[i] = ld_fr(a.in + gi[i]);
+      if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
     if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
       const BTw *ph[PER], *pl[PER];
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const u32 e = tid + (u32)i * NTT_THREADS;
-      if (e < total) st_fr(a.out + gi[i], v[i]);
+      if (e < total) st_fr(vout + gi[i], v[i]);
     }
   }
 }
@@ -560,7 +564,13 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
 
 // data: device, 2^log_n Montgomery Fr, in place.  scratch: device, same size (ping-pong for the
 // digit-reversing last pass; may be null when log_n <= NTT_MAX_R).
+// `more`: up to two further vectors transformed in place by the same launch - only for single-pass sizes (no scratch
+// vector to share); a small proof's three iFFTs / coset FFTs are one launch each instead of three latency-bound ones
+static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hipStream_t st, fr_t *const *more, u32 n_more);
 int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hipStream_t st) {
+  return ntt_run_batch(c, data, scratch, log_n, mode, st, nullptr, 0);
+}
+static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hipStream_t st, fr_t *const *more, u32 n_more) {
   if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
   const bool inverse = (mode == BH_IFFT || mode == BH_ICOSET_FFT);
   uint32_t r[3] = {0, 0, 0}, L = 1;
@@ -577,6 +587,7 @@ int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hip
     // last pass scratch -> data (digit-reversing scatter)
     a.in = (p == 0) ? data : scratch;
     a.out = (last) ? data : scratch;
+    for (u32 y = 0; y < 2; y++) { a.in_y[y] = y < n_more ? more[y] : nullptr; a.out_y[y] = y < n_more ? more[y] : nullptr; }
     a.master = master;
     a.tw_lo = tab.tw_lo[inverse ? 1 : 0];
     a.tw_hi = tab.tw_hi[inverse ? 1 : 0];
@@ -602,7 +613,8 @@ int ntt_run(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, int mode, hip
     a.log_c = log_c;
     const u64 tiles = ((u64)1 << log_n) >> (r[p] + log_c);
     a.xcd_swizzle = (tiles >= 64 && (tiles & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles), dim3(NTT_THREADS), 0, st, a);
+    if (n_more && L != 1) return BH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
     BH_HIP_CHECK(hipGetLastError());
     s += r[p];
   }
@@ -657,9 +669,14 @@ int fr_gen_powers(Context &c, fr_t *out, u64 n, const fr_t &g, const fr_t &scale
 int h_poly_dev(Context &c, fr_t *a, fr_t *b, fr_t *cc, fr_t *scratch, uint32_t log_n, hipStream_t st) {
   int rc;
   fr_t *v[3] = {a, b, cc};
-  for (int i = 0; i < 3; i++) {
-    if ((rc = ntt_run(c, v[i], scratch, log_n, BH_IFFT, st))) return rc;
-    if ((rc = ntt_run(c, v[i], scratch, log_n, BH_COSET_FFT, st))) return rc;
+  if (log_n <= NTT_MAX_R) {   // single-pass sizes: a, b and c in one launch per transform
+    if ((rc = ntt_run_batch(c, a, scratch, log_n, BH_IFFT, st, v + 1, 2))) return rc;
+    if ((rc = ntt_run_batch(c, a, scratch, log_n, BH_COSET_FFT, st, v + 1, 2))) return rc;
+  } else {
+    for (int i = 0; i < 3; i++) {
+      if ((rc = ntt_run(c, v[i], scratch, log_n, BH_IFFT, st))) return rc;
+      if ((rc = ntt_run(c, v[i], scratch, log_n, BH_COSET_FFT, st))) return rc;
+    }
   }
   u64 n = (u64)1 << log_n;
   fr_t zinv;
