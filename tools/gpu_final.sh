@@ -2,7 +2,7 @@
 # Round-2 final GPU run: the whole -m gpu suite, smoke, bench.py (default flags), and the rocprofv3 evidence that
 # DESIGN.md / bench.py cite (kernel stats of the timed-steps-only bench command, PMC passes of the dominant kernel)
 cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r2final3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2final4
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
