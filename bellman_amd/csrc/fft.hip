@@ -318,8 +318,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
       gi[i] = g;
       u32 ex = 0;
       if (live) ex = !a.is_last ? (u32)((((u64)(jp0 + col) * row) << a.s) & n_mask) : (u32)g;
-      ph[i] = hi_tab + (ex >> a.lb);
-      pl[i] = lo_tab + (ex & lb_mask);
+      ph[i] = hi_tab ? hi_tab + (ex >> a.lb) : nullptr;   // no table: plain fft / the 1/n of ifft below
+      pl[i] = lo_tab ? lo_tab + (ex & lb_mask) : nullptr;
     }
     if (hi_tab) {
       TwReg cur = tw_load(ph[0]);
