@@ -38,17 +38,19 @@ def test_bench_single_gpu_contract_small():
     assert "workload" in out["config"] and "model" not in out["config"]
 
 
-def test_bench_two_ranks_on_one_gpu_gloo():
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_ranks_on_one_gpu_gloo(ranks):
+    """2 ranks, and the 8 ranks of the driver's full-node run (rank-count-dependent splits of the C5 legs)"""
     env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "12",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29517 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--log-n", "12",
            "--proof-log-n", "10", "--c5-log-n", "13", "--check-log-n", "10"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = _last_json_line(r.stdout)
     for k in CONTRACT_KEYS:
         assert k in out, k
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["value"] > 0
     # the parity assertions of the N > 1 legs ran (they raise inside bench.py otherwise)
     assert "== one multiexp" in out["sharded_fold_check"]
     assert out["create_proof_sharded"]["scaling"] == "strong" and "identical to the single-GPU proof" in out["create_proof_sharded"]["workload"]
