@@ -85,7 +85,8 @@ def soak_proofs(w):
         w.synchronize()
         marks.append(round(free_mb()))
     print("free MiB after each proof cycle:", marks, "elapsed %.1fs" % (time.time() - t0))
-    assert marks[-1] >= marks[2] - 64, "device memory keeps shrinking"
+    # the pools reach their steady state after a few cycles (how many depends on how many jobs really overlap)
+    assert marks[-1] >= marks[len(marks) // 2] - 16, "device memory keeps shrinking"
     print("soak ok (proof path)")
     before = free_mb()
     w.trim()
