@@ -56,7 +56,7 @@ def soak_proofs(w):
     marks = []
     t0 = time.time()
     ref = {}
-    for cycle in range(12):
+    for cycle in range(int(os.environ.get("SOAK_CYCLES", "12"))):
         r1cs = pg.R1CS.from_demo(w, 1, rounds, seed)
         params = pg.Parameters.generate(w, r1cs, G1_GEN_MONT, G2_GEN_MONT, 48577, 22580, 53332, 5481, 3673)
         if cycle % 3 == 0:   # through the serialized form as well
