@@ -174,10 +174,19 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
   __syncthreads();
   const u64 *src = pairs_in + (u64)w * n;
   const u64 lt_mask = ((u64)1 << lane) - 1;
+  // all of the thread's keys are loaded before the ranking rounds: one exposed memory latency per tile instead of one
+  // per round (the rounds themselves are ballots, LDS and barriers)
+  u64 keys[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; r++) {
+    const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
+    keys[r] = idx < n ? src[idx] : 0;
+  }
+#pragma unroll
   for (int r = 0; r < SORT_ROUNDS; r++) {
     const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
     const bool valid = idx < n;
-    u64 key = valid ? src[idx] : 0;
+    const u64 key = keys[r];
     const u32 bin = (u32)(key >> shift) & 0xff;
     // wavefront match-any over the 8-bit bin: lanes with equal bins
     u64 mask = __ballot(valid);
