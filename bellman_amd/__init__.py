@@ -18,5 +18,5 @@ from .errors import (  # noqa: F401
     UnexpectedIdentity,
 )
 from .multicore import Waiter, Worker  # noqa: F401
-from .multiexp import Bases, DensityTracker, FullDensity, multiexp, point_add  # noqa: F401
+from .multiexp import Bases, DensityTracker, FullDensity, Scalars, multiexp, multiexp_scalars, multiexp_sharded, point_add  # noqa: F401
 from .domain import EvaluationDomain  # noqa: F401

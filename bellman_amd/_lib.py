@@ -14,13 +14,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
 
 # every symbol include/bellman_hip.h declares, then the test hooks of include/bellman_hip_test.h
 EXPORTS = [
-    "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus",
+    "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus", "bh_runtime_configure", "bh_ctx_set_limits", "bh_ctx_info",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
     "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_trim",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
+    "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars",
+    "bh_msm_sharded_async", "bh_msm_sharded_wait",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
     "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev", "bh_r1cs_eval_transposed_dev", "bh_fr_powers_dev", "bh_fr_qap_ext_dev",
@@ -28,6 +30,7 @@ EXPORTS = [
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
+    "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class",
 ]
 
 
@@ -52,6 +55,7 @@ def load():
     # environment before the process' first HIP call
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.bh_runtime_configure()   # records that the request was made before this library's first HIP call
     c = ctypes
     vp, sz, u32, i32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_int
     lib.bh_version.restype = c.c_char_p
@@ -72,6 +76,11 @@ def load():
     lib.bh_dev_zero_on.argtypes = [vp, vp, sz, vp]
     lib.bh_ctx_synchronize.argtypes = [vp]
     lib.bh_ctx_trim.argtypes = [vp]
+    lib.bh_test_groth16_prove_via_call_sites.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    lib.bh_test_demo_assignment.argtypes = [i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.bh_test_shard_cuts.argtypes = [vp, sz, sz, vp, sz, vp]
+    lib.bh_test_pool_size_class.argtypes = [sz]
+    lib.bh_test_pool_size_class.restype = sz
     lib.bh_test_fp_lazy_host.argtypes = [i32, vp, vp, vp]
     lib.bh_test_msm_plan.argtypes = [sz, i32, c.c_uint, vp]
     lib.bh_test_proof_slice.argtypes = [sz, sz, sz, c.POINTER(sz), c.POINTER(sz)]
@@ -108,6 +117,21 @@ def load():
     lib.bh_msm_async_opts.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, c.POINTER(vp)]
     lib.bh_msm_async_dev_opts.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, c.POINTER(vp)]
     lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
+    lib.bh_runtime_configure.argtypes = []
+    lib.bh_ctx_set_limits.argtypes = [vp, u32, sz, sz]
+    lib.bh_ctx_info.argtypes = [vp, vp]
+    lib.bh_scalars_register.argtypes = [vp, vp, sz, i32, c.POINTER(vp)]
+    lib.bh_scalars_adopt_dev.argtypes = [vp, vp, sz, i32, i32, c.POINTER(vp)]
+    lib.bh_scalars_release.argtypes = [vp]
+    lib.bh_scalars_release.restype = None
+    lib.bh_scalars_len.argtypes = [vp]
+    lib.bh_scalars_len.restype = sz
+    lib.bh_scalars_dev_ptr.argtypes = [vp]
+    lib.bh_scalars_dev_ptr.restype = vp
+    lib.bh_msm_async_scalars.argtypes = [vp, vp, sz, vp, sz, sz, vp, sz, vp, c.POINTER(vp)]
+    lib.bh_h_poly_fr_scalars.argtypes = [vp, vp, vp, vp, sz, c.POINTER(vp)]
+    lib.bh_msm_sharded_async.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, sz, c.POINTER(vp)]
+    lib.bh_msm_sharded_wait.argtypes = [vp, vp]
     lib.bh_groth16_params_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, c.POINTER(vp)]
     lib.bh_groth16_params_release.argtypes = [vp]
     lib.bh_groth16_params_read.argtypes = [vp, vp, sz, i32, c.POINTER(vp)]

@@ -2,6 +2,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <memory>
+#include <thread>
+
 #include "../../include/bellman_hip_test.h"
 #include "common.hpp"
 #include "msm_types.hpp"
@@ -22,6 +26,9 @@ void msm_job_delete(MsmJobImpl *j);
 int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
                     int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
+void msm_job_track(MsmJobImpl &job);
+bool msm_complete_oldest(Context &c);
+size_t msm_jobs_in_flight(Context &c);
 hipStream_t msm_job_stream(MsmJobImpl &job);
 void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
@@ -123,6 +130,16 @@ struct bh_bases {
   // optional window table (bh_bases_precompute): [W][n] affine records, row 0 = a copy of the bases
   void *table = nullptr;
   WindowTable tab = {0, 0, 0};
+  bool auto_table = false;   // built at registration under the context's table budget; bh_ctx_trim may drop it
+  bh_ctx *ctx = nullptr;
+};
+// a scalar vector resident in HBM (bh_scalars_*): create_proof hands the same assignment to up to four multiexps
+struct bh_scalars {
+  bh_ctx *ctx;
+  void *dev;
+  size_t n;
+  int fmt;
+  bool pooled;   // dev came from the context's pool (else: adopted from the caller, not freed)
 };
 struct bh_msm_job {
   MsmJobImpl *impl;
@@ -165,16 +182,47 @@ static unsigned auto_table_max_log2(int group) {
   }();
   return v >= 0 ? (unsigned)v : (group == BH_G1 ? 16u : 22u);
 }
+static size_t table_bytes_for(const bh_bases *b, unsigned c) {
+  const u32 W = (256 + c - 1) / c;
+  return (size_t)W * b->n * (b->group == BH_G1 ? 96 : 192);
+}
 static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
   bh_bases *b = new bh_bases{group, dev, n, owned};
+  b->ctx = ctx;
+  // A wrapped (non-owned) buffer is a LIVE view: the caller may fill or rewrite it after wrapping, on any stream.
+  // Nothing is snapshotted from it - no host mirror of the leading records (tiny multiexps take the kernel
+  // pipeline), no automatic window table - so every multiexp reads the buffer as it is when the job runs.
+  // (bh_bases_precompute on such a handle is an explicit snapshot, documented in the header.)
+  if (!owned) { *out = b; return BH_OK; }
   int rc = finish_bases(ctx, b);
   if (rc != BH_OK) {
-    if (owned && dev) (void)hipFree(dev);
+    if (dev) (void)hipFree(dev);
     delete b;
     return rc;
   }
+  // automatic window table: only while all automatic tables of the context stay within its budget (default a
+  // quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB / bh_ctx_set_limits): a table is 13-32 x its base
+  // vector (2^22 G2 points: 12.9 GB) and must not starve the per-proof workspaces
   const unsigned lg = auto_table_max_log2(group);
-  if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) (void)bh_bases_precompute(ctx, b, 0);   // best effort
+  if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) {
+    const size_t need = table_bytes_for(b, table_window_bits(n, group == BH_G2));
+    bool fits;
+    {
+      std::lock_guard<std::mutex> g(ctx->c.job_mu);
+      fits = ctx->c.table_bytes + need <= ctx->c.table_budget;
+      if (fits) ctx->c.table_bytes += need;   // reserved
+    }
+    if (fits) {
+      if (bh_bases_precompute(ctx, b, 0) == BH_OK) {   // best effort
+        b->auto_table = true;
+        std::lock_guard<std::mutex> g(ctx->c.job_mu);
+        ctx->c.tables.push_back(b);
+      } else {
+        std::lock_guard<std::mutex> g(ctx->c.job_mu);
+        ctx->c.table_bytes -= need;
+      }
+    }
+  }
   *out = b;
   return BH_OK;
 }
@@ -188,20 +236,82 @@ const char *bh_version(void) { return "bellman_hip 0.1 (gfx950)"; }
 // A proof keeps 6-7 job streams in flight (one per multiexp + the h block); the HIP runtime multiplexes streams onto
 // GPU_MAX_HW_QUEUES hardware queues, 4 by default, and jobs that share a queue run one after the other (MiMC-322
 // proof 2.99 ms with 4 queues, 2.23 ms with 16; 12 concurrent 2^20 proofs 33.1 -> 36.2 /s:
-// profiles/r2_call12_hw_queues.txt).  The runtime reads the variable when it initialises, so this only takes effect
-// if the library is loaded before the process makes its first HIP call; a value set by the user wins.
-__attribute__((constructor)) static void bh_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// profiles/r2_call12_hw_queues.txt).  The runtime reads the variable when it initialises, so the host program calls
+// bh_runtime_configure() before its first HIP call (the Python loader and bench.py set the variable themselves); the
+// library no longer touches the environment behind the caller's back when it is loaded.
+static std::atomic<bool> g_hip_touched{false};      // this library has made a HIP call
+static std::atomic<bool> g_configured_early{false};
+int bh_runtime_configure(void) {
+  const bool early = !g_hip_touched.load();
+  const char *cur = getenv("GPU_MAX_HW_QUEUES");
+  if (!cur || !*cur) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  if (early) g_configured_early.store(true);
+  return early ? 1 : 0;
+}
 
 int bh_ctx_create(int device, bh_ctx **out) {
   int count = 0;
+  const char *q = getenv("GPU_MAX_HW_QUEUES");
+  const int queues_env = (q && *q) ? atoi(q) : 0;
+  const bool early = g_configured_early.load() || (!g_hip_touched.load() && queues_env > 0);
+  g_hip_touched.store(true);
   if (hipGetDeviceCount(&count) != hipSuccess || count <= device || device < 0) return BH_ERR_NO_DEVICE;
   BH_HIP_CHECK(hipSetDevice(device));
   bh_ctx *ctx = new bh_ctx();
   ctx->c.device = device;
+  ctx->c.hw_queues_env = queues_env;
+  ctx->c.configured_early = early;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->c.num_cus = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    ctx->c.num_cus = prop.multiProcessorCount;
+    ctx->c.hbm_total = prop.totalGlobalMem;
+  }
+  // jobs in flight per context: a 2^20-term multiexp holds ~0.6 GB of workspace - by default as many as fit a
+  // quarter of the device's memory at that size, at least 8 (create_proof issues 8, prover.rs:244-318)
+  {
+    const char *e = getenv("BELLMAN_HIP_MAX_JOBS");
+    long v = e && *e ? strtol(e, nullptr, 10) : 0;
+    if (v <= 0) v = (long)(ctx->c.hbm_total / 4 / (size_t(640) << 20));
+    ctx->c.max_jobs = (uint32_t)(v < 8 ? 8 : v > 4096 ? 4096 : v);
+  }
+  {
+    const char *e = getenv("BELLMAN_HIP_TABLE_BUDGET_MB");
+    ctx->c.table_budget = (e && *e) ? (size_t)strtoull(e, nullptr, 10) << 20 : ctx->c.hbm_total / 4;
+  }
+  {
+    const char *e = getenv("BELLMAN_HIP_POOL_CAP_MB");
+    if (e && *e) ctx->c.pool.set_cap((size_t)strtoull(e, nullptr, 10) << 20);
+  }
+  Context *cp = &ctx->c;
+  ctx->c.pool.set_pressure_handler([cp] { return msm_complete_oldest(*cp); });
   BH_HIP_CHECK(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
   *out = ctx;
+  return BH_OK;
+}
+int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes) {
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  if (max_jobs_in_flight) ctx->c.max_jobs = max_jobs_in_flight;
+  if (pool_cap_bytes != (size_t)-1) ctx->c.pool.set_cap(pool_cap_bytes);
+  if (table_budget_bytes != (size_t)-1) { std::lock_guard<std::mutex> g(ctx->c.job_mu); ctx->c.table_budget = table_budget_bytes; }
+  return BH_OK;
+}
+int bh_ctx_info(bh_ctx *ctx, bh_ctx_info_t *info) {
+  if (!ctx || !info) return BH_ERR_INVALID_ARG;
+  memset(info, 0, sizeof *info);
+  info->device = ctx->c.device;
+  info->num_cus = (uint32_t)ctx->c.num_cus;
+  info->hbm_bytes = ctx->c.hbm_total;
+  info->hw_queues_requested = (uint32_t)ctx->c.hw_queues_env;
+  info->hw_queues_set_before_hip_init = ctx->c.configured_early ? 1u : 0u;
+  info->max_jobs_in_flight = ctx->c.max_jobs;
+  info->jobs_in_flight = (uint32_t)msm_jobs_in_flight(ctx->c);
+  info->pool_bytes_held = ctx->c.pool.bytes_held();
+  info->pool_bytes_idle = ctx->c.pool.bytes_idle();
+  {
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    info->table_bytes = ctx->c.table_bytes;
+    info->table_budget = ctx->c.table_budget;
+  }
   return BH_OK;
 }
 int bh_ctx_trim(bh_ctx *ctx) {
@@ -211,6 +321,18 @@ int bh_ctx_trim(bh_ctx *ctx) {
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   BH_HIP_CHECK(hipDeviceSynchronize());
   ctx->c.pool.release_all();
+  {
+    // window tables built automatically at registration are a cache too (the handles stay usable without them;
+    // bh_bases_precompute rebuilds one on request)
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    for (bh_bases *b : ctx->c.tables) {
+      if (b->table) (void)hipFree(b->table);
+      b->table = nullptr;
+      b->auto_table = false;
+    }
+    ctx->c.tables.clear();
+    ctx->c.table_bytes = 0;
+  }
   {
     std::lock_guard<std::mutex> g(ctx->c.fft_mu);
     for (auto &kv : ctx->c.fft_tables) fft_tables_free(kv.second);
@@ -415,6 +537,45 @@ int bh_h_poly_fr(bh_ctx *ctx, const void *a_host, const void *b_host, const void
   return rc;
 }
 
+int bh_h_poly_fr_scalars(bh_ctx *ctx, const void *a_host, const void *b_host, const void *c_host, size_t n_evals,
+                         bh_scalars **h_out) {
+  if (!ctx || !h_out || (n_evals && (!a_host || !b_host || !c_host))) return BH_ERR_INVALID_ARG;
+  uint32_t log_n = 0;
+  size_t m = 1;
+  while (m < n_evals) {   // EvaluationDomain::from_coeffs (domain.rs:47-79)
+    m *= 2;
+    log_n++;
+    if (log_n >= 32) return BH_ERR_DEGREE_TOO_LARGE;
+  }
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  const size_t bytes = sizeof(fr_t) * m, in_bytes = sizeof(fr_t) * n_evals;
+  // the three vectors are staged on three streams so that the copies of b and c overlap the first transforms... the
+  // h block itself is a dependent chain, so: one caller-private stream (concurrent proofs do not serialise on the
+  // context stream)
+  void *stv = nullptr;
+  int rc = bh_stream_create(ctx, &stv);
+  if (rc != BH_OK) return rc;
+  hipStream_t st = (hipStream_t)stv;
+  void *d[3] = {ctx->c.pool.acquire(bytes), ctx->c.pool.acquire(bytes), ctx->c.pool.acquire(bytes)};
+  void *scratch = log_n > 11 ? ctx->c.pool.acquire(bytes) : nullptr;
+  const void *h[3] = {a_host, b_host, c_host};
+  rc = (d[0] && d[1] && d[2] && (log_n <= 11 || scratch)) ? BH_OK : BH_ERR_HIP;
+  for (int i = 0; i < 3 && rc == BH_OK; i++) {
+    if (m > n_evals && hipMemsetAsync((char *)d[i] + in_bytes, 0, bytes - in_bytes, st) != hipSuccess) rc = BH_ERR_HIP;
+    if (rc == BH_OK && in_bytes && hipMemcpyAsync(d[i], h[i], in_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+      rc = BH_ERR_HIP;
+  }
+  if (rc == BH_OK) rc = h_poly_dev(ctx->c, (fr_t *)d[0], (fr_t *)d[1], (fr_t *)d[2], (fr_t *)scratch, log_n, st);
+  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  (void)bh_stream_destroy(ctx, stv);
+  ctx->c.pool.release(d[1]);
+  ctx->c.pool.release(d[2]);
+  ctx->c.pool.release(scratch);
+  if (rc != BH_OK) { ctx->c.pool.release(d[0]); return rc; }
+  *h_out = new bh_scalars{ctx, d[0], m - 1, BH_SCALARS_MONT, true};   // a.len() - 1 coefficients, prover.rs:238-239
+  return BH_OK;
+}
+
 // ---- bases -------------------------------------------------------------------------------------
 int bh_bases_register(bh_ctx *ctx, int group, const void *host_points, size_t n, size_t stride, long inf_offset,
                       bh_bases **out) {
@@ -535,6 +696,15 @@ int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, 
 }
 int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits) {
   if (!ctx || !b) return BH_ERR_INVALID_ARG;
+  if (b->auto_table) {   // replaced by an explicit table: no longer the context's to drop or to count
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    auto &v = ctx->c.tables;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == b) { v.erase(v.begin() + i); break; }
+    const size_t bytes = (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192);
+    ctx->c.table_bytes = ctx->c.table_bytes > bytes ? ctx->c.table_bytes - bytes : 0;
+    b->auto_table = false;
+  }
   if (b->table) { (void)hipFree(b->table); b->table = nullptr; }
   if (b->n == 0) return BH_OK;
   const u32 c = window_bits ? window_bits : table_window_bits(b->n, b->group == BH_G2);
@@ -568,6 +738,14 @@ int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows
 void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
   (void)ctx;
   if (!b) return;
+  if (b->auto_table && b->ctx) {
+    std::lock_guard<std::mutex> g(b->ctx->c.job_mu);
+    auto &v = b->ctx->c.tables;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == b) { v.erase(v.begin() + i); break; }
+    const size_t bytes = (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192);
+    b->ctx->c.table_bytes = b->ctx->c.table_bytes > bytes ? b->ctx->c.table_bytes - bytes : 0;
+  }
   if (b->table) (void)hipFree(b->table);
   if (b->owned && b->dev) (void)hipFree(b->dev);
   delete b;
@@ -640,9 +818,10 @@ static bool tiny_msm_on_host(const bh_bases *bases, size_t skip, const void *sca
 
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      const bh_msm_opts *o, bh_msm_job **out) {
+                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0) {
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
+  if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
   if (o) {
     if (o->window_bits && (o->window_bits < 2 || o->window_bits > 24)) return BH_ERR_INVALID_ARG;
     opts.c = o->window_bits; opts.chunk = o->chunk; opts.flags = o->flags;
@@ -650,9 +829,13 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (fmt != BH_SCALARS_CANONICAL && fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
   if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  // back-pressure (src/multicore.rs:47-73): at the cap the issuing thread completes the oldest job itself
+  while (msm_jobs_in_flight(ctx->c) >= ctx->c.max_jobs)
+    if (!msm_complete_oldest(ctx->c)) break;
   MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);
   if (!impl) return BH_ERR_HIP;
-  if (n && n <= TINY_MSM_MAX && scalars_on_host && (!density || density_on_host) && !(opts.flags & BH_MSM_NO_SMALL_PATH)) {
+  if (n && n <= TINY_MSM_MAX && scalars_on_host && (!density || density_on_host) && !(opts.flags & BH_MSM_NO_SMALL_PATH) &&
+      !shard_ref_n) {
     int trc = BH_OK;
     alignas(16) unsigned char res[192];
     if (tiny_msm_on_host(bases, skip, scalars, n, fmt, density, &trc, res)) {
@@ -694,8 +877,48 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     msm_job_delete(impl);
     return rc;
   }
+  msm_job_track(*impl);
   *out = new bh_msm_job{impl};
   return BH_OK;
+}
+// ---- scalars resident in HBM --------------------------------------------------------------------
+int bh_scalars_register(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, bh_scalars **out) {
+  if (!ctx || !out || (n && !scalars_host)) return BH_ERR_INVALID_ARG;
+  if (scalar_fmt != BH_SCALARS_CANONICAL && scalar_fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  void *d = ctx->c.pool.acquire(n ? n * 32 : 32);
+  if (!d) return BH_ERR_HIP;
+  if (n) {
+    // pageable host memory: the copy is staged by the runtime and the call returns once the source may be reused
+    if (hipMemcpyAsync(d, scalars_host, n * 32, hipMemcpyHostToDevice, ctx->c.stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+      ctx->c.pool.release(d);
+      return BH_ERR_HIP;
+    }
+  }
+  *out = new bh_scalars{ctx, d, n, scalar_fmt, true};
+  return BH_OK;
+}
+int bh_scalars_adopt_dev(bh_ctx *ctx, void *scalars_dev, size_t n, int scalar_fmt, int take_ownership, bh_scalars **out) {
+  if (!ctx || !out || (n && !scalars_dev)) return BH_ERR_INVALID_ARG;
+  if (scalar_fmt != BH_SCALARS_CANONICAL && scalar_fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
+  *out = new bh_scalars{ctx, scalars_dev, n, scalar_fmt, take_ownership != 0};
+  return BH_OK;
+}
+void bh_scalars_release(bh_scalars *s) {
+  if (!s) return;
+  if (s->pooled) s->ctx->c.pool.release(s->dev);   // callers release after the multiexps that read it were waited on
+  delete s;
+}
+size_t bh_scalars_len(const bh_scalars *s) { return s ? s->n : 0; }
+const void *bh_scalars_dev_ptr(const bh_scalars *s) { return s ? s->dev : nullptr; }
+int bh_msm_async_scalars(bh_ctx *ctx, const bh_bases *bases, size_t skip, const bh_scalars *scalars, size_t first,
+                         size_t n, const uint64_t *density_words, size_t density_len, const bh_msm_opts *opts,
+                         bh_msm_job **job) {
+  if (!scalars || scalars->ctx != ctx || first > scalars->n || n > scalars->n - first) return BH_ERR_INVALID_ARG;
+  // scalars on the device, density map on the host (a DensityTracker's words, 2^20 bits = 128 KiB)
+  return msm_common(ctx, bases, skip, (const char *)scalars->dev + first * 32, false, n, scalars->fmt, density_words, true,
+                    density_len, opts, job);
 }
 int bh_msm_async(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host, size_t n, int fmt,
                  const uint64_t *density_words, size_t density_len, bh_msm_job **job) {
@@ -714,6 +937,129 @@ int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const
                           bh_msm_job **job) {
   return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, opts, job);
 }
+// ---- one multiexp over several contexts of this process (one per GPU) -----------------------------
+struct bh_msm_sharded_job {
+  int group;
+  std::vector<bh_msm_job *> jobs;                 // one per shard, in shard order
+  std::vector<std::vector<uint64_t>> density;     // per-shard density words (re-based to bit 0), alive until the wait
+};
+// index of the t-th (0-based) set bit of an LSB0 bitmap of n bits; n when there are not that many
+static size_t select_bit(const uint64_t *words, size_t n, size_t t) {
+  const size_t nw = (n + 63) / 64;
+  for (size_t w = 0; w < nw; w++) {
+    uint64_t x = words[w];
+    if (w == nw - 1 && (n & 63)) x &= (((uint64_t)1 << (n & 63)) - 1);
+    const size_t pc = (size_t)__builtin_popcountll(x);
+    if (t < pc) {
+      for (;; x &= x - 1, t--)
+        if (t == 0) return w * 64 + (size_t)__builtin_ctzll(x);
+    }
+    t -= pc;
+  }
+  return n;
+}
+// scalar index at which shard k starts (cut[k]) and the shard's first base index (off[k]): shard k computes the
+// scalars [cut[k], cut[k+1]) - the dense entries whose base index skip + rank falls into [off[k], off[k+1]) plus the
+// non-dense entries between them; the last shard takes everything left (it is the one that can run out of bases)
+static void shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
+                       std::vector<size_t> &cut, std::vector<size_t> &off) {
+  cut.assign(n_shards + 1, 0);
+  off.assign(n_shards + 1, 0);
+  for (size_t k = 0; k < n_shards; k++) off[k + 1] = off[k] + lens[k];
+  for (size_t k = 1; k < n_shards; k++) {
+    if (off[k] <= skip) { cut[k] = 0; continue; }
+    const size_t t = off[k] - skip;   // dense entries that precede the shard
+    cut[k] = density_words ? select_bit(density_words, n_scalars, t) : (t < n_scalars ? t : n_scalars);
+  }
+  cut[n_shards] = n_scalars;
+}
+int bh_test_shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
+                       size_t *cuts_out) {
+  if (!lens || !n_shards || !cuts_out) return BH_ERR_INVALID_ARG;
+  std::vector<size_t> cut, off;
+  shard_cuts(lens, n_shards, skip, density_words, n_scalars, cut, off);
+  memcpy(cuts_out, cut.data(), (n_shards + 1) * sizeof(size_t));
+  return BH_OK;
+}
+size_t bh_test_pool_size_class(size_t bytes) { return DevicePool::size_class(bytes); }
+int bh_msm_sharded_async(bh_ctx *const *ctxs, const bh_bases *const *shards, size_t n_shards, size_t skip,
+                         const void *scalars_host, size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
+                         size_t density_len, bh_msm_sharded_job **out) {
+  if (!ctxs || !shards || !n_shards || !out || (n_scalars && !scalars_host)) return BH_ERR_INVALID_ARG;
+  if (density_words && density_len != n_scalars) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329
+  const int group = shards[0]->group;
+  for (size_t k = 0; k < n_shards; k++)
+    if (!ctxs[k] || !shards[k] || shards[k]->group != group) return BH_ERR_INVALID_ARG;
+  std::vector<size_t> lens(n_shards);
+  for (size_t k = 0; k < n_shards; k++) lens[k] = shards[k]->n;
+  std::vector<size_t> cut, off;
+  shard_cuts(lens.data(), n_shards, skip, density_words, n_scalars, cut, off);
+  std::unique_ptr<bh_msm_sharded_job> sj(new bh_msm_sharded_job());
+  sj->group = group;
+  sj->density.resize(n_shards);
+  int rc = BH_OK;
+  for (size_t k = 0; k < n_shards && rc == BH_OK; k++) {
+    const size_t lo = cut[k], hi = cut[k + 1] > cut[k] ? cut[k + 1] : cut[k], n = hi - lo;
+    // bases before the shard's first used record: only the shard that contains `skip` starts inside itself
+    const size_t local_skip = skip > off[k] ? (skip - off[k] < shards[k]->n ? skip - off[k] : shards[k]->n) : 0;
+    const uint64_t *dw = nullptr;
+    if (density_words && n) {
+      std::vector<uint64_t> &d = sj->density[k];
+      d.assign((n + 63) / 64, 0);
+      const size_t sh = lo & 63, w0 = lo >> 6, nw_all = (n_scalars + 63) / 64;
+      for (size_t w = 0; w < d.size(); w++) {
+        uint64_t x = density_words[w0 + w] >> sh;
+        if (sh && w0 + w + 1 < nw_all) x |= density_words[w0 + w + 1] << (64 - sh);
+        d[w] = x;
+      }
+      if (n & 63) d.back() &= (((uint64_t)1 << (n & 63)) - 1);
+      dw = d.data();
+    }
+    bh_msm_job *j = nullptr;
+    const bh_msm_opts o = {0, 0, BH_MSM_NO_SMALL_PATH};
+    rc = msm_common(ctxs[k], shards[k], local_skip, (const char *)scalars_host + lo * 32, true, n, scalar_fmt, dw, true,
+                    dw ? n : 0, &o, &j, n_scalars ? n_scalars : 1);
+    if (rc == BH_OK) sj->jobs.push_back(j);
+  }
+  if (rc != BH_OK) {
+    unsigned char sink[192];
+    for (bh_msm_job *j : sj->jobs) (void)bh_msm_wait(j, sink);
+    return rc;
+  }
+  *out = sj.release();
+  return BH_OK;
+}
+int bh_msm_sharded_wait(bh_msm_sharded_job *job, void *out_affine) {
+  if (!job || !out_affine) return BH_ERR_INVALID_ARG;
+  const size_t rec = job->group == BH_G1 ? 96 : 192;
+  alignas(16) unsigned char acc[192], part[192];
+  memset(acc, 0, sizeof acc);
+  // Error precedence of the whole multiexp from the shards': only the last shard can
+  // reach the end of the bases, and every entry of an earlier shard precedes the first EOF entry, so an identity
+  // consumed in the reference's top window by ANY shard wins over the EOF; without an EOF any identity is the error.
+  bool hip_fail = false, eof = false, ident = false, ident_top = false;
+  int other = BH_OK;
+  for (size_t k = 0; k < job->jobs.size(); k++) {
+    MsmJobImpl *impl = job->jobs[k]->impl;
+    const int rc = msm_job_finish(*impl, part, nullptr);
+    if (rc < 0) { hip_fail = true; other = rc; }
+    eof |= impl->saw_eof;
+    ident |= impl->saw_ident;
+    // a shard that saw both resolves "top window, before its first EOF entry" itself
+    ident_top |= impl->saw_ident_top;
+    if (rc == BH_OK) host_point_add(job->group, acc, acc, part, 1);
+    msm_job_delete(impl);
+    delete job->jobs[k];
+  }
+  delete job;
+  if (hip_fail) return other;
+  if (eof && ident) return ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF;
+  if (eof) return BH_ERR_UNEXPECTED_EOF;
+  if (ident) return BH_ERR_UNEXPECTED_IDENTITY;
+  memcpy(out_affine, acc, rec);
+  return BH_OK;
+}
+
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;
   float ms[4] = {0, 0, 0, 0};

@@ -4,11 +4,15 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <condition_variable>
+#include <functional>
+#include <list>
 #include <map>
 #include <mutex>
 #include <vector>
 
 #include "../../include/bellman_hip.h"
+struct bh_bases;
 #include "ec.cuh"
 #include "ff.cuh"
 
@@ -24,31 +28,62 @@ namespace bh {
     }                                                                                   \
   } while (0)
 
-// Size-bucketed cache of device allocations: hipMalloc/hipFree synchronise the device, so
-// the per-call workspaces of the (asynchronous, concurrent) MSM entry points are recycled.
+// Size-classed cache of device allocations: hipMalloc/hipFree synchronise the device, so the per-call
+// workspaces of the (asynchronous, concurrent) MSM entry points are recycled.
+//   * size classes at 1/8 octave (a request is rounded up by at most 12.5 %; power-of-two classes wasted up to
+//     40 % of every workspace below 1 GiB);
+//   * when hipMalloc fails, or an optional byte cap (bh_ctx_set_limits) would be exceeded, the idle blocks of
+//     the OTHER classes are handed back to the driver and the allocation is retried;
+//   * when that is not enough the context's pressure handler runs - it completes the oldest multiexp still in
+//     flight (whose workspace then returns to the pool) - and the allocation is retried, until nothing is left in
+//     flight.  This is the analogue of Worker::compute running a task inline once the queue is deep
+//     (src/multicore.rs:47-73): a caller that issues more work than fits waits, it is not refused.
 class DevicePool {
  public:
   ~DevicePool() { release_all(); }
+  static size_t size_class(size_t bytes) {
+    if (bytes < 256) return 256;
+    int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = size_t(1) << (lg - 3);
+    return (bytes + step - 1) & ~(step - 1);
+  }
+  void set_cap(size_t bytes) { std::lock_guard<std::mutex> g(mu_); cap_ = bytes; }
+  void set_pressure_handler(std::function<bool()> f) { pressure_ = std::move(f); }
+  size_t bytes_held() { std::lock_guard<std::mutex> g(mu_); return held_; }
+  size_t bytes_idle() { std::lock_guard<std::mutex> g(mu_); return idle_; }
   void *acquire(size_t bytes) {
     if (bytes == 0) bytes = 16;
-    size_t cap = 256;
-    while (cap < bytes) cap <<= 1;
-    if (cap > (size_t(1) << 30)) cap = (bytes + ((size_t(1) << 28) - 1)) & ~((size_t(1) << 28) - 1);
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      auto it = free_.find(cap);
-      if (it != free_.end() && !it->second.empty()) {
-        void *p = it->second.back();
-        it->second.pop_back();
-        live_[p] = cap;
-        return p;
+    const size_t cap = size_class(bytes);
+    for (;;) {
+      bool over_cap = false;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = free_.find(cap);
+        if (it != free_.end() && !it->second.empty()) {
+          void *p = it->second.back();
+          it->second.pop_back();
+          idle_ -= cap;
+          live_[p] = cap;
+          return p;
+        }
+        over_cap = cap_ && held_ + cap > cap_;
+        if (!over_cap) held_ += cap;   // reserved before the (unlocked) hipMalloc so that concurrent callers see it
       }
+      if (!over_cap) {
+        void *p = nullptr;
+        if (hipMalloc(&p, cap) == hipSuccess) {
+          std::lock_guard<std::mutex> g(mu_);
+          live_[p] = cap;
+          return p;
+        }
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> g(mu_);
+        held_ -= cap;
+      }
+      if (trim_idle()) continue;                 // idle blocks of other classes went back to the driver
+      if (pressure_ && pressure_()) continue;    // an in-flight job was completed: its workspace is back in the pool
+      return nullptr;
     }
-    void *p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> g(mu_);
-    live_[p] = cap;
-    return p;
   }
   void release(void *p) {
     if (!p) return;
@@ -56,19 +91,29 @@ class DevicePool {
     auto it = live_.find(p);
     if (it == live_.end()) return;
     free_[it->second].push_back(p);
+    idle_ += it->second;
     live_.erase(it);
   }
-  void release_all() {
-    std::lock_guard<std::mutex> g(mu_);
-    for (auto &kv : free_)
-      for (void *p : kv.second) (void)hipFree(p);
-    free_.clear();
+  // hands every idle block back to the driver; true if that freed anything
+  bool trim_idle() {
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (auto &kv : free_)
+        for (void *p : kv.second) { drop.push_back(p); held_ -= kv.first; idle_ -= kv.first; }
+      free_.clear();
+    }
+    for (void *p : drop) (void)hipFree(p);
+    return !drop.empty();
   }
+  void release_all() { (void)trim_idle(); }
 
  private:
   std::mutex mu_;
   std::map<size_t, std::vector<void *>> free_;
   std::map<void *, size_t> live_;
+  size_t held_ = 0, idle_ = 0, cap_ = 0;   // bytes obtained from the driver / of those idle / optional cap (0 = none)
+  std::function<bool()> pressure_;
 };
 
 // per-job HIP objects that are expensive to create: recycled across MSM jobs
@@ -111,6 +156,16 @@ struct Context {
   std::mutex job_mu;
   std::vector<JobResources> job_pool;
   std::vector<hipStream_t> stream_pool;   // bh_stream_create / destroy recycle streams (creation costs ~1 ms)
+  // multiexps issued and not yet completed, oldest first (guarded by job_mu).  Back-pressure (src/multicore.rs:47-73:
+  // Worker::compute runs the task inline once 4 x threads are pending): when `max_jobs` are in flight, or the
+  // workspace pool cannot serve an allocation, the issuing thread COMPLETES the oldest job itself (stream
+  // synchronise + host tail; the result is kept in the job for its bh_msm_wait) instead of failing.
+  std::list<struct MsmJobImpl *> inflight;
+  uint32_t max_jobs = 64;
+  size_t hbm_total = 0, table_bytes = 0, table_budget = 0;   // window tables built automatically stay below the budget
+  std::vector<struct ::bh_bases *> tables;                     // handles that own an automatically built table (job_mu)
+  int hw_queues_env = 0;          // GPU_MAX_HW_QUEUES seen when the context was created (0 = unset: the runtime's 4)
+  bool configured_early = false;  // bh_runtime_configure ran before this library's first HIP call
 };
 
 }  // namespace bh

@@ -509,54 +509,73 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
   std::lock_guard<std::mutex> g(c.fft_mu);
   fr_t one;
   fe_one(one);
-  bool generated = false;
   const int dir = inverse ? 1 : 0;
+  // Everything new is built into locals and PUBLISHED into the context only after every allocation and launch of
+  // this call succeeded (and the generating stream drained): a failed hipMalloc / launch leaves the cache exactly as
+  // it was, so a retry regenerates instead of running a kernel with half a table pair (null *_hi pointer).
+  std::vector<BTw *> fresh;   // freed on failure
+  auto fail = [&](int rc) {
+    (void)hipStreamSynchronize(st);
+    for (BTw *p : fresh) (void)hipFree(p);
+    return rc;
+  };
+  auto make = [&](BTw **dst, u64 count, const fr_t &base, const fr_t &scale) -> int {
+    BTw *p = nullptr;
+    int rc = make_btw_table(&p, count, base, scale, st);
+    if (p) fresh.push_back(p);
+    if (rc == BH_OK) *dst = p;
+    return rc;
+  };
+  BTw *new_master = nullptr;
   if (!c.fft_master[dir]) {   // w_2048^(+-i), i < 1024
     fr_t w = fr_domain_omega_host(NTT_LOG_TILE);
     if (inverse) fe_inv(w, w);
-    int rc = make_btw_table(&c.fft_master[dir], 1024, w, one, st);
-    if (rc) return rc;
-    generated = true;
+    int rc = make(&new_master, 1024, w, one);
+    if (rc) return fail(rc);
   }
-  FftTables &t = c.fft_tables[log_n];
+  auto it = c.fft_tables.find(log_n);
+  FftTables t = it != c.fft_tables.end() ? it->second : FftTables();
   const u64 n = (u64)1 << log_n;
   if (!t.init) {
-    t.init = true;
     t.lb = (log_n + 1) / 2;
     fr_t nn = fr_from_u64_host(n);
     fe_inv(t.minv, nn);
     t.zinv = zinv_host(log_n);   // ~800 host field products: computed once per domain size, not per proof
-    int rc = make_btw_table(&t.minv_dev, 1, one, t.minv, st);   // the single entry 1/n
-    if (rc) return rc;
-    generated = true;
+    int rc = make(&t.minv_dev, 1, one, t.minv);   // the single entry 1/n
+    if (rc) return fail(rc);
+    t.init = true;
   }
   const u64 n_lo = (u64)1 << t.lb, n_hi = (u64)1 << (log_n - t.lb);
   auto two_level = [&](BTw **lo, BTw **hi, const fr_t &base, const fr_t &scale) -> int {
-    int rc = make_btw_table(lo, n_lo, base, scale, st);
+    BTw *l = nullptr, *h = nullptr;
+    int rc = make(&l, n_lo, base, scale);
     if (rc) return rc;
     const fr_t step = fr_pow_u64_host(base, n_lo);
-    rc = make_btw_table(hi, n_hi, step, one, st);
-    generated = true;
-    return rc;
+    rc = make(&h, n_hi, step, one);
+    if (rc) return rc;
+    *lo = l; *hi = h;   // a pair is set together or not at all
+    return BH_OK;
   };
   if (need_tw && !t.tw_lo[dir]) {
     fr_t w = fr_domain_omega_host(log_n);
     if (inverse) fe_inv(w, w);
     int rc = two_level(&t.tw_lo[dir], &t.tw_hi[dir], w, one);
-    if (rc) return rc;
+    if (rc) return fail(rc);
   }
   if (need_coset && !t.coset_lo) {
     int rc = two_level(&t.coset_lo, &t.coset_hi, fr_from_u64_host(7), one);   // MULTIPLICATIVE_GENERATOR
-    if (rc) return rc;
+    if (rc) return fail(rc);
   }
   if (need_icoset && !t.icoset_lo) {
     fr_t ginv;
     fe_inv(ginv, fr_from_u64_host(7));
     int rc = two_level(&t.icoset_lo, &t.icoset_hi, ginv, t.minv);   // 7^-i / n
-    if (rc) return rc;
+    if (rc) return fail(rc);
   }
   // tables are generated on `st`; later users may be on other streams
-  if (generated) BH_HIP_CHECK(hipStreamSynchronize(st));
+  if (!fresh.empty() && hipStreamSynchronize(st) != hipSuccess) return fail(BH_ERR_HIP);
+  if (new_master) c.fft_master[dir] = new_master;
+  c.fft_tables[log_n] = t;
   *out = t;
   *master = c.fft_master[dir];
   return BH_OK;

@@ -248,6 +248,33 @@ double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mo
   });
   return ms;
 }
+int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const void *witness, const void *constants,
+                            size_t counts3[3], void *a, void *b, void *c, void *inputs, void *aux, uint64_t *a_aux_density,
+                            uint64_t *b_input_density, uint64_t *b_aux_density) {
+  // host only: synthesises the demo circuit into a ProvingAssignment exactly as create_proof does (prover.rs:182-215,
+  // input constraints appended) and copies its fields out.  First call with null outputs for the counts.
+  using namespace groth16;
+  if (!counts3) return BH_ERR_INVALID_ARG;
+  try {
+    return with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &circ) -> int {
+      ProvingAssignment pa;
+      pa.alloc_input([] { return Fr::one(); });
+      circ.synthesize(pa);
+      for (size_t i = 0; i < pa.input_assignment.size(); i++)
+        pa.enforce([i](bellman::LinearCombination lc) { return lc + bellman::Variable::new_unchecked(bellman::Index::Input, i); },
+                   [](bellman::LinearCombination lc) { return lc; }, [](bellman::LinearCombination lc) { return lc; });
+      counts3[0] = pa.a.size(); counts3[1] = pa.input_assignment.size(); counts3[2] = pa.aux_assignment.size();
+      if (!a) return BH_OK;
+      memcpy(a, pa.a.data(), pa.a.size() * 32); memcpy(b, pa.b.data(), pa.b.size() * 32); memcpy(c, pa.c.data(), pa.c.size() * 32);
+      memcpy(inputs, pa.input_assignment.data(), pa.input_assignment.size() * 32);
+      memcpy(aux, pa.aux_assignment.data(), pa.aux_assignment.size() * 32);
+      memcpy(a_aux_density, pa.a_aux_density.words(), (pa.aux_assignment.size() + 63) / 64 * 8);
+      memcpy(b_input_density, pa.b_input_density.words(), (pa.input_assignment.size() + 63) / 64 * 8);
+      memcpy(b_aux_density, pa.b_aux_density.words(), (pa.aux_assignment.size() + 63) / 64 * 8);
+      return BH_OK;
+    });
+  } catch (...) { return BH_ERR_HIP; }
+}
 void bh_test_fr_from_u512_host(void *r, const void *limbs8) {
   uint64_t w[8];
   memcpy(w, limbs8, 64);

@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
+
 #include "msm_types.hpp"
 
 namespace bh {
@@ -104,6 +106,46 @@ int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 ski
 int window_table(int group, void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {
   return group == BH_G1 ? window_table_g1(table_dev, n, c, W, st) : window_table_g2(table_dev, n, c, W, st);
 }
+// runs the group's finish (stream synchronise, error resolution, host tail) once; caller holds job.mu
+static void msm_job_complete_locked(MsmJobImpl &job) {
+  if (job.done) return;
+  job.done_rc = job.group == BH_G1 ? msm_finish_g1(job, job.done_out, job.done_ms) : msm_finish_g2(job, job.done_out, job.done_ms);
+  job.done = true;
+}
+void msm_job_track(MsmJobImpl &job) {
+  if (job.trivial) return;
+  std::lock_guard<std::mutex> g(job.ctx->job_mu);
+  job.ctx->inflight.push_back(&job);
+}
+static void msm_job_untrack(MsmJobImpl &job) {
+  std::lock_guard<std::mutex> g(job.ctx->job_mu);
+  job.ctx->inflight.remove(&job);
+}
+size_t msm_jobs_in_flight(Context &c) {
+  std::lock_guard<std::mutex> g(c.job_mu);
+  return c.inflight.size();
+}
+// Back-pressure: completes the oldest job in flight on the calling thread.  true = a job was completed, or one is
+// being completed by another thread right now (the caller should retry what it was doing); false = nothing in flight.
+bool msm_complete_oldest(Context &c) {
+  MsmJobImpl *pick = nullptr;
+  bool busy = false;
+  {
+    std::lock_guard<std::mutex> g(c.job_mu);
+    for (MsmJobImpl *j : c.inflight) {
+      if (j->mu.try_lock()) { pick = j; break; }   // held across job_mu's release: the waiter of `j` cannot delete it
+      busy = true;
+    }
+  }
+  if (!pick) {
+    if (busy) std::this_thread::yield();
+    return busy;
+  }
+  msm_job_complete_locked(*pick);
+  msm_job_untrack(*pick);   // lock order mu -> job_mu; the scan above only try_locks mu under job_mu
+  pick->mu.unlock();
+  return true;
+}
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   if (job.trivial) {
     const size_t rec = job.group == BH_G1 ? 96 : 192;
@@ -111,7 +153,12 @@ int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     if (ms) ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
     return job.early_rc;
   }
-  return job.group == BH_G1 ? msm_finish_g1(job, out_affine, ms) : msm_finish_g2(job, out_affine, ms);
+  msm_job_untrack(job);   // first: a back-pressure scan that has not picked the job yet will never see it
+  std::lock_guard<std::mutex> g(job.mu);   // ... and one that has finishes before we look
+  msm_job_complete_locked(job);
+  memcpy(out_affine, job.done_out, job.group == BH_G1 ? 96 : 192);
+  if (ms) memcpy(ms, job.done_ms, sizeof job.done_ms);
+  return job.done_rc;
 }
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
                    hipStream_t st) {

@@ -624,6 +624,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   job.err_dev = err;
   job.scalars_dev = scalars_dev; job.density_dev = density_dev; job.word_prefix = b.word_prefix;
   job.bases_dev = bases_dev; job.skip = skip; job.n_bases = n_bases; job.fmt = fmt;
+  job.ref_n = opts.ref_n; job.always_resolve_ident = opts.always_resolve_ident;
 
   job.timed = (opts.flags & BH_MSM_STAGE_TIMES) != 0;
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_begin, st));
@@ -819,9 +820,12 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
         (void)hipEventElapsedTime(&ms[3], job.ev_accum, job.ev_end);
       }
     }
-    if (ef.eof && ef.ident) {
-      // both kinds of failure exist: the reference reports the top window's first failure
-      const double cref = (p.nd < 32) ? 3.0 : std::ceil(std::log((double)p.nd));   // multiexp.rs:318-322
+    job.saw_eof = ef.eof != 0;
+    job.saw_ident = ef.ident != 0;
+    if (ef.ident && (ef.eof || job.always_resolve_ident)) {
+      // both kinds of failure exist (or the caller folds shards): the reference reports the top window's first failure
+      const u64 nref = job.ref_n ? job.ref_n : p.nd;
+      const double cref = (nref < 32) ? 3.0 : std::ceil(std::log((double)nref));   // multiexp.rs:318-322
       const u32 c_ref = (u32)cref, w_ref = (255 + c_ref - 1) / c_ref, lo_ref = c_ref * (w_ref - 1);
       hipLaunchKernelGGL(msm_err_resolve_kernel<F>, dim3((p.nd + 255) / 256), dim3(256), 0, job.stream,
                          job.scalars_dev, job.fmt, p.nd, job.density_dev, job.word_prefix, job.skip, job.n_bases,
@@ -829,8 +833,10 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
       if (hipMemcpyAsync(&ef, job.err_dev, sizeof ef, hipMemcpyDeviceToHost, job.stream) != hipSuccess ||
           hipStreamSynchronize(job.stream) != hipSuccess)
         rc = BH_ERR_HIP;
-      else
-        rc = ef.ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF;
+      else {
+        job.saw_ident_top = ef.ident_top != 0;
+        rc = !ef.eof ? BH_ERR_UNEXPECTED_IDENTITY : ef.ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF;
+      }
     } else if (ef.eof) {
       rc = BH_ERR_UNEXPECTED_EOF;
     } else if (ef.ident) {

@@ -34,6 +34,11 @@ struct MsmOpts {
   u32 c = 0;        // window bits
   u32 chunk = 0;    // K
   u32 flags = 0;    // BH_MSM_*
+  // a shard of a multi-context multiexp (bh_msm_sharded_async): the reference's window size follows the TOTAL
+  // number of exponents (multiexp.rs:318-322), and the shard reports whether an identity base was consumed in that
+  // top window even when it saw no EOF itself - the fold needs it for the error precedence
+  u64 ref_n = 0;
+  bool always_resolve_ident = false;
 };
 
 struct MsmPlan {
@@ -80,6 +85,16 @@ struct MsmJobImpl {
   u64 skip = 0, n_bases = 0;
   int fmt = 0;
   ErrFlags *err_dev = nullptr;
+  // completion state (msm.hip): whoever completes the job - its bh_msm_wait, or another issuing thread under
+  // back-pressure - holds `mu` while it synchronises the stream and runs the host tail, and leaves the outcome here
+  u64 ref_n = 0;                     // MsmOpts::ref_n
+  bool always_resolve_ident = false;
+  bool saw_eof = false, saw_ident = false, saw_ident_top = false;   // after completion
+  std::mutex mu;
+  bool done = false;
+  int done_rc = BH_OK;
+  float done_ms[4] = {0, 0, 0, 0};
+  alignas(16) unsigned char done_out[192];
 };
 
 

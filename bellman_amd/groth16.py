@@ -550,3 +550,65 @@ def assemble(params, sums, r, s):
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     check(_lib.load().bh_groth16_assemble(params._h, p(sums), p(rs[0:1]), p(rs[1:2]), p(out)), "create_proof")
     return Proof(out)
+
+
+# ---- the reference's call sites as the Rust shim issues them (shim/patches, csrc/groth16_callsites.cpp) ----------
+
+
+def demo_assignment(kind, size, seed, witness, constants=None):
+    """The ProvingAssignment create_proof synthesises for a C++ demo circuit (prover.rs:182-215), as numpy arrays:
+    dict(a, b, c, input_assignment, aux_assignment: [n,4] uint64 Montgomery; a_aux_density, b_input_density,
+    b_aux_density: LSB0 uint64 words).  Host only (test hook)."""
+    lib = _lib.load()
+    wit = fr_to_mont_array(witness if isinstance(witness, np.ndarray) else list(witness))
+    con = fr_to_mont_array(constants if isinstance(constants, np.ndarray) else list(constants)) if constants is not None \
+        else np.zeros((1, 4), dtype=np.uint64)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    counts = (ctypes.c_size_t * 3)()
+    check(lib.bh_test_demo_assignment(kind, size, seed, p(wit), p(con), counts, None, None, None, None, None, None, None, None))
+    nc, ni, na = counts[0], counts[1], counts[2]
+    out = dict(a=np.zeros((nc, 4), np.uint64), b=np.zeros((nc, 4), np.uint64), c=np.zeros((nc, 4), np.uint64),
+               input_assignment=np.zeros((ni, 4), np.uint64), aux_assignment=np.zeros((na, 4), np.uint64),
+               a_aux_density=np.zeros((na + 63) // 64 + 1, np.uint64), b_input_density=np.zeros((ni + 63) // 64 + 1, np.uint64),
+               b_aux_density=np.zeros((na + 63) // 64 + 1, np.uint64))
+    check(lib.bh_test_demo_assignment(kind, size, seed, p(wit), p(con), counts, p(out["a"]), p(out["b"]), p(out["c"]),
+                                      p(out["input_assignment"]), p(out["aux_assignment"]), p(out["a_aux_density"]),
+                                      p(out["b_input_density"]), p(out["b_aux_density"])))
+    return out
+
+
+def prove_assignment_arrays(params, asg, r, s, timings=None):
+    """bh_groth16_prove_assignment on the arrays of demo_assignment (already Montgomery)."""
+    lib = _lib.load()
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 4)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_groth16_prove_assignment(params._h, p(asg["a"]), p(asg["b"]), p(asg["c"]), asg["a"].shape[0],
+                                          p(asg["input_assignment"]), asg["input_assignment"].shape[0], p(asg["aux_assignment"]),
+                                          asg["aux_assignment"].shape[0], p(asg["a_aux_density"]), p(asg["b_input_density"]),
+                                          p(asg["b_aux_density"]), p(rs[0:1]), p(rs[1:2]), p(out), tm), "create_proof")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)
+
+
+def prove_via_call_sites(params, asg, r, s, patched_prover, timings=None):
+    """The h block + eight multiexps issued as bellman's create_proof issues them through the Rust shim:
+    patched_prover=True  - groth16/src/prover.rs patched (scalars registered once, h block in one device call);
+    patched_prover=False - only multiexp.rs / domain.rs patched (7 host FFT round trips, host pointwise passes, serial
+                           Fr -> Exponent, 8 multiexps each uploading its scalars).
+    timings: [issue + waits, total] host ms."""
+    lib = _lib.load()
+    rs = fr_to_mont_array([r, s])
+    out = np.zeros(48, dtype=np.uint64)
+    tm = (ctypes.c_float * 2)()
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    check(lib.bh_test_groth16_prove_via_call_sites(params._h, 1 if patched_prover else 0, p(asg["a"]), p(asg["b"]), p(asg["c"]),
+                                                   asg["a"].shape[0], p(asg["input_assignment"]), asg["input_assignment"].shape[0],
+                                                   p(asg["aux_assignment"]), asg["aux_assignment"].shape[0], p(asg["a_aux_density"]),
+                                                   p(asg["b_input_density"]), p(asg["b_aux_density"]), p(rs[0:1]), p(rs[1:2]), p(out), tm),
+          "create_proof (call sites)")
+    if timings is not None:
+        timings[:] = list(tm)
+    return Proof(out)

@@ -142,10 +142,24 @@ class Bases:
 
     @classmethod
     def wrap_device(cls, worker, group, dev_ptr, n):
+        """A LIVE view of a device array of packed records (not owned, nothing snapshotted: no window table unless
+        precompute() is called explicitly)."""
         self = cls.__new__(cls)
         self.worker, self.group, self.n = worker, group, n
         h = ctypes.c_void_p()
         check(_lib.load().bh_bases_wrap_dev(worker.ctx, group, dev_ptr, n, ctypes.byref(h)))
+        self._h = h
+        self._auto_precompute()
+        return self
+
+    @classmethod
+    def copy_device(cls, worker, group, dev_ptr, n):
+        """An owned handle holding a device-to-device copy of n packed records (registered like a CRS query: the
+        automatic window table applies)."""
+        self = cls.__new__(cls)
+        self.worker, self.group, self.n = worker, group, n
+        h = ctypes.c_void_p()
+        check(_lib.load().bh_bases_copy_dev(worker.ctx, group, dev_ptr, n, ctypes.byref(h)))
         self._h = h
         self._auto_precompute()
         return self
@@ -208,6 +222,85 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
         ms = (ctypes.c_float * 4)()
         check(lib.bh_msm_wait_profile(job, out.ctypes.data_as(ctypes.c_void_p), ms), "multiexp.wait")
         return (out, list(ms)) if timed else out
+
+    return Waiter(fn=finish)
+
+
+class Scalars:
+    """A scalar vector resident in HBM (bh_scalars_*): the `Arc<Vec<Exponent>>` that create_proof shares between
+    several multiexps (groth16/src/prover.rs:267-318), uploaded once."""
+
+    def __init__(self, worker, scalars, mont=False):
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        self.worker, self.n = worker, sc.shape[0]
+        h = ctypes.c_void_p()
+        check(_lib.load().bh_scalars_register(worker.ctx, sc.ctypes.data_as(ctypes.c_void_p), self.n, 1 if mont else 0,
+                                              ctypes.byref(h)), "scalars_register")
+        self._h = h
+
+    def __len__(self):
+        return self.n
+
+    def release(self):
+        if self._h:
+            _lib.load().bh_scalars_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def multiexp_scalars(pool, bases, density_map, scalars, skip=0, first=0, n=None, window_bits=0, chunk=0, flags=0):
+    """multiexp over scalars [first, first + n) of a registered vector (bh_msm_async_scalars) -> Waiter."""
+    lib = _lib.load()
+    n = len(scalars) - first if n is None else n
+    words, dlen = None, 0
+    if isinstance(density_map, DensityTracker):
+        dlen = density_map.get_query_size()
+        words = density_map.words()
+    opts = MsmOpts(window_bits, chunk, flags)
+    job = ctypes.c_void_p()
+    check(lib.bh_msm_async_scalars(pool.ctx, bases._h, skip, scalars._h, first, n,
+                                   None if words is None else words.ctypes.data_as(ctypes.c_void_p), dlen,
+                                   ctypes.cast(ctypes.pointer(opts), ctypes.c_void_p), ctypes.byref(job)), "multiexp")
+    w = _WORDS[bases.group]
+
+    def finish():
+        _keep = (words, scalars)  # noqa: F841  (alive until the job has been waited on)
+        out = np.zeros(w, dtype=np.uint64)
+        check(lib.bh_msm_wait(job, out.ctypes.data_as(ctypes.c_void_p)), "multiexp.wait")
+        return out
+
+    return Waiter(fn=finish)
+
+
+def multiexp_sharded(workers, shards, density_map, exponents, skip=0, mont=False):
+    """ONE multiexp over several contexts of this process (bh_msm_sharded_async): workers[k] / shards[k] = the
+    context on GPU k and the k-th contiguous piece of the base vector registered on it -> Waiter."""
+    lib = _lib.load()
+    k = len(workers)
+    assert k == len(shards) and k > 0
+    sc = np.ascontiguousarray(exponents, dtype=np.uint64).reshape(-1, 4)
+    words, dlen = None, 0
+    if isinstance(density_map, DensityTracker):
+        dlen = density_map.get_query_size()
+        words = density_map.words()
+    ctxs = (ctypes.c_void_p * k)(*[w.ctx for w in workers])
+    hs = (ctypes.c_void_p * k)(*[b._h for b in shards])
+    job = ctypes.c_void_p()
+    check(lib.bh_msm_sharded_async(ctxs, hs, k, skip, sc.ctypes.data_as(ctypes.c_void_p), sc.shape[0], 1 if mont else 0,
+                                   None if words is None else words.ctypes.data_as(ctypes.c_void_p), dlen, ctypes.byref(job)),
+          "multiexp (sharded)")
+    w = _WORDS[shards[0].group]
+
+    def finish():
+        _keep = (sc, words)  # noqa: F841
+        out = np.zeros(w, dtype=np.uint64)
+        check(lib.bh_msm_sharded_wait(job, out.ctypes.data_as(ctypes.c_void_p)), "multiexp.wait (sharded)")
+        return out
 
     return Waiter(fn=finish)
 

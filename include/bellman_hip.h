@@ -57,6 +57,35 @@ void bh_ctx_destroy(bh_ctx *ctx);
 /* Worker::log_num_threads analogue (src/multicore.rs:29-31): log2 of the CU count. */
 uint32_t bh_ctx_log_num_cus(const bh_ctx *ctx);
 const char *bh_version(void);
+/* Process-level runtime settings, to be called BEFORE the process makes its first HIP call (the HIP runtime reads
+ * them when it initialises): asks for 16 hardware queues (GPU_MAX_HW_QUEUES, unless the variable is already set) -
+ * a proof keeps 6-7 job streams in flight and the runtime's default of 4 queues serialises them.  Returns 1 when no
+ * HIP call had been made through this library yet, 0 when it is (probably) too late to take effect.  The library
+ * never changes the environment on its own. */
+int bh_runtime_configure(void);
+/* Limits of a context (0 / (size_t)-1 = leave unchanged):
+ *   max_jobs_in_flight  multiexps issued and not yet completed.  At the limit bh_msm_async* completes the OLDEST job
+ *                       on the calling thread before issuing (its result is kept for its bh_msm_wait) - the analogue
+ *                       of Worker::compute running a task inline once 4 x threads are pending
+ *                       (src/multicore.rs:47-73).  Default: BELLMAN_HIP_MAX_JOBS, else from the device's memory.
+ *   pool_cap_bytes      cap on the device memory the context's workspace pool holds (0 = none; BELLMAN_HIP_POOL_CAP_MB).
+ *                       An allocation that does not fit first returns idle blocks to the driver, then completes jobs in
+ *                       flight as above, and only fails (BH_ERR_HIP) when nothing is left to wait for.  The same
+ *                       happens when hipMalloc itself fails.
+ *   table_budget_bytes  total size of the window tables built AUTOMATICALLY at registration (bh_bases_register etc.;
+ *                       default a quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB); bh_ctx_trim drops them. */
+int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes);
+typedef struct {
+  int32_t device;
+  uint32_t num_cus;
+  uint64_t hbm_bytes;
+  uint32_t hw_queues_requested;            /* GPU_MAX_HW_QUEUES when the context was created (0 = unset: runtime default, 4) */
+  uint32_t hw_queues_set_before_hip_init;  /* 1 = set before this library's first HIP call (bh_runtime_configure or the
+                                              caller's environment): the request can have taken effect */
+  uint32_t max_jobs_in_flight, jobs_in_flight;
+  uint64_t pool_bytes_held, pool_bytes_idle, table_bytes, table_budget;
+} bh_ctx_info_t;
+int bh_ctx_info(bh_ctx *ctx, bh_ctx_info_t *info);
 
 /* ---- raw device memory helpers (so callers can keep vectors resident in HBM) -------- */
 int bh_dev_alloc(bh_ctx *ctx, size_t bytes, void **dev_ptr);
@@ -146,7 +175,10 @@ int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits);
 int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows, size_t *bytes);
 /* a new owned handle holding a device-to-device copy of `n` packed records */
 int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
-/* wrap an existing device array of packed 96/192-byte records (not owned) */
+/* wrap an existing device array of packed 96/192-byte records (not owned): a LIVE view - nothing is copied or
+ * precomputed from the buffer at wrap time (no host mirror for tiny multiexps, no automatic window table), every
+ * multiexp reads the buffer as it is when the job runs; the caller orders its writes before issuing.
+ * bh_bases_precompute on such a handle is an explicit SNAPSHOT of the buffer's contents at that call. */
 int bh_bases_wrap_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out);
 void bh_bases_release(bh_ctx *ctx, bh_bases *b);
 size_t bh_bases_len(const bh_bases *b);
@@ -207,6 +239,47 @@ int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
 int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev,
                           size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
                           size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
+
+/* ---- scalar vectors resident in HBM ------------------------------------------------------------------
+ * create_proof hands the same `Arc<Vec<Exponent>>` to several multiexps (groth16/src/prover.rs:267,279,285,300,306,
+ * 316,318: input_assignment to three, aux_assignment to four): registered once, uploaded once.  scalar_fmt as for
+ * bh_msm_async - with BH_SCALARS_MONT a Rust `Vec<Scalar>` is handed over as is and the serial Fr -> Exponent pass of
+ * prover.rs:241-261 disappears (the conversion happens on the device inside the digit kernel). */
+typedef struct bh_scalars bh_scalars;
+int bh_scalars_register(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, bh_scalars **out);
+/* the same over an existing device vector; take_ownership != 0: the vector came from bh_dev_alloc of this context and
+ * is returned to it by bh_scalars_release */
+int bh_scalars_adopt_dev(bh_ctx *ctx, void *scalars_dev, size_t n, int scalar_fmt, int take_ownership, bh_scalars **out);
+/* release after every multiexp issued over the handle has been waited on */
+void bh_scalars_release(bh_scalars *s);
+size_t bh_scalars_len(const bh_scalars *s);
+const void *bh_scalars_dev_ptr(const bh_scalars *s);
+/* multiexp over scalars [first, first + n) of a registered vector; the density map (NULL = FullDensity) is given on
+ * the HOST as for bh_msm_async and describes exactly those n scalars; opts may be NULL */
+int bh_msm_async_scalars(bh_ctx *ctx, const bh_bases *bases, size_t skip, const bh_scalars *scalars, size_t first,
+                         size_t n, const uint64_t *density_words, size_t density_len, const bh_msm_opts *opts,
+                         bh_msm_job **job);
+/* The h block of create_proof (groth16/src/prover.rs:221-245) with the result LEFT IN HBM: a, b, c = n_evals
+ * constraint evaluations (Montgomery Fr, host); *h_out = the m - 1 quotient coefficients (Montgomery) as a registered
+ * scalar vector, ready for the H multiexp - no download, no Fr -> Exponent pass (prover.rs:241-242), no re-upload. */
+int bh_h_poly_fr_scalars(bh_ctx *ctx, const void *a_host, const void *b_host, const void *c_host, size_t n_evals,
+                         bh_scalars **h_out);
+
+/* ---- one multiexp over several GPUs of ONE process (the reference is a single process,
+ * src/multicore.rs:21-92) ------------------------------------------------------------------------
+ * ctxs[k] = a context on GPU k (bh_ctx_create(k)), shards[k] = the k-th contiguous piece of the base vector,
+ * registered on ctxs[k]; the concatenation of the shards is the `bases` of multiexp(pool, (bases, skip), density,
+ * exponents).  The call cuts the exponents where the base index skip + rank_i crosses a shard boundary (re-basing the
+ * density map), issues one job per shard - each GPU runs the whole single-GPU pipeline on its piece, there is no
+ * device-to-device exchange - and bh_msm_sharded_wait folds the per-shard results (96 / 192 bytes each) on the
+ * host.  Result and error semantics are those of ONE multiexp over the whole vector, including "EOF vs. identity:
+ * the top window's first failure wins" (src/multiexp.rs:295-300) with the window size of the whole length.  Several
+ * contexts on the same device are allowed (tests on a single-GPU box). */
+typedef struct bh_msm_sharded_job bh_msm_sharded_job;
+int bh_msm_sharded_async(bh_ctx *const *ctxs, const bh_bases *const *shards, size_t n_shards, size_t skip,
+                         const void *scalars_host, size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
+                         size_t density_len, bh_msm_sharded_job **job);
+int bh_msm_sharded_wait(bh_msm_sharded_job *job, void *out_affine);
 
 /* ---- fixed-base scalar multiplication (fixture / CRS generation; SURVEY §8 f4,
  * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device */

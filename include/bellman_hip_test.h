@@ -40,7 +40,31 @@ int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
 /* host-only: milliseconds to synthesise a demo circuit (kind/size/seed as bh_groth16_prove_demo) into a
  * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); no device involved */
 double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
+/* host only: the ProvingAssignment create_proof synthesises for a demo circuit (arguments as bh_groth16_prove_demo; input
+ * constraints of prover.rs:208-215 appended).  counts3 = [n_constraints, n_inputs, n_aux]; with a == NULL only the counts
+ * are returned; otherwise a, b, c (n_constraints Fr), inputs, aux (Montgomery Fr) and the three LSB0 density bitmaps */
+int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const void *witness, const void *constants,
+                            size_t counts3[3], void *a, void *b, void *c, void *inputs, void *aux, uint64_t *a_aux_density,
+                            uint64_t *b_input_density, uint64_t *b_aux_density);
 void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
+
+/* host only: where bh_msm_sharded_async cuts the exponents for shards of lens[k] bases (cuts_out[n_shards + 1]), and
+ * the size class the workspace pool rounds a request up to */
+int bh_test_shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
+                       size_t *cuts_out);
+size_t bh_test_pool_size_class(size_t bytes);
+/* create_proof's h block + eight multiexps issued as the reference's call sites would issue them through the Rust shim
+ * (shim/patches/bellman-hip.patch), transcribed in C++ (csrc/groth16_callsites.cpp):
+ *   mode 1  groth16/src/prover.rs patched: bh_scalars_register x2, bh_msm_async_scalars x8, bh_h_poly_fr_scalars
+ *   mode 0  only multiexp.rs / domain.rs patched: 7 x bh_fft_fr on host vectors, the pointwise passes and the
+ *           Fr -> Exponent passes on the host, 8 x bh_msm_async with canonical host scalars
+ * arguments as bh_groth16_prove_assignment; ms2 (optional): [issue + waits, total] host milliseconds */
+int bh_test_groth16_prove_via_call_sites(bh_params *params, int mode, const void *a_evals, const void *b_evals,
+                                         const void *c_evals, size_t n_constraints, const void *input_assignment,
+                                         size_t n_inputs, const void *aux_assignment, size_t n_aux,
+                                         const uint64_t *a_aux_density, const uint64_t *b_input_density,
+                                         const uint64_t *b_aux_density, const void *r, const void *s, void *proof_out,
+                                         float *ms2);
 
 #ifdef __cplusplus
 }

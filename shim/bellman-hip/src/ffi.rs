@@ -28,6 +28,21 @@ pub struct BhParams {
 pub struct BhR1cs {
     _private: [u8; 0],
 }
+/// opaque `bh_scalars`
+#[repr(C)]
+pub struct BhScalars {
+    _private: [u8; 0],
+}
+/// opaque `bh_msm_sharded_job`
+#[repr(C)]
+pub struct BhMsmShardedJob {
+    _private: [u8; 0],
+}
+/// opaque `bh_proof_job`
+#[repr(C)]
+pub struct BhProofJob {
+    _private: [u8; 0],
+}
 /// `bh_csr`: one constraint matrix in CSR form (include/bellman_hip.h)
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -43,6 +58,22 @@ pub struct BhMsmOpts {
     pub window_bits: u32,
     pub chunk: u32,
     pub flags: u32,
+}
+/// `bh_ctx_info_t`: what bh_ctx_info reports about a context
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct BhCtxInfo {
+    pub device: i32,
+    pub num_cus: u32,
+    pub hbm_bytes: u64,
+    pub hw_queues_requested: u32,
+    pub hw_queues_set_before_hip_init: u32,
+    pub max_jobs_in_flight: u32,
+    pub jobs_in_flight: u32,
+    pub pool_bytes_held: u64,
+    pub pool_bytes_idle: u64,
+    pub table_bytes: u64,
+    pub table_budget: u64,
 }
 
 pub const BH_OK: c_int = 0;
@@ -73,6 +104,9 @@ extern "C" {
     pub fn bh_ctx_destroy(ctx: *mut BhCtx);
     pub fn bh_ctx_log_num_cus(ctx: *const BhCtx) -> u32;
     pub fn bh_version() -> *const c_char;
+    pub fn bh_runtime_configure() -> c_int;
+    pub fn bh_ctx_set_limits(ctx: *mut BhCtx, max_jobs_in_flight: u32, pool_cap_bytes: usize, table_budget_bytes: usize) -> c_int;
+    pub fn bh_ctx_info(ctx: *mut BhCtx, info: *mut BhCtxInfo) -> c_int;
     pub fn bh_dev_alloc(ctx: *mut BhCtx, bytes: usize, dev_ptr: *mut *mut c_void) -> c_int;
     pub fn bh_dev_free(ctx: *mut BhCtx, dev_ptr: *mut c_void) -> c_int;
     pub fn bh_dev_upload(ctx: *mut BhCtx, dev_dst: *mut c_void, host_src: *const c_void, bytes: usize) -> c_int;
@@ -114,6 +148,15 @@ extern "C" {
     pub fn bh_point_lincomb(group: c_int, r: *mut c_void, points: *const c_void, scalars_canonical: *const c_void, n: usize);
     pub fn bh_msm_async_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_host: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
     pub fn bh_msm_async_dev_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_dev: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words_dev: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
+    pub fn bh_scalars_register(ctx: *mut BhCtx, scalars_host: *const c_void, n: usize, scalar_fmt: c_int, out: *mut *mut BhScalars) -> c_int;
+    pub fn bh_scalars_adopt_dev(ctx: *mut BhCtx, scalars_dev: *mut c_void, n: usize, scalar_fmt: c_int, take_ownership: c_int, out: *mut *mut BhScalars) -> c_int;
+    pub fn bh_scalars_release(s: *mut BhScalars);
+    pub fn bh_scalars_len(s: *const BhScalars) -> usize;
+    pub fn bh_scalars_dev_ptr(s: *const BhScalars) -> *const c_void;
+    pub fn bh_msm_async_scalars(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars: *const BhScalars, first: usize, n: usize, density_words: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
+    pub fn bh_h_poly_fr_scalars(ctx: *mut BhCtx, a_host: *const c_void, b_host: *const c_void, c_host: *const c_void, n_evals: usize, h_out: *mut *mut BhScalars) -> c_int;
+    pub fn bh_msm_sharded_async(ctxs: *const *mut BhCtx, shards: *const *const BhBases, n_shards: usize, skip: usize, scalars_host: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words: *const u64, density_len: usize, job: *mut *mut BhMsmShardedJob) -> c_int;
+    pub fn bh_msm_sharded_wait(job: *mut BhMsmShardedJob, out_affine: *mut c_void) -> c_int;
     pub fn bh_fixed_base_mul_dev(ctx: *mut BhCtx, group: c_int, base_affine_host: *const c_void, scalars_dev: *const c_void, n: usize, scalar_fmt: c_int, out_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bh_groth16_params_create(ctx: *mut BhCtx, alpha_g1: *const c_void, beta_g1: *const c_void, beta_g2: *const c_void, delta_g1: *const c_void, delta_g2: *const c_void, h: *const c_void, nh: usize, l: *const c_void, nl: usize, a: *const c_void, na: usize, b_g1: *const c_void, nb1: usize, b_g2: *const c_void, nb2: usize, out: *mut *mut BhParams) -> c_int;
     pub fn bh_groth16_params_read(ctx: *mut BhCtx, bytes: *const c_void, len: usize, checked: c_int, out: *mut *mut BhParams) -> c_int;

@@ -6,6 +6,9 @@
 //! `shim/patches/` routes exactly that case here (decided at run time by `TypeId`, with two trait hooks
 //! for the base source and the density map) and leaves every other instantiation on the CPU path.
 //!
+//! `bh_runtime_configure()` (16 hardware queues) is called when the process-wide context is first requested - before
+//! this crate's first HIP call; a host program that initialises HIP earlier calls it itself, first thing in `main`.
+//!
 //! NOT COMPILED in the image this repository is built in (no Rust toolchain there): `ffi.rs` is generated
 //! from the C header and checked by `tests/test_shim_cpu.py`; the rest is written against the `bls12_381`
 //! 0.8 / `ff` 0.13 / `group` 0.13 APIs bellman pins.
@@ -61,6 +64,7 @@ pub fn context() -> Option<&'static Context> {
     CONTEXT
         .get_or_init(|| {
             let layout = layout::Layout::probe()?;
+            unsafe { ffi::bh_runtime_configure() };
             let device: c_int = std::env::var("BELLMAN_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
             let mut raw: *mut ffi::BhCtx = ptr::null_mut();
             let rc = unsafe { ffi::bh_ctx_create(device, &mut raw) };
@@ -145,10 +149,36 @@ pub enum Density<'a> {
     Bits { words: &'a [u64], len: usize },
 }
 
+/// A scalar vector resident in HBM (`bh_scalars`): what `Arc<Vec<Exponent<Fr>>>` is on the CPU path.  create_proof
+/// hands the same assignment to up to four multiexps (groth16/src/prover.rs:267,279,285,300,306,316,318): it is
+/// uploaded once, as the Montgomery `Scalar`s it already is (no `Fr -> Exponent` pass, prover.rs:241-261).
+pub struct Scalars {
+    raw: *mut ffi::BhScalars,
+    len: usize,
+}
+unsafe impl Send for Scalars {}
+unsafe impl Sync for Scalars {}
+impl Scalars {
+    pub fn len(&self) -> usize {
+        self.len
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len == 0
+    }
+}
+impl Drop for Scalars {
+    fn drop(&mut self) {
+        // every MsmJob over the vector holds an Arc to it, so no job can still read it here
+        unsafe { ffi::bh_scalars_release(self.raw) }
+    }
+}
+
 /// An MSM in flight == `Waiter<Result<G, SynthesisError>>` (src/multicore.rs:94-118).
 pub struct MsmJob {
     raw: *mut ffi::BhMsmJob,
     group: c_int,
+    /// device-resident scalars the job reads (kept alive until the job has been waited on)
+    _scalars: Option<Arc<Scalars>>,
 }
 unsafe impl Send for MsmJob {}
 
@@ -160,12 +190,25 @@ pub enum MsmOutput {
 
 impl MsmJob {
     /// Blocks until the job's stream has finished (`Waiter::wait`), returns the affine result record.
-    pub fn wait(self) -> Result<MsmOutput, HipError> {
+    pub fn wait(mut self) -> Result<MsmOutput, HipError> {
         let mut g1 = [0u64; 12];
         let mut g2 = [0u64; 24];
         let out = if self.group == ffi::BH_G1 { g1.as_mut_ptr() as *mut c_void } else { g2.as_mut_ptr() as *mut c_void };
-        check(unsafe { ffi::bh_msm_wait(self.raw, out) })?;
+        let raw = std::mem::replace(&mut self.raw, ptr::null_mut()); // the library frees the job in bh_msm_wait
+        check(unsafe { ffi::bh_msm_wait(raw, out) })?;
         Ok(if self.group == ffi::BH_G1 { MsmOutput::G1(g1) } else { MsmOutput::G2(g2) })
+    }
+}
+impl Drop for MsmJob {
+    /// bellman's create_proof drops the remaining Waiters when an earlier `wait()?` fails: a job that was never
+    /// waited on still owns a stream, a pinned buffer and its device workspace - the library requires every job to
+    /// be waited on, so do it here (into a scratch record).
+    fn drop(&mut self) {
+        if !self.raw.is_null() {
+            let mut sink = [0u64; 24];
+            let _ = unsafe { ffi::bh_msm_wait(self.raw, sink.as_mut_ptr() as *mut c_void) };
+            self.raw = ptr::null_mut();
+        }
     }
 }
 
@@ -190,7 +233,66 @@ impl Context {
         };
         let mut raw: *mut ffi::BhMsmJob = ptr::null_mut();
         check(unsafe { ffi::bh_msm_async(self.raw, bases, skip, scalars, n, fmt, words, dlen, &mut raw) })?;
-        Ok(MsmJob { raw, group })
+        Ok(MsmJob { raw, group, _scalars: None })
+    }
+
+    fn msm_scalars(
+        &self,
+        group: c_int,
+        bases: *const ffi::BhBases,
+        skip: usize,
+        scalars: &Arc<Scalars>,
+        density: &Density<'_>,
+    ) -> Result<MsmJob, HipError> {
+        let n = scalars.len();
+        let (words, dlen) = match density {
+            Density::Full => (ptr::null(), 0usize),
+            Density::Bits { words, len } => {
+                assert!(*len == n, "density map and exponents differ in length"); // multiexp.rs:324-329
+                (words.as_ptr(), *len)
+            }
+        };
+        let mut raw: *mut ffi::BhMsmJob = ptr::null_mut();
+        check(unsafe {
+            ffi::bh_msm_async_scalars(self.raw, bases, skip, scalars.raw, 0, n, words, dlen, ptr::null(), &mut raw)
+        })?;
+        Ok(MsmJob { raw, group, _scalars: Some(scalars.clone()) })
+    }
+
+    /// `Vec<Scalar>` -> HBM, once (Montgomery, as it is in memory).
+    pub fn register_scalars(&self, v: &[Scalar]) -> Result<Arc<Scalars>, HipError> {
+        let mut raw: *mut ffi::BhScalars = ptr::null_mut();
+        check(unsafe {
+            ffi::bh_scalars_register(self.raw, v.as_ptr() as *const c_void, v.len(), ffi::BH_SCALARS_MONT, &mut raw)
+        })?;
+        Ok(Arc::new(Scalars { raw, len: v.len() }))
+    }
+    /// `multiexp` over a registered scalar vector (the whole of it).
+    pub fn msm_g1_scalars(&self, bases: &Arc<Vec<G1Affine>>, skip: usize, scalars: &Arc<Scalars>, density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g1_cache, ffi::BH_G1, self.layout.g1, bases)?;
+        self.msm_scalars(ffi::BH_G1, dev, skip, scalars, density)
+    }
+    pub fn msm_g2_scalars(&self, bases: &Arc<Vec<G2Affine>>, skip: usize, scalars: &Arc<Scalars>, density: &Density<'_>) -> Result<MsmJob, HipError> {
+        let dev = self.bases_for(&self.g2_cache, ffi::BH_G2, self.layout.g2, bases)?;
+        self.msm_scalars(ffi::BH_G2, dev, skip, scalars, density)
+    }
+    /// The h block of `create_proof` (groth16/src/prover.rs:221-245) with the quotient's m - 1 coefficients left in
+    /// HBM as a registered scalar vector, ready for the H multiexp.
+    pub fn h_poly_scalars(&self, a: &[Scalar], b: &[Scalar], c: &[Scalar]) -> Result<Arc<Scalars>, HipError> {
+        assert!(a.len() == b.len() && b.len() == c.len());
+        let mut raw: *mut ffi::BhScalars = ptr::null_mut();
+        check(unsafe {
+            ffi::bh_h_poly_fr_scalars(
+                self.raw,
+                a.as_ptr() as *const c_void,
+                b.as_ptr() as *const c_void,
+                c.as_ptr() as *const c_void,
+                a.len(),
+                &mut raw,
+            )
+        })?;
+        let len = unsafe { ffi::bh_scalars_len(raw) };
+        Ok(Arc::new(Scalars { raw, len }))
     }
 
     /// `multiexp(pool, (bases, skip), density, exponents)` for G1 with `Scalar`s handed over as they are

@@ -1,0 +1,112 @@
+"""Host-side logic added in round 3, checked without a GPU:
+  * the workspace pool's size classes (1/8 octave: a request is rounded up by at most 12.5 %);
+  * where a multi-context multiexp cuts its exponents (bh_msm_sharded_async; the reference semantics are those of
+    ONE multiexp over the concatenated bases, src/multiexp.rs:45-86,210-332) against a numpy model;
+  * the ProvingAssignment the C++ demo circuits synthesise (prover.rs:182-215) against the Python restatement;
+  * the Rust patch: groth16/src/prover.rs is patched, every bellman_hip:: call it makes exists in the shim crate, and
+    every ffi:: call of the crate exists in the generated ffi.rs."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from bellman_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pool_size_classes_are_an_eighth_octave():
+    lib = _lib.load()
+    rnd = np.random.default_rng(1)
+    for bytes_ in [1, 255, 256, 257, 4096, 600 << 20, (1 << 30) + 1, 30 << 30] + [int(x) for x in rnd.integers(1, 1 << 36, 200)]:
+        c = lib.bh_test_pool_size_class(bytes_)
+        assert c >= bytes_ and c >= 256
+        assert c <= max(256, bytes_ + bytes_ // 8 + 1), (bytes_, c)      # at most 12.5 % waste
+        assert lib.bh_test_pool_size_class(c) == c                        # classes are fixed points
+    # a 0.6 GB multiexp workspace used to be rounded to 1 GiB
+    assert lib.bh_test_pool_size_class(600 << 20) <= 640 << 20
+
+
+def _model_cuts(lens, skip, density, n):
+    """scalar i goes to the shard that holds base skip + rank_i (dense entries); non-dense entries go with the
+    preceding dense entry's shard... any assignment of non-dense entries is valid, so only dense entries are checked."""
+    off = np.concatenate([[0], np.cumsum(lens)])
+    dense = np.ones(n, bool) if density is None else density
+    rank = np.cumsum(dense) - dense
+    base = skip + rank
+    shard_of = np.searchsorted(off[1:], base, side="right")
+    shard_of = np.minimum(shard_of, len(lens) - 1)     # beyond the end: the last shard reports EOF
+    return dense, shard_of
+
+
+def test_shard_cuts_match_the_base_index_model():
+    lib = _lib.load()
+    rnd = np.random.default_rng(7)
+    for trial in range(200):
+        k = int(rnd.integers(1, 6))
+        lens = rnd.integers(0, 40, k).astype(np.uint64)
+        n = int(rnd.integers(0, 150))
+        skip = int(rnd.integers(0, 30))
+        use_density = trial % 2 == 1
+        density = rnd.random(n) < rnd.random() if use_density else None
+        words = None
+        if use_density:
+            padded = np.zeros(((n + 63) // 64 + 1) * 64, dtype=np.uint8)
+            padded[:n] = density
+            words = np.packbits(padded, bitorder="little").view(np.uint64).copy()
+        cuts = np.zeros(k + 1, dtype=np.uint64)
+        rc = lib.bh_test_shard_cuts(lens.ctypes.data_as(ctypes.c_void_p), k, skip,
+                                    None if words is None else words.ctypes.data_as(ctypes.c_void_p), n,
+                                    cuts.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        cuts = cuts.astype(np.int64)
+        assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts) >= 0), (lens, skip, n, cuts)
+        dense, shard_of = _model_cuts(lens.astype(np.int64), skip, density, n)
+        got = np.searchsorted(cuts[1:], np.arange(n), side="right")
+        got = np.minimum(got, k - 1)
+        assert np.array_equal(got[dense], shard_of[dense]), (lens, skip, n, cuts)
+
+
+def test_demo_assignment_matches_the_python_restatement():
+    """bh_test_demo_assignment (C++ ChainCircuit through ProvingAssignment) == tests.circuits.chain_assignment_fast"""
+    from bellman_amd import groth16 as pg
+    from oracle import cref
+    from tests import circuits
+
+    rounds, seed, x0 = 37, 99, 123456789
+    asg = pg.demo_assignment(1, rounds, seed, [x0])
+    f = circuits.chain_assignment_fast(rounds, seed, x0)
+    for key in ("a", "b", "c", "input_assignment", "aux_assignment"):
+        assert cref.arr_to_ints(cref.fr_from_mont(asg[key])) == [v % circuits.Q for v in f[key]], key
+    for key in ("a_aux_density", "b_input_density", "b_aux_density"):
+        bits = np.unpackbits(asg[key].view(np.uint8), bitorder="little")[:len(f[key])].astype(bool)
+        assert list(bits) == list(f[key]), key
+
+
+def test_prover_rs_patch_and_shim_are_consistent():
+    patch = open(os.path.join(ROOT, "shim", "patches", "bellman-hip.patch")).read()
+    assert "+++ b/groth16/src/prover.rs" in patch and "+++ b/groth16/Cargo.toml" in patch
+    assert "issue_on_device" in patch and "finish_proof" in patch
+    lib_rs = open(os.path.join(ROOT, "shim", "bellman-hip", "src", "lib.rs")).read()
+    ffi_rs = open(os.path.join(ROOT, "shim", "bellman-hip", "src", "ffi.rs")).read()
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    # context methods the patched bellman calls on bellman_hip::Context
+    for m in set(re.findall(r"\bctx\.(\w+)\(", added)):
+        assert re.search(r"pub fn %s\b" % m, lib_rs), "bellman_hip::Context::%s missing" % m
+    for name in set(re.findall(r"bellman_hip::(\w+)", added)):
+        if name[0].islower():
+            assert re.search(r"pub fn %s\b" % name, lib_rs), name
+        else:
+            assert re.search(r"pub (struct|enum) %s\b" % name, lib_rs), name
+    # functions of bellman::hip the patched prover.rs uses exist in the patched src/hip.rs
+    hip_rs = added[added.index("//! Routes the BLS12-381 instantiations"):]
+    for f in set(re.findall(r"\bdev::(\w+)", added)):
+        assert re.search(r"pub fn %s\b" % f, hip_rs), "bellman::hip::%s missing" % f
+    for fn in set(re.findall(r"ffi::(bh_\w+)\(", lib_rs)):
+        assert "pub fn %s(" % fn in ffi_rs, fn
+    # an unwaited job is waited for when dropped (create_proof drops the remaining Waiters on an early `?`)
+    assert "impl Drop for MsmJob" in lib_rs and "impl Drop for Scalars" in lib_rs
+    # `#[cfg]` never sits directly on an `if` (attributes on if-expressions are rejected by rustc)
+    assert not re.search(r"#\[cfg\([^\n]*\)\]\n\+?\s*if ", added)

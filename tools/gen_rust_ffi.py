@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "bellman_hip.h")
 OUT = os.path.join(ROOT, "shim", "bellman-hip", "src", "ffi.rs")
 
-OPAQUE = {"bh_ctx": "BhCtx", "bh_bases": "BhBases", "bh_msm_job": "BhMsmJob", "bh_params": "BhParams", "bh_r1cs": "BhR1cs"}
-STRUCTS = {"bh_csr": "BhCsr", "bh_msm_opts": "BhMsmOpts"}
+OPAQUE = {"bh_ctx": "BhCtx", "bh_bases": "BhBases", "bh_msm_job": "BhMsmJob", "bh_params": "BhParams", "bh_r1cs": "BhR1cs",
+          "bh_scalars": "BhScalars", "bh_msm_sharded_job": "BhMsmShardedJob", "bh_proof_job": "BhProofJob"}
+STRUCTS = {"bh_csr": "BhCsr", "bh_msm_opts": "BhMsmOpts", "bh_ctx_info_t": "BhCtxInfo"}
 SCALAR = {
     "int": "c_int", "unsigned": "c_uint", "unsigned int": "c_uint", "long": "c_long", "uint32_t": "u32", "uint64_t": "u64",
-    "size_t": "usize", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
+    "int32_t": "i32", "size_t": "usize", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void",
 }
 
 
@@ -26,14 +27,13 @@ def strip_comments(text):
 def c_type_to_rust(ctype):
     """'const uint64_t *' -> '*const u64' ; 'bh_bases **' -> '*mut *mut BhBases'"""
     t = ctype.strip()
-    stars = t.count("*")
-    t = t.replace("*", " ").strip()
-    const = False
-    words = t.split()
-    if words and words[0] == "const":
-        const = True
-        words = words[1:]
-    base = " ".join(words)
+    # base type (with its own leading const), then one `*` per pointer level, each optionally followed by `const`
+    # ("bh_ctx *const *": pointer to const pointer to BhCtx -> *const *mut BhCtx)
+    m = re.match(r"^(const\s+)?([A-Za-z_][\w ]*?)\s*((?:\*\s*(?:const\s*)?)*)$", t)
+    if not m:
+        raise ValueError("unknown C type %r" % ctype)
+    const, base = bool(m.group(1)), " ".join(m.group(2).split())
+    levels = re.findall(r"\*\s*(const)?", m.group(3))
     if base in OPAQUE:
         r = OPAQUE[base]
     elif base in STRUCTS:
@@ -42,12 +42,14 @@ def c_type_to_rust(ctype):
         r = SCALAR[base]
     else:
         raise ValueError("unknown C type %r" % ctype)
-    if stars == 0:
+    if not levels:
         return r
-    # innermost pointer carries the constness, outer ones are out-parameters
-    out = ("*const " if const else "*mut ") + r
-    for _ in range(stars - 1):
-        out = "*mut " + out
+    # the pointee of level k is const when the qualifier to its left says so: the base's `const` for the innermost
+    # pointer, the `const` after the previous `*` for the others; an unqualified outer pointer is an out-parameter
+    quals = [const] + [bool(q) for q in levels[:-1]]
+    out = r
+    for q in quals:
+        out = ("*const " if q else "*mut ") + out
     return out
 
 
@@ -97,6 +99,12 @@ def render(decls):
         "/// `bh_msm_opts`: per-job plan overrides; all-zero = tuned defaults",
         "#[repr(C)]", "#[derive(Clone, Copy, Default)]",
         "pub struct BhMsmOpts {", "    pub window_bits: u32,", "    pub chunk: u32,", "    pub flags: u32,", "}",
+        "/// `bh_ctx_info_t`: what bh_ctx_info reports about a context",
+        "#[repr(C)]", "#[derive(Clone, Copy, Default, Debug)]",
+        "pub struct BhCtxInfo {", "    pub device: i32,", "    pub num_cus: u32,", "    pub hbm_bytes: u64,",
+        "    pub hw_queues_requested: u32,", "    pub hw_queues_set_before_hip_init: u32,", "    pub max_jobs_in_flight: u32,",
+        "    pub jobs_in_flight: u32,", "    pub pool_bytes_held: u64,", "    pub pool_bytes_idle: u64,", "    pub table_bytes: u64,",
+        "    pub table_budget: u64,", "}",
         "",
     ]
     consts = [("BH_OK", 0), ("BH_ERR_UNEXPECTED_IDENTITY", 1), ("BH_ERR_UNEXPECTED_EOF", 2), ("BH_ERR_DEGREE_TOO_LARGE", 3),
