@@ -27,6 +27,8 @@ int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 ski
                     int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
 void msm_job_track(MsmJobImpl &job);
+bool msm_slot_try_reserve(Context &c);
+void msm_slot_release(Context &c);
 bool msm_complete_oldest(Context &c);
 size_t msm_jobs_in_flight(Context &c);
 hipStream_t msm_job_stream(MsmJobImpl &job);
@@ -830,16 +832,17 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   // back-pressure (src/multicore.rs:47-73): at the cap the issuing thread completes the oldest job itself
-  while (msm_jobs_in_flight(ctx->c) >= ctx->c.max_jobs)
-    if (!msm_complete_oldest(ctx->c)) break;
+  while (!msm_slot_try_reserve(ctx->c))
+    if (!msm_complete_oldest(ctx->c)) std::this_thread::yield();   // the slots are held by calls still issuing
   MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);
-  if (!impl) return BH_ERR_HIP;
+  if (!impl) { msm_slot_release(ctx->c); return BH_ERR_HIP; }
   if (n && n <= TINY_MSM_MAX && scalars_on_host && (!density || density_on_host) && !(opts.flags & BH_MSM_NO_SMALL_PATH) &&
       !shard_ref_n) {
     int trc = BH_OK;
     alignas(16) unsigned char res[192];
     if (tiny_msm_on_host(bases, skip, scalars, n, fmt, density, &trc, res)) {
       msm_job_set_result(*impl, trc, trc == BH_OK ? res : nullptr);
+      msm_job_track(*impl);   // trivial: only gives the slot back
       *out = new bh_msm_job{impl};
       return BH_OK;
     }
@@ -875,6 +878,7 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     unsigned char dummy[192];
     (void)msm_job_finish(*impl, dummy, ms);
     msm_job_delete(impl);
+    msm_slot_release(ctx->c);
     return rc;
   }
   msm_job_track(*impl);

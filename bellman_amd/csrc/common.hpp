@@ -161,6 +161,7 @@ struct Context {
   // workspace pool cannot serve an allocation, the issuing thread COMPLETES the oldest job itself (stream
   // synchronise + host tail; the result is kept in the job for its bh_msm_wait) instead of failing.
   std::list<struct MsmJobImpl *> inflight;
+  uint32_t issuing = 0;           // slots reserved by calls that are between the cap check and msm_job_track (job_mu)
   uint32_t max_jobs = 64;
   size_t hbm_total = 0, table_bytes = 0, table_budget = 0;   // window tables built automatically stay below the budget
   std::vector<struct ::bh_bases *> tables;                     // handles that own an automatically built table (job_mu)

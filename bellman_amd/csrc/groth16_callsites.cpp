@@ -54,7 +54,10 @@ struct ScalarsHandle {
 };
 // wait order of prover.rs:339-354: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
 enum { A_IN, A_AUX, B1_IN, B1_AUX, B2_IN, B2_AUX, H, L };
-MsmSums wait_all(Jobs &jobs) {
+MsmSums wait_all(Jobs &jobs, const Parameters &p) {
+  // prover.rs:320-324 sits between the last multiexp call and the first wait()
+  if (p.vk.delta_g1.is_identity() || p.vk.delta_g2.is_identity())
+    throw SynthesisError(BH_ERR_UNEXPECTED_IDENTITY, "UnexpectedIdentity");
   MsmSums m;
   int rcs[8];
   rcs[0] = jobs.wait(A_IN, &m.a_in); rcs[1] = jobs.wait(A_AUX, &m.a_aux);
@@ -83,7 +86,7 @@ MsmSums issue_patched(Parameters &p, const CallSiteInputs &in) {
   check(bh_msm_async_scalars(ctx, p.b_g2, b_in_total, aux.s, 0, in.n_aux, in.b_aux_density, in.n_aux, nullptr, &jobs.j[B2_AUX]));
   check(bh_h_poly_fr_scalars(ctx, in.a, in.b, in.c, in.n_cons, &h.s));
   check(bh_msm_async_scalars(ctx, p.h, 0, h.s, 0, bh_scalars_len(h.s), nullptr, 0, nullptr, &jobs.j[H]));
-  return wait_all(jobs);
+  return wait_all(jobs, p);
 }
 
 // ---- mode 0 ----------------------------------------------------------------------------------------------------------
@@ -163,7 +166,7 @@ MsmSums issue_unpatched_prover(Parameters &p, const CallSiteInputs &in) {
   multiexp(p.b_g1, b_in_total, aux_exps, in.b_aux_density, B1_AUX);     // :302-307
   multiexp(p.b_g2, 0, in_exps, in.b_input_density, B2_IN);              // :312-317
   multiexp(p.b_g2, b_in_total, aux_exps, in.b_aux_density, B2_AUX);     // :318
-  return wait_all(jobs);
+  return wait_all(jobs, p);
 }
 }  // namespace
 

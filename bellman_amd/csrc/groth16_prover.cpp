@@ -380,14 +380,17 @@ static Proof prove_core(const AssignmentSource &src, Parameters &params, const F
   std::thread blind_thread([&] {
     try { blind = blind_terms(params, r, s); } catch (...) { blind_err = std::current_exception(); }
   });
+  std::exception_ptr msm_err;
   try {
     msm_sums(src, params, 0, 1, sums, tm, nullptr);
   } catch (...) {
-    blind_thread.join();
-    throw;
+    msm_err = std::current_exception();   // every job has been drained by now (JobSet)
   }
   blind_thread.join();
+  // prover.rs:320-324 returns UnexpectedIdentity for an identity delta BEFORE any multiexp is waited on: that error
+  // takes precedence over whatever a multiexp reports (e.g. UnexpectedEof from a short query)
   if (blind_err) std::rethrow_exception(blind_err);
+  if (msm_err) std::rethrow_exception(msm_err);
   Proof p = finish_proof(blind, sums, r, s);
   if (tm) tm->total_ms = (float)(now_ms() - t0);
   return p;

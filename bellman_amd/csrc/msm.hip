@@ -112,10 +112,22 @@ static void msm_job_complete_locked(MsmJobImpl &job) {
   job.done_rc = job.group == BH_G1 ? msm_finish_g1(job, job.done_out, job.done_ms) : msm_finish_g2(job, job.done_out, job.done_ms);
   job.done = true;
 }
+// reserves a slot under the context's job cap: true = reserved (release it with msm_job_track / msm_slot_release)
+bool msm_slot_try_reserve(Context &c) {
+  std::lock_guard<std::mutex> g(c.job_mu);
+  if (c.inflight.size() + c.issuing >= c.max_jobs) return false;
+  c.issuing++;
+  return true;
+}
+void msm_slot_release(Context &c) {
+  std::lock_guard<std::mutex> g(c.job_mu);
+  if (c.issuing) c.issuing--;
+}
+// the issued job takes the slot its caller reserved
 void msm_job_track(MsmJobImpl &job) {
-  if (job.trivial) return;
   std::lock_guard<std::mutex> g(job.ctx->job_mu);
-  job.ctx->inflight.push_back(&job);
+  if (job.ctx->issuing) job.ctx->issuing--;
+  if (!job.trivial) job.ctx->inflight.push_back(&job);
 }
 static void msm_job_untrack(MsmJobImpl &job) {
   std::lock_guard<std::mutex> g(job.ctx->job_mu);

@@ -28,8 +28,11 @@ class EvaluationDomain:
             exp += 1
             if exp >= FR_S:
                 raise PolynomialDegreeTooLarge()
-        padded = np.zeros((m, 4), dtype=np.uint64)
-        padded[: coeffs.shape[0]] = coeffs
+        if coeffs.shape[0] == m:
+            padded = coeffs   # already a full domain: no second host copy (8 GiB at 2^28)
+        else:
+            padded = np.zeros((m, 4), dtype=np.uint64)
+            padded[: coeffs.shape[0]] = coeffs
         dev = worker.alloc(m * 32)
         worker.upload(dev, padded)
         return cls(worker, dev, m, exp)

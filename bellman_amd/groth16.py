@@ -227,6 +227,20 @@ class Parameters:
         check(lib.bh_bases_download(self.worker.ctx, b, 0, n.value, out.ctypes.data_as(ctypes.c_void_p)), "Parameters.query")
         return out
 
+    def bases(self, which):
+        """the device-resident query itself as a (borrowed) Bases handle: get_h / get_l / get_a / get_b_g1 / get_b_g2 of
+        ParameterSource (groth16/src/lib.rs:443-473) without the offset - for multiexps issued by the caller"""
+        from .multiexp import Bases
+
+        idx = ("h", "l", "a", "b_g1", "b_g2").index(which)
+        b, n = ctypes.c_void_p(), ctypes.c_size_t()
+        check(_lib.load().bh_groth16_params_query(self._h, idx, ctypes.byref(b), ctypes.byref(n)), "Parameters.bases")
+        hb = Bases.__new__(Bases)
+        hb.worker, hb.group, hb.n = self.worker, 2 if idx == 4 else 1, n.value
+        hb._h = b
+        hb.release = lambda: None   # owned by the parameters
+        return hb
+
     def vk(self):
         """alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2 as affine Montgomery records"""
         outs = [np.zeros(w, dtype=np.uint64) for w in (12, 12, 24, 12, 24)]

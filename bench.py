@@ -147,6 +147,43 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     conc_r = threads * per_thread / (time.perf_counter() - t0)
     assert last_r.a.tobytes() == last.a.tobytes() and last_r.b.tobytes() == last.b.tobytes() and \
         last_r.c.tobytes() == last.c.tobytes(), "device-evaluated constraints gave a different proof"
+    # The drop-in as a patched bellman drives it (shim/patches/bellman-hip.patch; the C calls are issued by the C++
+    # transcription csrc/groth16_callsites.cpp - no Rust toolchain here): the h block + eight multiexps of
+    # prover.rs:217-318 on an assignment synthesised beforehand (synthesis is the same host work in every variant),
+    # (a) with groth16/src/prover.rs patched, (b) with only multiexp.rs / domain.rs patched; (c) the mirror's own
+    # bh_groth16_prove_assignment.  All three must give the same proof.
+    asg = pg.demo_assignment(1, rounds, CIRCUIT_SEED, [987654321 + proofs])
+    call_sites = {}
+    ref_tm = []
+    for i in range(proofs + 1):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        ref_proof = pg.prove_assignment_arrays(params, asg, 0xABCDEF0123 + proofs, 0x123456789AB, tm)
+        if i:
+            ref_tm.append((time.perf_counter() - t0) * 1e3)
+    assert ref_proof.a.tobytes() == last.a.tobytes() and ref_proof.b.tobytes() == last.b.tobytes() and \
+        ref_proof.c.tobytes() == last.c.tobytes()
+    for name, patched in (("create_proof_via_patched_call_sites", True), ("create_proof_via_multiexp_and_fft_call_sites_only", False)):
+        ws = []
+        for i in range(proofs + 1):
+            t0 = time.perf_counter()
+            got = pg.prove_via_call_sites(params, asg, 0xABCDEF0123 + proofs, 0x123456789AB, patched)
+            if i:
+                ws.append((time.perf_counter() - t0) * 1e3)
+        assert got.a.tobytes() == last.a.tobytes() and got.b.tobytes() == last.b.tobytes() and got.c.tobytes() == last.c.tobytes(), \
+            name + ": proof differs from bh_groth16_prove_assignment"
+        call_sites[name] = {"ms_after_synthesis": round(float(np.mean(ws)), 2), "proofs_per_s_after_synthesis": round(1e3 / float(np.mean(ws)), 3),
+                            "samples": proofs}
+    call_sites["create_proof_via_patched_call_sites"]["calls"] = (
+        "groth16/src/prover.rs patched: bh_scalars_register x2 (Montgomery, shared by the multiexps that use them), "
+        "bh_msm_async_scalars x8, bh_h_poly_fr_scalars x1 (h coefficients stay in HBM), bh_msm_wait x8; host tail prover.rs:320-360")
+    call_sites["create_proof_via_multiexp_and_fft_call_sites_only"]["calls"] = (
+        "only src/multiexp.rs + src/domain.rs patched: 7 x bh_fft_fr on host vectors (upload + download each), mul/sub/divide_by_z "
+        "on the host (one chunk per host thread), serial Fr -> Exponent passes (prover.rs:241-261), 8 x bh_msm_async with "
+        "canonical host scalars (each uploads its vector again)")
+    call_sites["bh_groth16_prove_assignment_same_inputs"] = {"ms_after_synthesis": round(float(np.mean(ref_tm)), 2)}
+    call_sites["note"] = ("all three proofs asserted bit-identical; host synthesis (ms_host_synthesis above) precedes each of them "
+                          "in a real create_proof")
     cpu = None
     if cpu_baseline:
         h, l, a, b1, b2 = (params.query(q) for q in ("h", "l", "a", "b_g1", "b_g2"))
@@ -191,6 +228,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "concurrent_host_threads": threads,
         "samples": proofs,
         "cpu_baseline": cpu,
+        "drop_in_call_sites": call_sites,
         "crs": "generate_parameters on the device from fixed toxic waste: %.0f ms (h, l, a, b_g1, b_g2 = %d G1 + %d G2 "
                "fixed-base multiplications, 1 iFFT, transposed sparse product); Parameters::write %.0f ms (%.0f MB, host "
                "encoding); Parameters::read(checked) %.0f ms / (unchecked) %.0f ms incl. the host-to-device copy - decoding, "
@@ -207,6 +245,46 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
             "proofs_per_s_concurrent": round(conc_r, 3),
         },
     }
+
+
+def bench_create_proof_c5(worker, log_n=24):
+    """BASELINE config C5's proof leg on ONE GPU: create_proof at 2^24 constraints (R1CS resident, CRS from the device
+    generator).  One sample after one warm-up; the parts == single and pairing checks live in tests/test_gpu_scale.py."""
+    from bellman_amd import groth16 as pg
+
+    rounds = (1 << log_n) - 3
+    seed = 2024
+    t0 = time.perf_counter()
+    r1cs = pg.R1CS.from_demo(worker, 1, rounds, seed)
+    capture_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+    generate_s = time.perf_counter() - t0
+    out = []
+    for i in range(2):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        proof = pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, seed, [55555 + i], None, 0xC5C5 + i, 0x5C5C, tm)
+        out.append((tm, (time.perf_counter() - t0) * 1e3))
+    tm, wall = out[1]
+    # sliced over 2 "ranks" on this one GPU: the fold must be the same proof (what N = 2 would assemble)
+    total = None
+    for part in range(2):
+        sums = pg.prove_demo_part(params, r1cs, 1, rounds, seed, [55555 + 1], None, part, 2)
+        total = sums if total is None else pg.sums_add(total, sums)
+    folded = pg.assemble(params, total, 0xC5C5 + 1, 0x5C5C)
+    assert folded.a.tobytes() == proof.a.tobytes() and folded.b.tobytes() == proof.b.tobytes() and folded.c.tobytes() == proof.c.tobytes(), \
+        "2-part proof differs from the single-GPU proof"
+    r1cs.release()
+    params.release()
+    worker.trim()
+    return {"workload": "groth16::create_proof, 2^%d constraints (BASELINE.json configs[4], proof leg), one GPU, R1CS resident; "
+                        "h query 2^%d G1 points, b_g2 query 2^%d G2 points (classic 16-window plan: no window table above 2^22)"
+                        % (log_n, log_n, log_n - 1),
+            "ms_total": round(wall, 1), "ms_host_witness": round(float(tm[0]), 1), "ms_gpu_part": round(wall - float(tm[0]), 1),
+            "proofs_per_s": round(1e3 / wall, 3), "samples": 1,
+            "check": "fold of the 2-part proof (prove_witness_part x2 + sums_add + assemble) == this proof",
+            "setup_s": {"r1cs_capture": round(capture_s, 1), "generate_parameters": round(generate_s, 1)}}
 
 
 def bench_create_proof_sharded(worker, log_n, world, rank, coll_dev, proofs=3):
@@ -297,7 +375,7 @@ def bench_msm_shape(worker, lib, group, log_n, iters=10):
     worker.upload(dt, t)
     assert lib.bh_fixed_base_mul_dev(worker.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
     worker.synchronize()
-    bases = bellman_amd.Bases.wrap_device(worker, group, dout, n)
+    bases = bellman_amd.Bases.copy_device(worker, group, dout, n)   # registered like a CRS query (automatic window table)
     sc = splitmix_scalars(n, 0x5CA1A + group)
     worker.upload(dt, sc)
     walls, stages = [], []
@@ -418,6 +496,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proof", action="store_true", help="skip the create_proof (config C4) measurement")
     ap.add_argument("--proof-log-n", type=int, default=20)
+    ap.add_argument("--c5-proof-log-n", type=int, default=24, help="N = 1: size of the C5 proof leg (0 = skip)")
     ap.add_argument("--c5-log-n", type=int, default=26,
                     help="N > 1 only: total size of the extra sharded MSM of BASELINE configs[4] (0 = skip)")
     ap.add_argument("--check-log-n", type=int, default=12,
@@ -435,6 +514,9 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     distributed = world > 1
+    # BENCH_FORCE_COLLECTIVE=1 at N = 1 (under torch.distributed.run): init the process group and run the per-step
+    # all-gather + fold anyway - executes the RCCL code path on a single-GPU box (tests/test_gpu_round3.py)
+    collective = distributed or (os.environ.get("BENCH_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback in bellman_amd)")
     # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share one GPU to smoke-test the N>1
@@ -443,7 +525,7 @@ def main():
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if distributed:
+    if collective:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -475,7 +557,7 @@ def main():
         w = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s_dev.data_ptr()),
                                  n=n, timed=True)
         part, ms = w.wait()
-        if distributed:   # one 96-byte all-gather over RCCL + local fold (bellman_amd/sharding.py)
+        if collective:   # one 96-byte all-gather over RCCL + local fold (bellman_amd/sharding.py)
             return sharding.fold_partials(part, 1, device=coll_dev if coll_dev == "cuda" else None), ms
         return part, ms
 
@@ -483,7 +565,7 @@ def main():
         result, _ = step()
 
     def barrier():
-        if distributed:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -498,7 +580,7 @@ def main():
         stage += np.array(ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    if distributed:
+    if collective:
         tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -596,6 +678,7 @@ def main():
                 "workload": "G1 Pippenger MSM, 2^%d (base,scalar) terms per GPU, FullDensity, inputs resident in HBM "
                             "(BASELINE.json configs[1])" % args.log_n,
                 "sharding": "bases split across ranks, one 96-B all-gather per step" if distributed else "single GPU",
+                "collective": ("%s%s world_size=%d" % (backend, " (RCCL)" if backend == "nccl" else "", world)) if collective else None,
                 "device_ms": {"pipeline": round(float(stage[0]), 4), "digits_sort": round(float(stage[1]), 4),
                               "bucket_accumulate": round(acc_ms, 4), "merge_reduce": round(float(stage[3]), 4)},
                 "headline": "`value` = terms of all ranks / wall time of the K timed steps (mean, the driver's contract), scalars and "
@@ -663,6 +746,8 @@ def main():
             out["create_proof_mimc"] = bench_mimc(worker, cpu_baseline=not args.no_cpu_baseline)
             out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
+            if args.c5_proof_log_n:
+                out["create_proof_c5"] = bench_create_proof_c5(worker, args.c5_proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of this same command
         # (tools/gpu_final.sh -> profiles/r2_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
         # read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte
@@ -681,7 +766,7 @@ def main():
                     "bound - uncorrected: %d) + WRITE_SIZE %d; algorithmic 128 B x 2^20 = %d" % (name, int(fetch + write), int(write), 128 << 20))
             break
         print(json.dumps(out), flush=True)
-    if distributed:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     worker.close()

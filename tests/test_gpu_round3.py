@@ -1,0 +1,402 @@
+"""GPU parity of what round 3 added to the boundary (run with `pytest -m gpu` on a MI355X):
+
+  * the reference's call sites as the patched Rust issues them (shim/patches/bellman-hip.patch, transcribed in
+    csrc/groth16_callsites.cpp): with groth16/src/prover.rs patched and without -> the same proof as
+    bh_groth16_prove_assignment / the oracle (groth16/src/prover.rs:217-360);
+  * scalar vectors registered once and shared by several multiexps (prover.rs:267-318);
+  * ONE multiexp over several contexts of one process (src/multicore.rs:21-92 is a single process), incl. density,
+    skip and the EOF / identity precedence of src/multiexp.rs:295-300 across shard boundaries;
+  * back-pressure: 64 concurrent 2^20-term multiexps under a capped workspace pool / a job cap all complete
+    (src/multicore.rs:47-73);
+  * wrapped device buffers are live views; the RCCL code path of bellman_amd/sharding.py on one GPU (world size 1).
+Integer work: every limb equal, no tolerances."""
+
+import ctypes
+import os
+import random
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cref  # noqa: E402
+from oracle.cengine import CBls12  # noqa: E402
+from oracle.pyref.generator import generate_parameters  # noqa: E402
+from tests import circuits  # noqa: E402
+from tests.test_gpu_groth16 import TOXIC, _chain_setup, _product_params, _same, worker  # noqa: E402,F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = circuits.Q
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the drop-in as patched
+# ---------------------------------------------------------------------------------------------------------------------
+def test_call_sites_mimc_322(worker):
+    """C1 through the call sequences of the patched bellman (both patch levels) == create_proof == the oracle"""
+    from bellman_amd import groth16 as pg
+    from oracle.pyref.prover import create_proof as oracle_create_proof
+
+    rnd = random.Random(3220)
+    cons = [rnd.randrange(Q) for _ in range(circuits.MIMC_ROUNDS)]
+    xl, xr, r, s = (rnd.randrange(Q) for _ in range(4))
+    p = generate_parameters(CBls12, circuits.mimc_circuit(0, 0, cons), CBls12.G1.gen, CBls12.G2.gen, **TOXIC)
+    want = oracle_create_proof(CBls12, circuits.mimc_circuit(xl, xr, cons), p, r, s)
+    pp = _product_params(worker, p)
+    asg = pg.demo_assignment(0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons)
+    assert asg["a"].shape[0] == 646 and asg["aux_assignment"].shape[0] == 645
+    for patched in (True, False):
+        tm = [0, 0]
+        got = pg.prove_via_call_sites(pp, asg, r, s, patched, tm)
+        assert _same(got, want.a, want.b, want.c), patched
+    assert _same(pg.prove_assignment_arrays(pp, asg, r, s), want.a, want.b, want.c)
+
+
+@pytest.mark.parametrize("rounds", [1, 61, 4093, (1 << 16) - 3])
+def test_call_sites_chain_circuit(worker, rounds):
+    from bellman_amd import groth16 as pg
+
+    seed, x0, r, s = 11 + rounds, 424242, 0x1234567 + rounds, 0x7654321
+    pp, vk, _ = _chain_setup(worker, rounds, seed)
+    asg = pg.demo_assignment(1, rounds, seed, [x0])
+    want = pg.create_proof_demo(pp, 1, rounds, seed, [x0], None, r, s)   # pinned to the oracle in test_gpu_groth16.py
+    got_ref = pg.prove_assignment_arrays(pp, asg, r, s)
+    assert _same(got_ref, want.a, want.b, want.c)
+    for patched in (True, False):
+        got = pg.prove_via_call_sites(pp, asg, r, s, patched)
+        assert _same(got, want.a, want.b, want.c), patched
+
+
+def test_call_sites_error_paths(worker):
+    """a short query -> UnexpectedEof through both call sequences, every job still waited on"""
+    from bellman_amd import UnexpectedEof
+    from bellman_amd import groth16 as pg
+
+    rounds, seed, x0 = 200, 5, 77
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l[:-3], a, b1, b2)
+    asg = pg.demo_assignment(1, rounds, seed, [x0])
+    for patched in (True, False):
+        with pytest.raises(UnexpectedEof):
+            pg.prove_via_call_sites(short, asg, 5, 6, patched)
+    assert worker.info()["jobs_in_flight"] == 0
+    # an identity delta is reported before any multiexp is waited on (prover.rs:320-324): it wins over the EOF
+    from bellman_amd import UnexpectedIdentity
+
+    zero1 = np.zeros(12, dtype=np.uint64)
+    both = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], zero1, vk["delta_g2"], h, l[:-3], a, b1, b2)
+    with pytest.raises(UnexpectedIdentity):
+        pg.create_proof_demo(both, 1, rounds, seed, [x0], None, 5, 6)
+    for patched in (True, False):
+        with pytest.raises(UnexpectedIdentity):
+            pg.prove_via_call_sites(both, asg, 5, 6, patched)
+    assert worker.info()["jobs_in_flight"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scalars registered once
+# ---------------------------------------------------------------------------------------------------------------------
+def test_registered_scalars_shared_by_multiexps(worker):
+    import bellman_amd
+
+    n = 5000
+    sc = cref.random_fr(n, 31)
+    sc[3] = 0
+    sc[4] = cref.ints_to_arr([1], 4)[0]
+    rnd = np.random.default_rng(32)
+    bits = rnd.random(n) < 0.6
+    g1 = cref.gen_bases(1, n + 7, a=3, b=5)
+    g2 = cref.gen_bases(2, int(bits.sum()) + 2, a=4, b=9)
+    hb1, hb2 = bellman_amd.Bases(worker, 1, g1), bellman_amd.Bases(worker, 2, g2)
+    for mont in (False, True):
+        host = cref.fr_to_mont(sc) if mont else sc
+        reg = bellman_amd.Scalars(worker, host, mont=mont)
+        dt = bellman_amd.DensityTracker()
+        dt.bv = bits
+        jobs = [bellman_amd.multiexp_scalars(worker, hb1, bellman_amd.FullDensity(), reg, skip=7),
+                bellman_amd.multiexp_scalars(worker, hb2, dt, reg, skip=2),
+                bellman_amd.multiexp_scalars(worker, hb1, bellman_amd.FullDensity(), reg, skip=0, first=1000, n=3000)]
+        want = [cref.multiexp(1, g1, 7, None, sc), cref.multiexp(2, g2, 2, cref.density_bitmap(bits), sc),
+                cref.multiexp(1, g1, 0, None, sc[1000:4000])]
+        for j, (rc, w) in zip(jobs, want):
+            assert rc == 0 and np.array_equal(j.wait(), w)
+        reg.release()
+    # out-of-range slices are refused
+    reg = bellman_amd.Scalars(worker, sc)
+    with pytest.raises(Exception):
+        bellman_amd.multiexp_scalars(worker, hb1, bellman_amd.FullDensity(), reg, first=n - 1, n=2)
+    reg.release()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one multiexp over several contexts of this process
+# ---------------------------------------------------------------------------------------------------------------------
+def _split(arr, cuts):
+    return [arr[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+
+
+@pytest.mark.parametrize("group,log_n,shards", [(1, 20, 2), (2, 16, 2), (1, 14, 3)])
+def test_sharded_multiexp_contexts_in_one_process(worker, group, log_n, shards):
+    """TWO (three) contexts on device 0, each holding a contiguous shard of the bases: the fold == ONE multiexp over
+    the whole vector - with FullDensity, and with a DensityTracker + skip whose dense entries cross the shard borders."""
+    import bellman_amd
+
+    n = 1 << log_n
+    workers = [worker] + [bellman_amd.Worker(0) for _ in range(shards - 1)]
+    try:
+        bases = cref.gen_bases(group, n + 5, a=7, b=3)
+        cuts = [0] + sorted(int(x) for x in np.random.default_rng(log_n).integers(1, n, shards - 1)) + [n + 5]
+        hs = [bellman_amd.Bases(w, group, piece) for w, piece in zip(workers, _split(bases, cuts))]
+        sc = cref.random_fr(n, 50 + log_n)
+        sc[1] = 0
+        threads = cref.lib().orc_max_threads()
+        # (1) FullDensity, skip = 5: issued through the C entry point from this thread
+        got = bellman_amd.multiexp_sharded(workers, hs, bellman_amd.FullDensity(), sc, skip=5).wait()
+        rc, want = cref.multiexp(group, bases, 5, None, sc, threads=threads)
+        assert rc == 0 and np.array_equal(got, want)
+        # (2) density + skip
+        bits = np.random.default_rng(log_n + 1).random(n) < 0.5
+        dt = bellman_amd.DensityTracker()
+        dt.bv = bits
+        got = bellman_amd.multiexp_sharded(workers, hs, dt, sc, skip=3).wait()
+        rc, want = cref.multiexp(group, bases, 3, cref.density_bitmap(bits), sc, threads=threads)
+        assert rc == 0 and np.array_equal(got, want)
+        # (3) the documented N-context pattern by hand: one host thread per context, each a plain multiexp over its
+        # shard, folded with bh_point_add
+        parts = [None] * shards
+        sc_cuts = [0] + [c - 5 for c in cuts[1:-1]] + [n]          # FullDensity, skip = 5: scalar i uses base 5 + i
+
+        def run(k):
+            sk = 5 if k == 0 else 0
+            parts[k] = bellman_amd.multiexp(workers[k], hs[k], bellman_amd.FullDensity(), sc[sc_cuts[k]:sc_cuts[k + 1]], skip=sk).wait()
+
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(shards)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        total = parts[0]
+        for p in parts[1:]:
+            total = bellman_amd.point_add(group, total, p)
+        rc, want = cref.multiexp(group, bases, 5, None, sc, threads=threads)
+        assert np.array_equal(total, want)
+        for h in hs:
+            h.release()
+    finally:
+        for w in workers[1:]:
+            w.close()
+
+
+def test_sharded_multiexp_error_semantics(worker):
+    """EOF can only come from the last shard; an identity base consumed in the reference's top window by ANY shard wins
+    over it (src/multiexp.rs:295-300); an identity under a zero scalar is skipped unseen - each case == the oracle's rc."""
+    import bellman_amd
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+
+    w2 = bellman_amd.Worker(0)
+    try:
+        n = 600
+        bases = cref.gen_bases(1, n, a=2, b=11)
+        sc = cref.random_fr(n, 77)
+
+        def run(b, s, skip=0):
+            hs = [bellman_amd.Bases(worker, 1, b[:250]), bellman_amd.Bases(w2, 1, b[250:])]
+            rc, want = cref.multiexp(1, b, skip, None, s)
+            try:
+                got = bellman_amd.multiexp_sharded([worker, w2], hs, bellman_amd.FullDensity(), s, skip=skip).wait()
+                assert rc == 0 and np.array_equal(got, want)
+                return 0
+            except UnexpectedIdentity:
+                assert rc == 1
+                return 1
+            except UnexpectedEof:
+                assert rc == 2
+                return 2
+            finally:
+                for h in hs:
+                    h.release()
+
+        assert run(bases, sc) == 0
+        assert run(bases[:-10], sc) == 2                           # EOF in the last shard
+        b = bases.copy()
+        b[100] = 0                                                  # identity in the FIRST shard, full-size scalar
+        assert run(b, sc) == 1
+        assert run(b[:-10], sc) == 1                                # ... with an EOF later: top-window identity first
+        s2 = sc.copy()
+        s2[100] = cref.ints_to_arr([5], 4)[0]                       # small scalar: not in the top window -> EOF wins
+        assert run(b[:-10], s2) == 2
+        s3 = sc.copy()
+        s3[100] = 0                                                 # zero scalar skips the identity unseen
+        assert run(b, s3) == 0
+        assert run(bases, sc, skip=1) == 2                          # skip pushes the last entry past the end
+    finally:
+        w2.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# back-pressure
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["pool_cap", "job_cap"])
+def test_64_concurrent_jobs_under_back_pressure(mode):
+    """64 multiexps of 2^20 G1 terms issued back to back from one thread (+ 2 more threads doing the same): with the
+    workspace pool capped at 3 GiB (~4 workspaces) or 4 jobs in flight, issuing completes the oldest job inline instead
+    of failing; every result equals the oracle's."""
+    import bellman_amd
+
+    w = bellman_amd.Worker(0)
+    try:
+        if mode == "pool_cap":
+            w.set_limits(max_jobs_in_flight=1000, pool_cap_bytes=3 << 30)
+        else:
+            w.set_limits(max_jobs_in_flight=4)
+        n = 1 << 20
+        t = cref.random_fr(n, 500)
+        gen = cref.g1_generator()
+        dt, dout = w.alloc(n * 32), w.alloc(n * 96)
+        w.upload(dt, t)
+        lib = w._lib
+        assert lib.bh_fixed_base_mul_dev(w.ctx, 1, _p(gen), dt, n, 0, dout, None) == 0
+        w.synchronize()
+        bases = bellman_amd.Bases.copy_device(w, 1, dout, n)
+        scs = [cref.random_fr(n, 600 + i) for i in range(2)]
+        want = [cref.point_mul(1, gen, cref.fr_dot(s, t)) for s in scs]
+        regs = [bellman_amd.Scalars(w, s) for s in scs]
+        peak = [0]
+
+        def burst(count):
+            jobs = []
+            for i in range(count):
+                jobs.append((i & 1, bellman_amd.multiexp_scalars(w, bases, bellman_amd.FullDensity(), regs[i & 1])))
+                peak[0] = max(peak[0], w.info()["jobs_in_flight"])
+            for which, j in jobs:
+                assert np.array_equal(j.wait(), want[which])
+
+        ts = [threading.Thread(target=burst, args=(16,)) for _ in range(2)]
+        [x.start() for x in ts]
+        burst(64)
+        [x.join() for x in ts]
+        info = w.info()
+        assert info["jobs_in_flight"] == 0
+        if mode == "pool_cap":
+            assert info["pool_bytes_held"] <= 3 << 30
+        else:
+            assert peak[0] <= 4
+        print(mode, "peak jobs in flight", peak[0], "pool held %.2f GiB" % (info["pool_bytes_held"] / 2**30))
+        for r in regs:
+            r.release()
+        bases.release()
+    finally:
+        w.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wrapped buffers, context info, RCCL
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [5, 3000])
+def test_wrapped_device_bases_are_a_live_view(worker, n):
+    """bh_bases_wrap_dev snapshots nothing: after the caller rewrites the buffer a multiexp over the same handle uses
+    the new contents - for a handful of terms (formerly answered from a host mirror) and for a table-eligible size."""
+    import bellman_amd
+
+    a, b = cref.gen_bases(1, n, a=3, b=4), cref.gen_bases(1, n, a=9, b=2)
+    sc = cref.random_fr(n, 12)
+    d = worker.alloc(n * 96)
+    worker.upload(d, a)
+    hb = bellman_amd.Bases.wrap_device(worker, 1, d, n)
+    assert hb.table_info() == (0, 0, 0)
+    assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), cref.multiexp(1, a, 0, None, sc)[1])
+    worker.upload(d, b)
+    assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc).wait(), cref.multiexp(1, b, 0, None, sc)[1])
+    hb.release()
+    worker.free(d)
+
+
+def test_fft_when_the_scratch_vector_cannot_be_had():
+    """a multi-pass transform needs a scratch vector of the same size: when the pool cannot provide it the entry point
+    returns BH_ERR_HIP (no partial transform, no CPU path) and the context stays usable"""
+    import bellman_amd
+
+    w = bellman_amd.Worker(0)
+    try:
+        data = cref.random_fr(1 << 20, 9)
+        d = bellman_amd.EvaluationDomain.from_coeffs(w, data)    # 32 MiB from the pool
+        w.set_limits(pool_cap_bytes=48 << 20)
+        with pytest.raises(Exception):
+            d.fft()
+        assert np.array_equal(d.as_ref(), data)                  # untouched
+        w.set_limits(pool_cap_bytes=0)
+        d.fft()
+        assert np.array_equal(d.into_coeffs(), cref.fft(data, cref.FFT, threads=16))
+    finally:
+        w.close()
+
+
+def test_ctx_info_and_table_budget(worker):
+    import bellman_amd
+
+    info = worker.info()
+    assert info["num_cus"] == 256 and info["hbm_bytes"] > 200 << 30
+    assert info["hw_queues_requested"] == 16 and info["hw_queues_set_before_hip_init"] == 1   # the loader asked in time
+    assert info["max_jobs_in_flight"] >= 8 and info["table_budget"] > 0
+    w = bellman_amd.Worker(0)
+    try:
+        pts = cref.gen_bases(2, 1 << 12, a=5, b=6)
+        hb = bellman_amd.Bases(w, 2, pts)
+        c, rows, nbytes = hb.table_info()
+        assert rows > 0 and w.info()["table_bytes"] == nbytes
+        w.set_limits(table_budget_bytes=0)
+        hb2 = bellman_amd.Bases(w, 2, pts)
+        assert hb2.table_info() == (0, 0, 0)                     # over budget: registered without a table
+        sc = cref.random_fr(1 << 12, 5)
+        want = cref.multiexp(2, pts, 0, None, sc)[1]
+        assert np.array_equal(bellman_amd.multiexp(w, hb, bellman_amd.FullDensity(), sc).wait(), want)
+        assert np.array_equal(bellman_amd.multiexp(w, hb2, bellman_amd.FullDensity(), sc).wait(), want)
+        w.trim()                                                  # drops the automatic table, the handle stays usable
+        assert hb.table_info() == (0, 0, 0) and w.info()["table_bytes"] == 0
+        assert np.array_equal(bellman_amd.multiexp(w, hb, bellman_amd.FullDensity(), sc).wait(), want)
+        hb.release()
+        hb2.release()
+    finally:
+        w.close()
+
+
+def test_rccl_code_path_world_size_one():
+    """The collective legs of bellman_amd/sharding.py with backend "nccl" (= RCCL) and CUDA tensors, on the one GPU of
+    this box: all_gather + fold of a partial result and of a proof's 960-byte sums, and bench.py's N = 1 launch through
+    torch.distributed.run with the collective forced on.  (N > 1 over xGMI is NOT measured in this repository.)"""
+    code = r"""
+import os, numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+import bellman_amd
+from bellman_amd import sharding, groth16 as pg
+from oracle import cref
+w = bellman_amd.Worker(0)
+n = 4096
+bases, sc = cref.gen_bases(1, n, a=1, b=1), cref.random_fr(n, 1)
+hb = bellman_amd.Bases(w, 1, bases)
+got = sharding.sharded_multiexp(w, hb, bellman_amd.FullDensity(), sc, 1, device="cuda")
+assert np.array_equal(got, cref.multiexp(1, bases, 0, None, sc)[1])
+sums = np.arange(120, dtype=np.uint64)
+assert np.array_equal(sharding.fold_sums(sums, device="cuda"), sums)
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 4.0
+dist.barrier(); dist.destroy_process_group(); w.close()
+print("RCCL_PATH_OK", torch.cuda.nccl.version())
+"""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--log-n", "12", "--no-proof",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, BENCH_FORCE_COLLECTIVE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert '"collective": "nccl' in line

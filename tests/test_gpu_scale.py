@@ -51,7 +51,7 @@ def _splitmix(n, seed):
     return splitmix_scalars(n, seed)
 
 
-def _device_bases(worker, group, t):
+def _device_bases(worker, group, t, table=False):
     """P_i = [t_i]G made on the device (bh_fixed_base_mul_dev; itself checked against the oracle's
     point_mul below and in test_gpu_parity.py) -> (Bases handle, host copy of the records)."""
     import bellman_amd
@@ -66,21 +66,25 @@ def _device_bases(worker, group, t):
     assert lib.bh_fixed_base_mul_dev(worker.ctx, group, _p(gen), dt, n, 0, dout, None) == 0
     worker.synchronize()
     worker.free(dt)
-    bases = bellman_amd.Bases.wrap_device(worker, group, dout, n)
+    bases = bellman_amd.Bases.wrap_device(worker, group, dout, n)   # a live view: no window table unless asked for
+    if table:
+        bases.precompute()
     host = bases.download()
     for i in (0, 1, n // 2, n - 1):   # spot-check the generator kernel against the oracle
         assert np.array_equal(host[i], cref.point_mul(group, gen, cref.limbs_to_int(t[i])))
     return bases, host, gen
 
 
-@pytest.mark.parametrize("group,log_n", [(1, 23), (1, 26), (2, 20), (2, 22)])
-def test_msm_c5_scale_matches_oracle(worker, group, log_n):
-    """multiexp over 2^log_n terms == restated multiexp_inner on all host cores, and == [sum s_i t_i]G."""
+@pytest.mark.parametrize("group,log_n,table", [(1, 23, False), (1, 26, False), (2, 20, False), (2, 22, True)])
+def test_msm_c5_scale_matches_oracle(worker, group, log_n, table):
+    """multiexp over 2^log_n terms == restated multiexp_inner on all host cores, and == [sum s_i t_i]G.  G2 2^20 runs the
+    classic 16-window plan (one lane per point, 2^19 buckets), G2 2^22 the window-table plan a registered CRS query gets."""
     import bellman_amd
 
     n = 1 << log_n
     t = _splitmix(n, 1000 + log_n)
-    bases, host_bases, gen = _device_bases(worker, group, t)
+    bases, host_bases, gen = _device_bases(worker, group, t, table)
+    assert (bases.table_info()[1] > 0) == table
     sc = _splitmix(n, 2000 + log_n)
     sc[1] = 0
     sc[2] = cref.ints_to_arr([1], 4)[0]
@@ -191,3 +195,114 @@ def test_proof_2_22_constraints_matches_oracle(worker):
     assert got.b.tobytes() == want[1].tobytes()
     assert got.c.tobytes() == want[2].tobytes()
     pp.release()
+
+
+def test_proof_2_24_config_c5(worker):
+    """BASELINE configs[4], proof leg: create_proof at 2^24 constraints on one GPU (CRS from the device generator, R1CS
+    resident).  (a) the proof satisfies the verification equation (oracle/pyref/pairing.py restates verify_proof,
+    groth16/src/verifier.rs:23-58) for the right public input only; (b) the proof assembled from 2 and from 8 parts
+    (prove_witness_part + sums_add + assemble: what 2 / 8 ranks compute) is the same proof; (c) its largest G2 multiexp -
+    b_g2 over 2^23 points, the first size without a window table: the classic 16-window plan with one lane per point in
+    accumulation AND reduction - equals the restated multiexp (src/multiexp.rs:210-332) on all host cores.
+    The full comparison with the restated prover is tools/check_proof_large.py 24 (profiles/r3_proof_2p24.txt)."""
+    import bellman_amd
+    from bellman_amd import groth16 as pg
+    from oracle.pyref import pairing
+    from tests.test_gpu_generator import _recs
+    from oracle.cengine import CBls12
+
+    log_n = 24
+    rounds = (1 << log_n) - 3
+    seed, x0, r, s = 2424, 31337, 0xABCDEF0123456789ABCDEF, 0x1234567890ABCDEF123
+    t0 = time.time()
+    r1cs = pg.R1CS.from_demo(worker, 1, rounds, seed)
+    g1, g2 = _recs(1, [CBls12.G1.gen])[0], _recs(2, [CBls12.G2.gen])[0]
+    params = pg.Parameters.generate(worker, r1cs, g1, g2, 48577, 22580, 53332, 5481, 3673)
+    t_setup = time.time() - t0
+    tm = [0, 0, 0, 0]
+    t0 = time.time()
+    proof = pg.create_proof_demo_r1cs(params, r1cs, 1, rounds, seed, [x0], None, r, s, tm)
+    t_proof = time.time() - t0
+    print("2^24 proof: setup %.1f s (capture + generate), proof %.0f ms wall, host ms [witness, h, msm, total] = %s"
+          % (t_setup, t_proof * 1e3, [round(x, 1) for x in tm]))
+    # (a) verification equation
+    asg = pg.demo_assignment(1, rounds, seed, [x0])
+    image = cref.arr_to_ints(cref.fr_from_mont(asg["input_assignment"][1:2]))[0]
+    alpha_g1, _, beta_g2, _, delta_g2 = params.vk()
+    gamma_g2, ic = params.vk_ext()
+    vk = dict(alpha_g1=cref.g1_to_py(alpha_g1)[0], beta_g2=cref.g2_to_py(beta_g2)[0], gamma_g2=cref.g2_to_py(gamma_g2)[0],
+              delta_g2=cref.g2_to_py(delta_g2)[0], ic=cref.g1_to_py(ic))
+    pr = (cref.g1_to_py(proof.a)[0], cref.g2_to_py(proof.b)[0], cref.g1_to_py(proof.c)[0])
+    assert pairing.verify_proof(vk, pr, [image])
+    assert not pairing.verify_proof(vk, pr, [(image + 1) % cref.Q])
+    # (b) parts
+    for parts in (2, 8):
+        total = None
+        for part in range(parts):
+            sums = pg.prove_demo_part(params, r1cs, 1, rounds, seed, [x0], None, part, parts)
+            total = sums if total is None else pg.sums_add(total, sums)
+        folded = pg.assemble(params, total, r, s)
+        assert folded.a.tobytes() == proof.a.tobytes() and folded.b.tobytes() == proof.b.tobytes() and \
+            folded.c.tobytes() == proof.c.tobytes(), parts
+    # (c) the b_g2 multiexp of this proof against the oracle
+    hb = params.bases("b_g2")
+    assert len(hb) > (1 << 22) and hb.table_info()[1] == 0          # no window table: the classic plan
+    n_aux = asg["aux_assignment"].shape[0]
+    bits = np.unpackbits(asg["b_aux_density"].view(np.uint8), bitorder="little")[:n_aux].astype(bool)
+    b_in_total = int(np.unpackbits(asg["b_input_density"].view(np.uint8), bitorder="little")[:2].sum())
+    dt = bellman_amd.DensityTracker()
+    dt.bv = bits
+    got, ms = bellman_amd.multiexp(worker, hb, dt, asg["aux_assignment"], skip=b_in_total, mont=True, timed=True).wait()
+    b2_host = params.query("b_g2")
+    t0 = time.time()
+    rc, want = cref.multiexp(2, b2_host, b_in_total, cref.density_bitmap(bits), cref.fr_from_mont(asg["aux_assignment"]),
+                             threads=cref.lib().orc_max_threads())
+    print("b_g2 multiexp (2^23 points, classic plan): device %.1f ms [sort %.1f, accumulate %.1f, reduce %.1f]; oracle %.1f s"
+          % (ms[0], ms[1], ms[2], ms[3], time.time() - t0))
+    assert rc == 0 and np.array_equal(got, want)
+    r1cs.release()
+    params.release()
+    worker.trim()
+
+
+@pytest.mark.parametrize("log_n", [26, 28])
+def test_fft_above_2_25(worker, log_n):
+    """EvaluationDomain at 2^26 ... 2^28 (src/domain.rs:57-59 allows up to 2^31; three passes, 2 - 8 GiB vectors; the
+    restated best_fft is too slow here, so the checks are size-independent):
+      * a SPARSE polynomial with coefficients at low, middle and top indices: every sampled output equals
+        sum_j a_j w^(i_j k) computed with Python integers - wrong index arithmetic above 2^25 (32-bit products, the
+        three-pass digit reversal) cannot survive this;
+      * coset_fft of the same polynomial at sampled points (a_j 7^(i_j) w^(i_j k));
+      * random data: ifft(fft(x)) == x and icoset_fft(coset_fft(x)) == x on every element.
+    2^29 ... 2^31 (16 - 64 GiB vectors + as much scratch) are not run anywhere in this repository."""
+    import bellman_amd
+
+    n = 1 << log_n
+    q = cref.Q
+    rnd = np.random.default_rng(log_n)
+    omega = pow(pow(7, (q - 1) >> 32, q), 1 << (32 - log_n), q)
+    pos = [0, 1, 2047, 2048, (1 << 22) + 5, n // 2 - 1, n // 2, n - 2049, n - 1] + [int(x) for x in rnd.integers(0, n, 7)]
+    pos = sorted(set(pos))
+    coef = [int(x) for x in rnd.integers(1, 1 << 62, len(pos))]
+    data = np.zeros((n, 4), dtype=np.uint64)
+    data[pos] = cref.fr_to_mont(cref.ints_to_arr(coef, 4))
+    ks = [0, 1, n - 1, n // 2, (1 << 25) + 3] + [int(x) for x in rnd.integers(0, n, 40)]
+    for mode, shift in (("fft", 1), ("coset_fft", 7)):
+        d = bellman_amd.EvaluationDomain.from_coeffs(worker, data)
+        getattr(d, mode)()
+        out = d.into_coeffs()
+        got = cref.arr_to_ints(cref.fr_from_mont(out[ks]))
+        for k, g in zip(ks, got):
+            want = sum(c * pow(shift, i, q) % q * pow(omega, (i * k) % n, q) for c, i in zip(coef, pos)) % q
+            assert g == want, (log_n, mode, k)
+        del out
+    del data
+    x = _splitmix(n, 7000 + log_n)
+    d = bellman_amd.EvaluationDomain.from_coeffs(worker, x)
+    d.fft()
+    d.ifft()
+    assert np.array_equal(d.as_ref(), x)
+    d.coset_fft()
+    d.icoset_fft()
+    assert np.array_equal(d.into_coeffs(), x)
+    worker.trim()

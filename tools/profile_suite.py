@@ -43,7 +43,7 @@ def run_msm(args):
     w = bellman_amd.Worker(0)
     n = 1 << log_n
     dout = make_bases(w, lib, group, n)
-    bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
+    bases = bellman_amd.Bases.copy_device(w, group, dout, n)
     s = splitmix_scalars(n, 2)
     ds = w.alloc(n * 32)
     w.upload(ds, s)
@@ -73,7 +73,7 @@ def run_sizes(args):
     w.upload(ds, s)
     for log_n in range(lo, hi + 1):
         n = 1 << log_n
-        bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
+        bases = bellman_amd.Bases.copy_device(w, group, dout, n)
         best, walls = None, []
         for it in range(7):
             t0 = time.perf_counter()

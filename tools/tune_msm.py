@@ -26,7 +26,7 @@ def main():
     gen = G1_GEN_MONT if group == 1 else G2_GEN_MONT
     assert lib.bh_fixed_base_mul_dev(w.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
     w.synchronize()
-    bases = bellman_amd.Bases.wrap_device(w, group, dout, n)
+    bases = bellman_amd.Bases.copy_device(w, group, dout, n)
     s = splitmix_scalars(n, 2)
     ds = w.alloc(n * 32)
     w.upload(ds, s)
