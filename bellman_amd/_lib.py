@@ -27,6 +27,7 @@ EXPORTS = [
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
     "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev", "bh_r1cs_eval_transposed_dev", "bh_fr_powers_dev", "bh_fr_qap_ext_dev",
     "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
+    "bh_groth16_prove_demo_async", "bh_groth16_proof_wait",
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
@@ -162,6 +163,8 @@ def load():
     lib.bh_groth16_prove_witness.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.bh_groth16_demo_r1cs.argtypes = [vp, i32, sz, c.c_uint64, vp, c.POINTER(vp)]
     lib.bh_groth16_prove_demo_r1cs.argtypes = [vp, vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.bh_groth16_prove_demo_async.argtypes = [vp, vp, i32, sz, c.c_uint64, vp, vp, vp, vp, c.POINTER(vp)]
+    lib.bh_groth16_proof_wait.argtypes = [vp, vp, vp]
     lib.bh_groth16_prove_witness_part.argtypes = [vp, vp, vp, sz, vp, sz, sz, sz, vp, vp]
     lib.bh_groth16_sums_add.argtypes = [vp, vp]
     lib.bh_groth16_sums_add.restype = None

@@ -15,7 +15,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <deque>
+#include <exception>
 #include <functional>
+#include <memory>
+#include <thread>
 #include <type_traits>
 #include <stdexcept>
 #include <utility>
@@ -265,6 +269,15 @@ Proof create_random_proof(bellman::Circuit &circuit, Parameters &params, Rng &&r
 // prover.rs:217-360 on an already synthesised assignment (input constraints already appended)
 Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s,
                        ProveTimings *timings = nullptr);
+// the same on plain views of the assignment's fields (what the C entry point receives: nothing is copied on the host)
+struct AssignmentView {
+  const Fr *a, *b, *c; size_t n_constraints;
+  const Fr *input_assignment; size_t n_inputs;
+  const Fr *aux_assignment; size_t n_aux;
+  const uint64_t *a_aux_density, *b_input_density, *b_aux_density;   // LSB0 words (DensityTracker::words)
+};
+Proof prove_assignment(const AssignmentView &v, Parameters &params, const Fr &r, const Fr &s,
+                       ProveTimings *timings = nullptr);
 // The same two entry points with the constraint evaluation on the device: only the witness
 // closures of `circuit` run on the host.  The circuit must have the shape `r1cs` was captured from
 // (it does whenever `params` belongs to it); a different variable count throws std::invalid_argument.
@@ -281,5 +294,43 @@ Proof assemble_proof(const Parameters &params, const MsmSums &sums, const Fr &r,
 Proof prove_witness(const R1cs &r1cs, Parameters &params, const Fr *input_assignment, size_t n_inputs,
                     const Fr *aux_assignment, size_t n_aux, const Fr &r, const Fr &s,
                     ProveTimings *timings = nullptr);
+
+// ---- one caller, proofs back to back ---------------------------------------------------------------------------
+// create_proof is synthesis on the host followed by the device part (prover.rs:182-215, then :217-360).  A single
+// caller that proves in a loop leaves the GPU idle during every synthesis and the host idle during every device part.
+// AsyncProof runs the device part of ONE proof on a helper thread; ProofPipeline keeps up to `depth` of them in flight
+// while the calling thread synthesises the next circuit - proofs come back in submission order, each identical to what
+// create_proof returns for the same circuit, r and s.
+struct AsyncProof {
+  std::thread worker;
+  Proof proof;
+  ProveTimings timings = {0, 0, 0, 0};
+  std::exception_ptr error;
+  std::unique_ptr<WitnessAssignment> witness;     // device-evaluated constraints (r1cs != null)
+  std::unique_ptr<ProvingAssignment> assignment;  // host-evaluated constraints, as in the reference
+  ~AsyncProof() { if (worker.joinable()) worker.join(); }
+  Proof wait(ProveTimings *tm = nullptr);          // joins; rethrows what the device part threw
+};
+// synthesises `circuit` on the calling thread (into a WitnessAssignment when `r1cs` is given, else into a
+// ProvingAssignment with the input constraints of prover.rs:208-215) and starts the device part
+std::unique_ptr<AsyncProof> create_proof_async(bellman::Circuit &circuit, const R1cs *r1cs, Parameters &params, const Fr &r,
+                                               const Fr &s);
+class ProofPipeline {
+ public:
+  ProofPipeline(Parameters &params, const R1cs *r1cs, size_t depth = 2) : params_(params), r1cs_(r1cs), depth_(depth ? depth : 1) {}
+  // blocks (by finishing the oldest proof into an internal queue) while `depth` proofs are in flight
+  void submit(bellman::Circuit &circuit, const Fr &r, const Fr &s);
+  Proof next(ProveTimings *tm = nullptr);   // the oldest submitted proof
+  size_t pending() const { return inflight_.size() + done_.size(); }
+
+ private:
+  Parameters &params_;
+  const R1cs *r1cs_;
+  size_t depth_;
+  std::deque<std::unique_ptr<AsyncProof>> inflight_;
+  struct Done { Proof proof; ProveTimings tm; std::exception_ptr error; };
+  std::deque<Done> done_;
+  void retire_oldest();
+};
 
 }  // namespace groth16

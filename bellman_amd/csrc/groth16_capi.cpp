@@ -2,6 +2,8 @@
 // the groth16 layer (declared in include/bellman_hip.h).
 #include <string.h>
 
+#include <memory>
+
 #include <chrono>
 #include <functional>
 #include <vector>
@@ -319,19 +321,15 @@ int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const vo
   ProveTimings tm = {0, 0, 0, 0};
   // everything that can allocate runs inside the guard: no C++ exception may cross the C boundary
   int rc = run_guarded([&] {
-    ProvingAssignment pa;
-    auto fill = [](std::vector<Fr> &v, const void *src, size_t n) { v.resize(n); if (n) memcpy(v.data(), src, n * 32); };
-    fill(pa.a, a_evals, n_constraints); fill(pa.b, b_evals, n_constraints); fill(pa.c, c_evals, n_constraints);
-    fill(pa.input_assignment, input_assignment, n_inputs); fill(pa.aux_assignment, aux_assignment, n_aux);
-    auto fill_d = [](bellman::DensityTracker &d, const uint64_t *w, size_t n) {
-      for (size_t i = 0; i < n; i++) { d.add_element(); if ((w[i >> 6] >> (i & 63)) & 1) d.inc(i); }
-    };
-    fill_d(pa.a_aux_density, a_aux_density, n_aux);
-    fill_d(pa.b_input_density, b_input_density, n_inputs);
-    fill_d(pa.b_aux_density, b_aux_density, n_aux);
+    // views of the caller's arrays: they are only read as bytes (uploads, the tiny input multiexps), never copied
+    AssignmentView v;
+    v.a = (const Fr *)a_evals; v.b = (const Fr *)b_evals; v.c = (const Fr *)c_evals; v.n_constraints = n_constraints;
+    v.input_assignment = (const Fr *)input_assignment; v.n_inputs = n_inputs;
+    v.aux_assignment = (const Fr *)aux_assignment; v.n_aux = n_aux;
+    v.a_aux_density = a_aux_density; v.b_input_density = b_input_density; v.b_aux_density = b_aux_density;
     Fr rr, ss;
     memcpy(&rr, r, 32); memcpy(&ss, s, 32);
-    return prove_assignment(pa, *params->p, rr, ss, &tm);
+    return prove_assignment(v, *params->p, rr, ss, &tm);
   }, proof_out);
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
@@ -381,6 +379,42 @@ int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circu
   int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
     return run_guarded([&] { R1csView view(r1cs); return create_proof(c, view.r, *params->p, rr, ss, &tm); }, proof_out);
   });
+  if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
+  return rc;
+}
+
+// ---- asynchronous proofs: synthesis on the calling thread, the device part on a helper thread ---------------------
+struct bh_proof_job {
+  std::unique_ptr<groth16::AsyncProof> job;
+  std::unique_ptr<R1csView> view;
+  int early_rc = BH_OK;
+};
+int bh_groth16_prove_demo_async(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
+                                const void *witness, const void *constants, const void *r, const void *s, bh_proof_job **out) {
+  using namespace groth16;
+  if (!params || !r || !s || !out) return BH_ERR_INVALID_ARG;
+  Fr rr, ss;
+  memcpy(&rr, r, 32); memcpy(&ss, s, 32);
+  std::unique_ptr<bh_proof_job> pj(new bh_proof_job());
+  if (r1cs) pj->view.reset(new R1csView(r1cs));
+  int rc = with_demo_circuit(circuit_kind, size, seed, witness, constants, [&](bellman::Circuit &c) -> int {
+    try {
+      pj->job = create_proof_async(c, r1cs ? &pj->view->r : nullptr, *params->p, rr, ss);
+      return BH_OK;
+    } catch (const bellman::SynthesisError &e) { return e.code;
+    } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
+    } catch (...) { return BH_ERR_HIP; }
+  });
+  if (rc != BH_OK) return rc;
+  *out = pj.release();
+  return BH_OK;
+}
+int bh_groth16_proof_wait(bh_proof_job *job, void *proof_out, float *timings4) {
+  using namespace groth16;
+  if (!job || !proof_out) return BH_ERR_INVALID_ARG;
+  std::unique_ptr<bh_proof_job> pj(job);
+  ProveTimings tm = {0, 0, 0, 0};
+  int rc = run_guarded([&] { return pj->job->wait(&tm); }, proof_out);
   if (timings4) { timings4[0] = tm.synthesis_ms; timings4[1] = tm.h_poly_ms; timings4[2] = tm.msm_ms; timings4[3] = tm.total_ms; }
   return rc;
 }

@@ -110,8 +110,11 @@ struct AssignmentSource {
   const Fr *inputs; size_t n_in;
   const Fr *aux; size_t n_aux;
   size_t n_cons;
-  // host path (prove_assignment): evaluations and density bitmaps computed during synthesis
-  const ProvingAssignment *host = nullptr;
+  // host path (prove_assignment): evaluations and density bitmaps computed during synthesis - plain views, so that the
+  // C entry point hands the caller's arrays through without copying them
+  bool host = false;
+  const Fr *a = nullptr, *b = nullptr, *c = nullptr;
+  const uint64_t *a_aux_density = nullptr, *b_input_density = nullptr, *b_aux_density = nullptr;   // LSB0 words
   // device path (prove_witness): matrices and densities already resident
   const R1cs *r1cs = nullptr;
 };
@@ -171,18 +174,21 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   const uint64_t *hw_a_aux = nullptr, *hw_b_in = nullptr, *hw_b_aux = nullptr;   // the same bitmaps on the host
   size_t b_in_total = 0;
   if (src.host) {
-    auto upload_density = [&](const DensityTracker &d, std::unique_ptr<DevBuf> &buf) {
-      const size_t nw = (d.get_query_size() + 63) / 64;
+    auto upload_density = [&](const uint64_t *words, size_t bits, std::unique_ptr<DevBuf> &buf) {
+      const size_t nw = (bits + 63) / 64;
       buf.reset(new DevBuf(ctx, nw * 8 + 8));
-      if (nw) check(bh_dev_upload_on(ctx, buf->p, d.words(), nw * 8, ps.st));
+      if (nw) check(bh_dev_upload_on(ctx, buf->p, words, nw * 8, ps.st));
       return (const uint64_t *)buf->p;
     };
-    dens_a_aux = upload_density(src.host->a_aux_density, dens_buf[0]);
-    dens_b_in = upload_density(src.host->b_input_density, dens_buf[1]);
-    dens_b_aux = upload_density(src.host->b_aux_density, dens_buf[2]);
-    b_in_total = src.host->b_input_density.get_total_density();
-    hw_a_aux = src.host->a_aux_density.words(); hw_b_in = src.host->b_input_density.words();
-    hw_b_aux = src.host->b_aux_density.words();
+    dens_a_aux = upload_density(src.a_aux_density, n_aux, dens_buf[0]);
+    dens_b_in = upload_density(src.b_input_density, n_in, dens_buf[1]);
+    dens_b_aux = upload_density(src.b_aux_density, n_aux, dens_buf[2]);
+    for (size_t w = 0; w < (n_in + 63) / 64; w++) {   // get_total_density (multiexp.rs:154-156)
+      uint64_t x = src.b_input_density[w];
+      if (w == n_in / 64 && (n_in & 63)) x &= (uint64_t(1) << (n_in & 63)) - 1;
+      b_in_total += (size_t)__builtin_popcountll(x);
+    }
+    hw_a_aux = src.a_aux_density; hw_b_in = src.b_input_density; hw_b_aux = src.b_aux_density;
   } else {
     check(bh_r1cs_density(src.r1cs->handle, 0, &dens_a_aux, &hw_a_aux, nullptr));
     check(bh_r1cs_density(src.r1cs->handle, 1, &dens_b_in, &hw_b_in, &b_in_total));
@@ -239,11 +245,11 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   auto enqueue_h_block = [&] {
     if (src.host) {
       // EvaluationDomain::from_coeffs pads with zeros (domain.rs:68): the padding is written on the device
-      const std::vector<Fr> *ev[3] = {&src.host->a, &src.host->b, &src.host->c};
+      const Fr *ev[3] = {src.a, src.b, src.c};
       void *dst[3] = {da.p, db.p, dc.p};
       for (int i = 0; i < 3; i++) {
         if (m > n_cons) check(bh_dev_zero_on(ctx, (char *)dst[i] + n_cons * 32, (m - n_cons) * 32, ps.st));
-        check(bh_dev_upload_on(ctx, dst[i], ev[i]->data(), n_cons * 32, ps.st));
+        check(bh_dev_upload_on(ctx, dst[i], ev[i], n_cons * 32, ps.st));
       }
     } else {
       // a = A.w, b = B.w, c = C.w straight into the FFT buffers (prover.rs:19-55,105-145 on the device)
@@ -411,11 +417,22 @@ MsmSums prove_witness_part(const R1cs &r1cs, Parameters &params, const Fr *input
 }
 
 Proof prove_assignment(ProvingAssignment &prover, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
+  AssignmentView v;
+  v.a = prover.a.data(); v.b = prover.b.data(); v.c = prover.c.data(); v.n_constraints = prover.a.size();
+  v.input_assignment = prover.input_assignment.data(); v.n_inputs = prover.input_assignment.size();
+  v.aux_assignment = prover.aux_assignment.data(); v.n_aux = prover.aux_assignment.size();
+  v.a_aux_density = prover.a_aux_density.words(); v.b_input_density = prover.b_input_density.words();
+  v.b_aux_density = prover.b_aux_density.words();
+  return prove_assignment(v, params, r, s, tm);
+}
+Proof prove_assignment(const AssignmentView &v, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   AssignmentSource src;
-  src.inputs = prover.input_assignment.data(); src.n_in = prover.input_assignment.size();
-  src.aux = prover.aux_assignment.data(); src.n_aux = prover.aux_assignment.size();
-  src.n_cons = prover.a.size();
-  src.host = &prover;
+  src.inputs = v.input_assignment; src.n_in = v.n_inputs;
+  src.aux = v.aux_assignment; src.n_aux = v.n_aux;
+  src.n_cons = v.n_constraints;
+  src.host = true;
+  src.a = v.a; src.b = v.b; src.c = v.c;
+  src.a_aux_density = v.a_aux_density; src.b_input_density = v.b_input_density; src.b_aux_density = v.b_aux_density;
   return prove_core(src, params, r, s, tm);
 }
 
@@ -534,6 +551,79 @@ Proof create_proof(Circuit &circuit, const R1cs &r1cs, Parameters &params, const
     tm->total_ms = (float)(now_ms() - t0);
   }
   return p;
+}
+
+// ---- one caller, proofs back to back (groth16.hpp) ---------------------------------------------------------------
+Proof AsyncProof::wait(ProveTimings *tm) {
+  if (worker.joinable()) worker.join();
+  if (tm) *tm = timings;
+  if (error) std::rethrow_exception(error);
+  return proof;
+}
+std::unique_ptr<AsyncProof> create_proof_async(Circuit &circuit, const R1cs *r1cs, Parameters &params, const Fr &r, const Fr &s) {
+  std::unique_ptr<AsyncProof> job(new AsyncProof());
+  const double t0 = now_ms();
+  if (r1cs) {
+    job->witness.reset(new WitnessAssignment());
+    WitnessAssignment &w = *job->witness;
+    w.input_assignment.reserve(r1cs->num_inputs);
+    w.aux_assignment.reserve(r1cs->num_aux);
+    w.alloc_input([] { return Fr::one(); });
+    circuit.synthesize(w);
+  } else {
+    job->assignment.reset(new ProvingAssignment());
+    ProvingAssignment &pa = *job->assignment;
+    pa.alloc_input([] { return Fr::one(); });
+    circuit.synthesize(pa);
+    for (size_t i = 0; i < pa.input_assignment.size(); i++) {
+      pa.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+                 [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+    }
+  }
+  const float synth_ms = (float)(now_ms() - t0);
+  AsyncProof *j = job.get();
+  Parameters *pp = &params;
+  job->worker = std::thread([j, r1cs, pp, r, s, synth_ms] {
+    try {
+      ProveTimings local = {0, 0, 0, 0};
+      if (r1cs) {
+        const WitnessAssignment &w = *j->witness;
+        j->proof = prove_witness(*r1cs, *pp, w.input_assignment.data(), w.input_assignment.size(), w.aux_assignment.data(),
+                                 w.aux_assignment.size(), r, s, &local);
+      } else {
+        j->proof = prove_assignment(*j->assignment, *pp, r, s, &local);
+      }
+      j->timings = local;
+      j->timings.synthesis_ms = synth_ms;
+      j->timings.total_ms = local.total_ms + synth_ms;
+    } catch (...) {
+      j->error = std::current_exception();
+    }
+  });
+  return job;
+}
+void ProofPipeline::retire_oldest() {
+  std::unique_ptr<AsyncProof> j = std::move(inflight_.front());
+  inflight_.pop_front();
+  Done d;
+  d.tm = ProveTimings{0, 0, 0, 0};
+  try { d.proof = j->wait(&d.tm); } catch (...) { d.error = std::current_exception(); }
+  done_.push_back(std::move(d));
+}
+void ProofPipeline::submit(Circuit &circuit, const Fr &r, const Fr &s) {
+  while (inflight_.size() >= depth_) retire_oldest();
+  inflight_.push_back(create_proof_async(circuit, r1cs_, params_, r, s));   // synthesis runs here, beside the proofs in flight
+}
+Proof ProofPipeline::next(ProveTimings *tm) {
+  if (done_.empty()) {
+    if (inflight_.empty()) throw std::logic_error("ProofPipeline::next without a submitted proof");
+    retire_oldest();
+  }
+  Done d = std::move(done_.front());
+  done_.pop_front();
+  if (tm) *tm = d.tm;
+  if (d.error) std::rethrow_exception(d.error);
+  return d.proof;
 }
 
 // ---- prover.rs:182-215 ----------------------------------------------------------------------------

@@ -626,3 +626,27 @@ def prove_via_call_sites(params, asg, r, s, patched_prover, timings=None):
     if timings is not None:
         timings[:] = list(tm)
     return Proof(out)
+
+
+def create_proof_demo_async(params, r1cs, kind, size, seed, witness, constants, r, s):
+    """bh_groth16_prove_demo_async: synthesis of the C++ demo circuit on this thread, the device part on a helper thread.
+    Returns wait(timings=None) -> Proof.  r1cs=None: host synthesis as in the reference."""
+    lib = _lib.load()
+    wit = fr_to_mont_array(witness if isinstance(witness, np.ndarray) else list(witness))
+    con = fr_to_mont_array(constants if isinstance(constants, np.ndarray) else list(constants)) if constants is not None \
+        else np.zeros((1, 4), dtype=np.uint64)
+    rs = fr_to_mont_array([r, s])
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    job = ctypes.c_void_p()
+    check(lib.bh_groth16_prove_demo_async(params._h, None if r1cs is None else r1cs._h, kind, size, seed, p(wit), p(con),
+                                          p(rs[0:1]), p(rs[1:2]), ctypes.byref(job)), "create_proof (async)")
+
+    def wait(timings=None):
+        out = np.zeros(48, dtype=np.uint64)
+        tm = (ctypes.c_float * 4)()
+        check(lib.bh_groth16_proof_wait(job, p(out), tm), "create_proof (async wait)")
+        if timings is not None:
+            timings[:] = list(tm)
+        return Proof(out)
+
+    return wait

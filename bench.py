@@ -147,6 +147,28 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     conc_r = threads * per_thread / (time.perf_counter() - t0)
     assert last_r.a.tobytes() == last.a.tobytes() and last_r.b.tobytes() == last.b.tobytes() and \
         last_r.c.tobytes() == last.c.tobytes(), "device-evaluated constraints gave a different proof"
+
+    # ONE caller thread, two proofs deep (bh_groth16_prove_demo_async / groth16::ProofPipeline): the synthesis of proof
+    # k+1 runs on this thread while a helper thread drives the device part of proof k.  Every proof uses the inputs of
+    # `last`, which it must equal.
+    def pipelined(r1cs_or_none, count):
+        waits, got = [], []
+        t0 = time.perf_counter()
+        for _ in range(count):
+            waits.append(pg.create_proof_demo_async(params, r1cs_or_none, 1, rounds, CIRCUIT_SEED, [987654321 + proofs], None,
+                                                    0xABCDEF0123 + proofs, 0x123456789AB))
+            if len(waits) == 2:
+                got.append(waits.pop(0)())
+        while waits:
+            got.append(waits.pop(0)())
+        rate = count / (time.perf_counter() - t0)
+        for g in got:
+            assert g.a.tobytes() == last.a.tobytes() and g.b.tobytes() == last.b.tobytes() and g.c.tobytes() == last.c.tobytes(), \
+                "pipelined proof differs from the synchronous one"
+        return rate
+
+    pipe_r = pipelined(r1cs, 10)
+    pipe_h = pipelined(None, 6)
     # The drop-in as a patched bellman drives it (shim/patches/bellman-hip.patch; the C calls are issued by the C++
     # transcription csrc/groth16_callsites.cpp - no Rust toolchain here): the h block + eight multiexps of
     # prover.rs:217-318 on an assignment synthesised beforehand (synthesis is the same host work in every variant),
@@ -224,6 +246,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "ms_issue_7_multiexps_then_h_block_incl_uploads": round(float(m[1]), 2),
         "ms_h_multiexp_and_waits": round(float(m[2]), 2),
         "proofs_per_s_excluding_host_synthesis": round(1e3 / (float(m[4]) - float(m[0])), 3),
+        "proofs_per_s_one_caller_pipelined": round(pipe_h, 3),
         "proofs_per_s_concurrent": round(conc, 3),
         "concurrent_host_threads": threads,
         "samples": proofs,
@@ -242,6 +265,9 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
             "ms_host_witness": round(float(mr[0]), 2),
             "ms_issue_7_multiexps_then_h_block_incl_uploads": round(float(mr[1]), 2),
             "ms_h_multiexp_and_waits": round(float(mr[2]), 2),
+            "proofs_per_s_one_caller_pipelined": round(pipe_r, 3),
+            "pipeline_note": "one caller thread, two proofs deep (bh_groth16_prove_demo_async): witness closures of proof k+1 on "
+                             "the caller thread while a helper thread runs the device part of proof k; proofs asserted identical",
             "proofs_per_s_concurrent": round(conc_r, 3),
         },
     }

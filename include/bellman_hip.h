@@ -388,6 +388,19 @@ int bh_fr_qap_ext_dev(bh_ctx *ctx, void *e_dev, const void *at_dev, const void *
 int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
                              size_t n_inputs, const void *aux_assignment, size_t n_aux, const void *r,
                              const void *s, void *proof_out, float *timings4);
+/* ---- one caller, proofs back to back: create_proof split at the synthesis / device boundary -----------------
+ * bh_groth16_prove_demo_async synthesises the circuit on the CALLING thread (prover.rs:182-215; with `r1cs` only the
+ * witness closures run, constraints are evaluated on the device) and returns while the device part (prover.rs:217-360)
+ * runs on a helper thread; bh_groth16_proof_wait blocks for it (the Waiter of the whole proof), writes the proof and
+ * frees the job.  Submitting proof k+1 before waiting for proof k overlaps its synthesis with proof k's GPU work - what
+ * groth16::ProofPipeline (csrc/groth16.hpp) does for C++ callers.  Proofs are identical to the synchronous calls'.
+ * r1cs == NULL: host synthesis as in the reference (bh_groth16_prove_demo). */
+typedef struct bh_proof_job bh_proof_job;
+int bh_groth16_prove_demo_async(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
+                                const void *witness, const void *constants, const void *r, const void *s,
+                                bh_proof_job **job);
+int bh_groth16_proof_wait(bh_proof_job *job, void *proof_out, float *timings4);
+
 /* ---- one proof over several GPUs: every rank holds the CRS and the matrices, builds the
  * witness and runs the (small) h block, but computes each of the eight multiexps of prover.rs:244-318
  * only over part `part` of `parts` of the scalar indices (contiguous, cut at multiples of 64).  The

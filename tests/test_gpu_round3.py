@@ -400,3 +400,31 @@ print("RCCL_PATH_OK", torch.cuda.nccl.version())
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     assert '"collective": "nccl' in line
+
+
+def test_async_proofs_two_deep_equal_the_synchronous_ones(worker):
+    """bh_groth16_prove_demo_async / bh_groth16_proof_wait (one caller, synthesis of proof k+1 beside the device part of
+    proof k): every proof equals create_proof's for the same circuit, r, s - with the constraints evaluated on the host
+    (as in the reference) and on the device; an error (short query) surfaces at the wait."""
+    from bellman_amd import UnexpectedEof
+    from bellman_amd import groth16 as pg
+
+    rounds, seed = 4093, 17
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    r1cs = pg.R1CS.from_demo(worker, 1, rounds, seed)
+    want = [pg.create_proof_demo(pp, 1, rounds, seed, [1000 + i], None, 50 + i, 60 + i) for i in range(5)]
+    for rc in (r1cs, None):
+        waits, got = [], []
+        for i in range(5):
+            waits.append(pg.create_proof_demo_async(pp, rc, 1, rounds, seed, [1000 + i], None, 50 + i, 60 + i))
+            if len(waits) == 2:
+                got.append(waits.pop(0)())
+        got += [w() for w in waits]
+        for g, w in zip(got, want):
+            assert _same(g, w.a, w.b, w.c)
+    short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h[:-2], l, a, b1, b2)
+    wait = pg.create_proof_demo_async(short, r1cs, 1, rounds, seed, [1], None, 2, 3)
+    with pytest.raises(UnexpectedEof):
+        wait()
+    assert worker.info()["jobs_in_flight"] == 0
+    r1cs.release()
