@@ -82,6 +82,20 @@ struct ChunkView {
   bool head_partial;    // first bucket started in an earlier chunk
   bool tail_partial;    // last bucket continues in the next chunk
 };
+// The plan's K is sized for n entries per window, but zero digits (z of them, sorted to the front) are skipped: sparse
+// density maps - create_proof's b_g1 / b_g2 queries use about half of the aux variables - and small scalars leave a
+// large part of the window empty, and with the plan's K the upper part of the launch would then have nothing to do
+// (measured: the 2^19 dense entries of a 2^20-term G2 multiexp ran on HALF of the chip's lanes, 11 ms instead of 5.5).
+// Every kernel that walks chunks therefore derives the window's effective chunk length from its zero count, so that
+// the n - z live entries are spread over all chunks_per_window lanes again; never below 8 (or the plan's K if smaller)
+// so that runs do not shatter into many partials.
+__device__ __forceinline__ u32 effective_chunk(u32 n, u32 z, u32 chunks_per_window, u32 K) {
+  const u32 live = n - z;
+  u32 k = (u32)(((u64)live + chunks_per_window - 1) / chunks_per_window);
+  const u32 floor_k = K < 8u ? K : 8u;
+  if (k < floor_k) k = floor_k;
+  return k < K ? k : K;
+}
 __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lane, u32 K, ChunkView &v) {
   const u64 b = (u64)z + (u64)lane * K;
   if (b >= n) return false;
@@ -108,7 +122,9 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
   const u64 *src = pairs + (u64)w * n;
   ChunkView v;
-  if (lane >= chunks_per_window || !chunk_view(src, n, zstart[w], lane, K, v)) return;
+  const u32 z = zstart[w];
+  K = effective_chunk(n, z, chunks_per_window, K);
+  if (lane >= chunks_per_window || !chunk_view(src, n, z, lane, K, v)) return;
   XYZZ<typename F::Mem> *bucket = pts + ((u64)w << (c - 1)) - 1;   // bucket[d], d = |digit| in [1, 2^(c-1)]
   const u64 slot = (u64)w * chunks_per_window + lane;
   __shared__ XYZZ<F> lds_acc[LDS_ACC ? 128 : 1];
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
   if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
   const u64 *src = pairs + (u64)w * n;
   const u32 z = zstart[w];
+  K = effective_chunk(n, z, chunks_per_window, K);   // the same rule as the accumulation
   ChunkView v;
   if (lane >= chunks_per_window || !chunk_view(src, n, z, lane, K, v)) return;
   if (!v.tail_partial) return;
