@@ -15,13 +15,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
 # every symbol include/bellman_hip.h declares, then the test hooks of include/bellman_hip_test.h
 EXPORTS = [
     "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus", "bh_runtime_configure", "bh_ctx_set_limits", "bh_ctx_info",
-    "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
+    "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_create_priority", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
     "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_trim",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
-    "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars",
+    "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after",
     "bh_msm_sharded_async", "bh_msm_sharded_wait",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
@@ -71,6 +71,7 @@ def load():
     lib.bh_dev_download.argtypes = [vp, vp, vp, sz]
     lib.bh_dev_zero.argtypes = [vp, vp, sz]
     lib.bh_stream_create.argtypes = [vp, c.POINTER(vp)]
+    lib.bh_stream_create_priority.argtypes = [vp, i32, c.POINTER(vp)]
     lib.bh_stream_destroy.argtypes = [vp, vp]
     lib.bh_stream_synchronize.argtypes = [vp, vp]
     lib.bh_dev_upload_on.argtypes = [vp, vp, vp, sz, vp]
@@ -130,6 +131,7 @@ def load():
     lib.bh_scalars_dev_ptr.argtypes = [vp]
     lib.bh_scalars_dev_ptr.restype = vp
     lib.bh_msm_async_scalars.argtypes = [vp, vp, sz, vp, sz, sz, vp, sz, vp, c.POINTER(vp)]
+    lib.bh_msm_async_dev_after.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, vp, c.POINTER(vp)]
     lib.bh_h_poly_fr_scalars.argtypes = [vp, vp, vp, vp, sz, c.POINTER(vp)]
     lib.bh_msm_sharded_async.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, sz, c.POINTER(vp)]
     lib.bh_msm_sharded_wait.argtypes = [vp, vp]

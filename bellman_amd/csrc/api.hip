@@ -32,6 +32,7 @@ void msm_slot_release(Context &c);
 bool msm_complete_oldest(Context &c);
 size_t msm_jobs_in_flight(Context &c);
 hipStream_t msm_job_stream(MsmJobImpl &job);
+int msm_job_after(MsmJobImpl &job, hipStream_t after);
 void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
@@ -352,6 +353,7 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   ctx->c.pool.release_all();
   for (auto &r : ctx->c.job_pool) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
+    if (r.dep_event) (void)hipEventDestroy(r.dep_event);
     if (r.pinned) (void)hipHostFree(r.pinned);
     if (r.hp_event) (void)hipEventDestroy(r.hp_event);
     if (r.hp_stream) (void)hipStreamDestroy(r.hp_stream);
@@ -360,6 +362,9 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   ctx->c.job_pool.clear();
   for (hipStream_t st : ctx->c.stream_pool) (void)hipStreamDestroy(st);
   ctx->c.stream_pool.clear();
+  for (hipStream_t st : ctx->c.hp_streams) (void)hipStreamDestroy(st);
+  ctx->c.hp_streams.clear();
+  ctx->c.hp_stream_pool.clear();
   if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
   delete ctx;
 }
@@ -414,10 +419,32 @@ int bh_stream_create(bh_ctx *ctx, void **stream) {
   *stream = (void *)st;
   return BH_OK;
 }
+int bh_stream_create_priority(bh_ctx *ctx, int high, void **stream) {
+  if (!high) return bh_stream_create(ctx, stream);
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  {
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    if (!ctx->c.hp_stream_pool.empty()) {
+      *stream = (void *)ctx->c.hp_stream_pool.back();
+      ctx->c.hp_stream_pool.pop_back();
+      return BH_OK;
+    }
+  }
+  int lo = 0, hi = 0;   // numerically lower = higher priority
+  BH_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  hipStream_t st = nullptr;
+  BH_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+  std::lock_guard<std::mutex> g(ctx->c.job_mu);
+  ctx->c.hp_streams.push_back(st);
+  *stream = (void *)st;
+  return BH_OK;
+}
 int bh_stream_destroy(bh_ctx *ctx, void *stream) {
   // the caller has synchronised the stream; it goes back to the pool (destroyed with the context)
   if (!stream) return BH_OK;
   std::lock_guard<std::mutex> g(ctx->c.job_mu);
+  for (hipStream_t h : ctx->c.hp_streams)
+    if (h == (hipStream_t)stream) { ctx->c.hp_stream_pool.push_back(h); return BH_OK; }
   ctx->c.stream_pool.push_back((hipStream_t)stream);
   return BH_OK;
 }
@@ -820,7 +847,7 @@ static bool tiny_msm_on_host(const bh_bases *bases, size_t skip, const void *sca
 
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0) {
+                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0, void *after_stream = nullptr) {
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
@@ -851,7 +878,8 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   const void *sc_dev = scalars;
   const u64 *dn_dev = density;
   int rc = BH_OK;
-  if (n && scalars_on_host) {
+  if (after_stream) rc = msm_job_after(*impl, (hipStream_t)after_stream);
+  if (rc == BH_OK && n && scalars_on_host) {
     void *p = ctx->c.pool.acquire(n * 32);
     if (!p) rc = BH_ERR_HIP;
     else {
@@ -1064,6 +1092,13 @@ int bh_msm_sharded_wait(bh_msm_sharded_job *job, void *out_affine) {
   return BH_OK;
 }
 
+int bh_msm_async_dev_after(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev, size_t n, int fmt,
+                           const uint64_t *density_words_dev, size_t density_len, const bh_msm_opts *opts, void *after_stream,
+                           bh_msm_job **job) {
+  if (!after_stream) return BH_ERR_INVALID_ARG;
+  return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, opts, job, 0,
+                    after_stream);
+}
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;
   float ms[4] = {0, 0, 0, 0};

@@ -124,6 +124,7 @@ struct JobResources {
   // high-priority stream, ordered after the accumulation by an event
   hipStream_t hp_stream = nullptr;
   hipEvent_t hp_event = nullptr;
+  hipEvent_t dep_event = nullptr;  // lazily created: orders the job after another stream (bh_msm_async_dev_after)
   void *pinned = nullptr;          // host-pinned landing buffer for the job's result
   size_t pinned_bytes = 0;
 };
@@ -156,6 +157,7 @@ struct Context {
   std::mutex job_mu;
   std::vector<JobResources> job_pool;
   std::vector<hipStream_t> stream_pool;   // bh_stream_create / destroy recycle streams (creation costs ~1 ms)
+  std::vector<hipStream_t> hp_stream_pool, hp_streams;   // the same for high-priority streams (bh_stream_create_priority)
   // multiexps issued and not yet completed, oldest first (guarded by job_mu).  Back-pressure (src/multicore.rs:47-73:
   // Worker::compute runs the task inline once 4 x threads are pending): when `max_jobs` are in flight, or the
   // workspace pool cannot serve an allocation, the issuing thread COMPLETES the oldest job itself (stream

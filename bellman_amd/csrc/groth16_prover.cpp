@@ -66,7 +66,13 @@ namespace {
 struct ProofStream {   // uploads + h block of one proof; independent of other proofs in flight
   bh_ctx *ctx;
   void *st = nullptr;
-  explicit ProofStream(bh_ctx *c) : ctx(c) { check(bh_stream_create(ctx, &st)); }
+  // the h block is a short dependent chain on the proof's critical path (the H multiexp waits for it): on a
+  // high-priority stream its kernels are dispatched ahead of the multiexps' whenever a SIMD frees up
+  // (BELLMAN_HIP_H_PRIORITY=0 switches that off for A/B runs)
+  explicit ProofStream(bh_ctx *c) : ctx(c) {
+    static const bool high = [] { const char *e = getenv("BELLMAN_HIP_H_PRIORITY"); return !(e && *e == '0'); }();
+    check(bh_stream_create_priority(ctx, high ? 1 : 0, &st));
+  }
   ~ProofStream() { if (st) { (void)bh_stream_synchronize(ctx, st); (void)bh_stream_destroy(ctx, st); } }
   ProofStream(const ProofStream &) = delete;
 };
@@ -284,13 +290,27 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     helper.join();
     if (helper_error) std::rethrow_exception(helper_error);
   } else {
-    issue_seven(false);
-    enqueue_h_block();
-    BH_TRACE("7 multiexps + h block issued; n_cons=%zu m=%zu", n_cons, m);
-    check(bh_stream_synchronize(ctx, ps.st));
-    BH_TRACE("h poly done");
+    // The H multiexp is ordered after the h block by an event (bh_msm_async_dev_after): the host never waits between
+    // them.  With the constraints evaluated on the device the h block is enqueued FIRST - nothing on the host delays it,
+    // and started late it queues behind the multiexps' long kernels, the H multiexp then runs alone at the end
+    // (profiles/r3_call2_proof_timeline.txt).  With host evaluations the multiexps go first: the GPU works while the
+    // host stages a, b, c (96 MiB of pageable memory at 2^20).
+    auto issue_h = [&] {
+      const Slice sl = slice_of(m - 1, part, parts);   // a.len() - 1, :238-244
+      check(bh_msm_async_dev_after(ctx, params.h, sl.lo, (const char *)da.p + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT, nullptr,
+                                   0, nullptr, ps.st, &h_job));
+    };
+    if (!src.host) {
+      enqueue_h_block();
+      issue_h();
+      issue_seven(false);
+    } else {
+      issue_seven(false);
+      enqueue_h_block();
+      issue_h();
+    }
+    BH_TRACE("7 multiexps + h block + H issued; n_cons=%zu m=%zu", n_cons, m);
     t1 = now_ms();
-    issue(params.h, 0, da.p, m - 1, nullptr, nullptr, &h_job);   // a.len() - 1, :238-244
   }
 
   BH_TRACE("all msm issued n_in=%zu n_aux=%zu", n_in, n_aux);

@@ -83,11 +83,18 @@ void msm_job_delete(MsmJobImpl *j) {
   for (void *ptr : j->dev_allocs) j->ctx->pool.release(ptr);
   {
     std::lock_guard<std::mutex> g(j->ctx->job_mu);
-    j->ctx->job_pool.push_back(j->res);
+    j->ctx->job_pool.push_back(j->res);   // (res.dep_event travels with the recycled resources)
   }
   delete j;
 }
 hipStream_t msm_job_stream(MsmJobImpl &job) { return job.stream; }
+// everything enqueued on `after` so far happens before anything the job enqueues from now on
+int msm_job_after(MsmJobImpl &job, hipStream_t after) {
+  if (!job.res.dep_event) BH_HIP_CHECK(hipEventCreateWithFlags(&job.res.dep_event, hipEventDisableTiming));
+  BH_HIP_CHECK(hipEventRecord(job.res.dep_event, after));
+  BH_HIP_CHECK(hipStreamWaitEvent(job.stream, job.res.dep_event, 0));
+  return BH_OK;
+}
 // a job whose answer is already known (computed on the host at issue time)
 void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record) {
   job.trivial = true;

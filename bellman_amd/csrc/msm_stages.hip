@@ -24,6 +24,8 @@
 //                  sums of those vectors and the plain window totals -> W*c points.
 //   6. tail        result = sum_w 2^(c*w) (sum_p 2^p U[w][p] + T[w]): a 256-step double-and-add,
 //                  inherently serial -> host, 64-bit limbs (host_fp.hpp).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <cmath>
 
@@ -308,7 +310,13 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   const u64 avg = (u64)p.n >> (p.c - 1);
   // ... but never so long that the chip runs out of lanes (one wavefront per SIMD for the register-heavy
   // one-lane-per-point G2 accumulation, two otherwise); runs of 2-4 chunks are still folded by their owner lane
-  const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2);
+  // ... x OVERSUB: a launch that fills the chip EXACTLY (one wavefront per SIMD for the one-lane-per-point G2 kernel)
+  // is the fastest when it runs alone, but inside a proof other jobs' kernels hold some SIMDs when it starts, the
+  // workgroups that find no slot wait for the first round to END, and the launch takes two rounds with most of the chip
+  // idle in the second (profiles/r3_call2_proof_timeline.txt: 10.2 ms instead of 5.5).  Four rounds' worth of shorter
+  // chunks bound that tail to a quarter and let other kernels in between.
+  static const u64 oversub = [] { const char *e = getenv("BELLMAN_HIP_TABLE_OVERSUB"); long v = e && *e ? strtol(e, nullptr, 10) : 4; return (u64)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+  const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2) * oversub;
   u64 k = std::max<u64>(base_k, avg);
   k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_min));
   p.chunk = forced_chunk ? forced_chunk : (u32)k;

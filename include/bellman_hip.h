@@ -96,6 +96,9 @@ int bh_dev_zero(bh_ctx *ctx, void *dev_ptr, size_t bytes);   /* hipMemsetAsync(0
 /* caller-owned streams (opaque hipStream_t) so that independent proofs issued from different host
  * threads do not serialise on the context stream; the *_on variants enqueue and return */
 int bh_stream_create(bh_ctx *ctx, void **stream);
+/* high != 0: a stream of the device's highest priority - for short work on a proof's critical path (the h block, whose
+ * result the H multiexp waits for) that must not queue behind another job's long-running kernels */
+int bh_stream_create_priority(bh_ctx *ctx, int high, void **stream);
 int bh_stream_destroy(bh_ctx *ctx, void *stream);
 int bh_stream_synchronize(bh_ctx *ctx, void *stream);
 int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes, void *stream);
@@ -239,6 +242,13 @@ int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
 int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev,
                           size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
                           size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
+
+/* as bh_msm_async_dev_opts, with the job ORDERED AFTER everything enqueued so far on `after_stream` (a stream of
+ * bh_stream_create, or any hipStream_t of this device): the scalars may still be being produced there - create_proof's
+ * H multiexp consumes the h block's coefficients (groth16/src/prover.rs:221-245) without the host waiting in between */
+int bh_msm_async_dev_after(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev, size_t n_scalars,
+                           int scalar_fmt, const uint64_t *density_words_dev, size_t density_len, const bh_msm_opts *opts,
+                           void *after_stream, bh_msm_job **job);
 
 /* ---- scalar vectors resident in HBM ------------------------------------------------------------------
  * create_proof hands the same `Arc<Vec<Exponent>>` to several multiexps (groth16/src/prover.rs:267,279,285,300,306,
