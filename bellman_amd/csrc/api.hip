@@ -354,6 +354,7 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   for (auto &r : ctx->c.job_pool) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
     if (r.dep_event) (void)hipEventDestroy(r.dep_event);
+    if (r.acc_event) (void)hipEventDestroy(r.acc_event);
     if (r.pinned) (void)hipHostFree(r.pinned);
     if (r.hp_event) (void)hipEventDestroy(r.hp_event);
     if (r.hp_stream) (void)hipStreamDestroy(r.hp_stream);

@@ -124,6 +124,7 @@ struct JobResources {
   // high-priority stream, ordered after the accumulation by an event
   hipStream_t hp_stream = nullptr;
   hipEvent_t hp_event = nullptr;
+  hipEvent_t acc_event = nullptr;  // lazily created: recorded after the job's bucket accumulation launch (the accumulation chain)
   hipEvent_t dep_event = nullptr;  // lazily created: orders the job after another stream (bh_msm_async_dev_after)
   void *pinned = nullptr;          // host-pinned landing buffer for the job's result
   size_t pinned_bytes = 0;
@@ -167,6 +168,13 @@ struct Context {
   uint32_t max_jobs = 64;
   size_t hbm_total = 0, table_bytes = 0, table_budget = 0;   // window tables built automatically stay below the budget
   std::vector<struct ::bh_bases *> tables;                     // handles that own an automatically built table (job_mu)
+  // The accumulation chain: bucket-accumulation launches that fill the chip run one after the other in issue order
+  // (each waits for the previous one's event) instead of sharing the SIMDs - two of them side by side take twice as
+  // long each, so every job of a proof would finish late and all the latency-bound merge / reduction tails would pile up
+  // at the end with the chip idle (profiles/r3_call3_proof_timeline.txt).  Chained, job k's tail runs beside job k+1's
+  // accumulation.  BELLMAN_HIP_ACC_CHAIN=0 switches it off.
+  std::mutex acc_mu;
+  hipEvent_t last_acc_event = nullptr;
   int hw_queues_env = 0;          // GPU_MAX_HW_QUEUES seen when the context was created (0 = unset: the runtime's 4)
   bool configured_early = false;  // bh_runtime_configure ran before this library's first HIP call
 };

@@ -77,13 +77,15 @@ MsmSums issue_patched(Parameters &p, const CallSiteInputs &in) {
   check(bh_scalars_register(ctx, in.inputs, in.n_in, BH_SCALARS_MONT, &inputs.s));
   check(bh_scalars_register(ctx, in.aux, in.n_aux, BH_SCALARS_MONT, &aux.s));
   const size_t b_in_total = popcount_bits(in.b_input_density, in.n_in);
+  // the G2 multiexp first: the longest job; the bucket accumulations run on the device in issue order and its
+  // reduction tail then overlaps the G1 accumulations (csrc/common.hpp, the accumulation chain)
+  check(bh_msm_async_scalars(ctx, p.b_g2, b_in_total, aux.s, 0, in.n_aux, in.b_aux_density, in.n_aux, nullptr, &jobs.j[B2_AUX]));
   check(bh_msm_async_scalars(ctx, p.l, 0, aux.s, 0, in.n_aux, nullptr, 0, nullptr, &jobs.j[L]));
   check(bh_msm_async_scalars(ctx, p.a, 0, inputs.s, 0, in.n_in, nullptr, 0, nullptr, &jobs.j[A_IN]));
   check(bh_msm_async_scalars(ctx, p.a, in.n_in, aux.s, 0, in.n_aux, in.a_aux_density, in.n_aux, nullptr, &jobs.j[A_AUX]));
   check(bh_msm_async_scalars(ctx, p.b_g1, 0, inputs.s, 0, in.n_in, in.b_input_density, in.n_in, nullptr, &jobs.j[B1_IN]));
   check(bh_msm_async_scalars(ctx, p.b_g1, b_in_total, aux.s, 0, in.n_aux, in.b_aux_density, in.n_aux, nullptr, &jobs.j[B1_AUX]));
   check(bh_msm_async_scalars(ctx, p.b_g2, 0, inputs.s, 0, in.n_in, in.b_input_density, in.n_in, nullptr, &jobs.j[B2_IN]));
-  check(bh_msm_async_scalars(ctx, p.b_g2, b_in_total, aux.s, 0, in.n_aux, in.b_aux_density, in.n_aux, nullptr, &jobs.j[B2_AUX]));
   check(bh_h_poly_fr_scalars(ctx, in.a, in.b, in.c, in.n_cons, &h.s));
   check(bh_msm_async_scalars(ctx, p.h, 0, h.s, 0, bh_scalars_len(h.s), nullptr, 0, nullptr, &jobs.j[H]));
   return wait_all(jobs, p);

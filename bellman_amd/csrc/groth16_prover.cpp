@@ -66,11 +66,11 @@ namespace {
 struct ProofStream {   // uploads + h block of one proof; independent of other proofs in flight
   bh_ctx *ctx;
   void *st = nullptr;
-  // the h block is a short dependent chain on the proof's critical path (the H multiexp waits for it): on a
-  // high-priority stream its kernels are dispatched ahead of the multiexps' whenever a SIMD frees up
-  // (BELLMAN_HIP_H_PRIORITY=0 switches that off for A/B runs)
+  // the h block is a short dependent chain on the proof's critical path (the H multiexp waits for it).
+  // BELLMAN_HIP_H_PRIORITY=1 puts it on a high-priority stream; measured: no gain for one proof and 8 % less throughput
+  // with twelve proofs in flight (profiles/r3_call3_oversub.txt), so it is off by default
   explicit ProofStream(bh_ctx *c) : ctx(c) {
-    static const bool high = [] { const char *e = getenv("BELLMAN_HIP_H_PRIORITY"); return !(e && *e == '0'); }();
+    static const bool high = [] { const char *e = getenv("BELLMAN_HIP_H_PRIORITY"); return e && *e == '1'; }();
     check(bh_stream_create_priority(ctx, high ? 1 : 0, &st));
   }
   ~ProofStream() { if (st) { (void)bh_stream_synchronize(ctx, st); (void)bh_stream_destroy(ctx, st); } }
@@ -300,15 +300,13 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
       check(bh_msm_async_dev_after(ctx, params.h, sl.lo, (const char *)da.p + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT, nullptr,
                                    0, nullptr, ps.st, &h_job));
     };
-    if (!src.host) {
-      enqueue_h_block();
-      issue_h();
-      issue_seven(false);
-    } else {
-      issue_seven(false);
-      enqueue_h_block();
-      issue_h();
-    }
+    // Issue order = order of the bucket accumulations on the device (the accumulation chain, common.hpp): the G2
+    // multiexp first - the longest job, its reduction tail then runs beside the G1 accumulations - and H last, by which
+    // time the h block (enqueued first when nothing on the host delays it) has long finished beside the others.
+    if (!src.host) enqueue_h_block();
+    issue_seven(true);
+    if (src.host) enqueue_h_block();
+    issue_h();
     BH_TRACE("7 multiexps + h block + H issued; n_cons=%zu m=%zu", n_cons, m);
     t1 = now_ms();
   }

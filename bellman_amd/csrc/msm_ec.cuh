@@ -657,6 +657,15 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
     const dim3 grid((p.chunks_per_window + wpb - 1) / wpb, p.W);
     const Affine<M> *bases = (const Affine<M> *)bases_dev;
+    // launches that fill the chip join the context's accumulation chain (common.hpp)
+    static const bool chain_on = [] { const char *e = getenv("BELLMAN_HIP_ACC_CHAIN"); return !(e && *e == '0'); }();
+    const bool chained = chain_on && (u64)grid.x * grid.y * 128 >= (u64)c.num_cus * 4 * 64;
+    std::unique_lock<std::mutex> chain_lock(c.acc_mu, std::defer_lock);
+    if (chained) {
+      if (!job.res.acc_event) BH_HIP_CHECK(hipEventCreateWithFlags(&job.res.acc_event, hipEventDisableTiming));
+      chain_lock.lock();
+      if (c.last_acc_event) BH_HIP_CHECK(hipStreamWaitEvent(st, c.last_acc_event, 0));
+    }
     if constexpr (F::LANES == 1) {
       if (lds_acc)
         hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
@@ -669,6 +678,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                          tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
     }
     BH_HIP_CHECK(hipGetLastError());
+    if (chained) {
+      BH_HIP_CHECK(hipEventRecord(job.res.acc_event, st));
+      c.last_acc_event = job.res.acc_event;
+      chain_lock.unlock();
+    }
     if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));   // brackets exactly the accumulate launch
     if (job.hp_stream) {   // the rest of the job (latency-bound chains) runs on the high-priority stream
       BH_HIP_CHECK(hipEventRecord(job.hp_event, st));

@@ -310,12 +310,13 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   const u64 avg = (u64)p.n >> (p.c - 1);
   // ... but never so long that the chip runs out of lanes (one wavefront per SIMD for the register-heavy
   // one-lane-per-point G2 accumulation, two otherwise); runs of 2-4 chunks are still folded by their owner lane
-  // ... x OVERSUB: a launch that fills the chip EXACTLY (one wavefront per SIMD for the one-lane-per-point G2 kernel)
-  // is the fastest when it runs alone, but inside a proof other jobs' kernels hold some SIMDs when it starts, the
-  // workgroups that find no slot wait for the first round to END, and the launch takes two rounds with most of the chip
-  // idle in the second (profiles/r3_call2_proof_timeline.txt: 10.2 ms instead of 5.5).  Four rounds' worth of shorter
-  // chunks bound that tail to a quarter and let other kernels in between.
-  static const u64 oversub = [] { const char *e = getenv("BELLMAN_HIP_TABLE_OVERSUB"); long v = e && *e ? strtol(e, nullptr, 10) : 4; return (u64)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+  // (x BELLMAN_HIP_TABLE_OVERSUB, default 1.  A launch that fills the chip EXACTLY - one wavefront per SIMD for the
+  // one-lane-per-point G2 kernel - is the fastest alone, but when other jobs' accumulations hold SIMDs at its start the
+  // workgroups that find no slot wait for the first round to END: 10.2 ms instead of 5.5 inside a proof,
+  // profiles/r3_call2_proof_timeline.txt.  Shorter chunks for several rounds bound that tail but multiply the partials
+  // the merge has to fold - reduce 1.0 -> 2.0 -> 3.1 ms for 2 / 4 rounds, profiles/r3_call3_oversub.txt; the
+  // accumulation chain of common.hpp removes the cause instead.)
+  static const u64 oversub = [] { const char *e = getenv("BELLMAN_HIP_TABLE_OVERSUB"); long v = e && *e ? strtol(e, nullptr, 10) : 1; return (u64)(v < 1 ? 1 : v > 64 ? 64 : v); }();
   const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2) * oversub;
   u64 k = std::max<u64>(base_k, avg);
   k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_min));
