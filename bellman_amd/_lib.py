@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
 EXPORTS = [
     "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus", "bh_runtime_configure", "bh_ctx_set_limits", "bh_ctx_info",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_create_priority", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
-    "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_trim",
+    "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_accumulations_after", "bh_ctx_trim",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
@@ -77,6 +77,7 @@ def load():
     lib.bh_dev_upload_on.argtypes = [vp, vp, vp, sz, vp]
     lib.bh_dev_zero_on.argtypes = [vp, vp, sz, vp]
     lib.bh_ctx_synchronize.argtypes = [vp]
+    lib.bh_ctx_accumulations_after.argtypes = [vp, vp]
     lib.bh_ctx_trim.argtypes = [vp]
     lib.bh_test_groth16_prove_via_call_sites.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     lib.bh_test_demo_assignment.argtypes = [i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

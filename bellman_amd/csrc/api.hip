@@ -363,6 +363,8 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   ctx->c.job_pool.clear();
   for (hipStream_t st : ctx->c.stream_pool) (void)hipStreamDestroy(st);
   ctx->c.stream_pool.clear();
+  for (hipEvent_t ev : ctx->c.barrier_events) (void)hipEventDestroy(ev);
+  ctx->c.barrier_events.clear();
   for (hipStream_t st : ctx->c.hp_streams) (void)hipStreamDestroy(st);
   ctx->c.hp_streams.clear();
   ctx->c.hp_stream_pool.clear();
@@ -462,6 +464,26 @@ int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t by
 int bh_dev_zero_on(bh_ctx *ctx, void *dev_ptr, size_t bytes, void *stream) {
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   if (bytes) BH_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, pick_stream(ctx, stream)));
+  return BH_OK;
+}
+int bh_ctx_accumulations_after(bh_ctx *ctx, void *stream) {
+  // the next chip-filling bucket accumulation issued on this context - and through the accumulation chain
+  // (common.hpp) every later one - starts after everything enqueued on `stream` so far
+  if (!ctx || !stream) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  std::lock_guard<std::mutex> g(ctx->c.acc_mu);
+  constexpr size_t RING = 64;   // an event is only referenced until the next accumulation is issued
+  if (ctx->c.barrier_events.size() < RING) {
+    hipEvent_t ev = nullptr;
+    BH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->c.barrier_events.push_back(ev);
+    ctx->c.barrier_next = ctx->c.barrier_events.size() - 1;
+  } else {
+    ctx->c.barrier_next = (ctx->c.barrier_next + 1) % RING;
+  }
+  hipEvent_t ev = ctx->c.barrier_events[ctx->c.barrier_next];
+  BH_HIP_CHECK(hipEventRecord(ev, (hipStream_t)stream));
+  if (ctx->c.pending_barriers.size() < RING / 2) ctx->c.pending_barriers.push_back(ev);
   return BH_OK;
 }
 int bh_ctx_synchronize(bh_ctx *ctx) {

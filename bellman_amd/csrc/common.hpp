@@ -175,6 +175,9 @@ struct Context {
   // accumulation.  BELLMAN_HIP_ACC_CHAIN=0 switches it off.
   std::mutex acc_mu;
   hipEvent_t last_acc_event = nullptr;
+  std::vector<hipEvent_t> barrier_events;   // events of bh_ctx_accumulations_after (a ring, recycled round robin)
+  size_t barrier_next = 0;
+  std::vector<hipEvent_t> pending_barriers; // ... not yet waited for by an accumulation
   int hw_queues_env = 0;          // GPU_MAX_HW_QUEUES seen when the context was created (0 = unset: the runtime's 4)
   bool configured_early = false;  // bh_runtime_configure ran before this library's first HIP call
 };

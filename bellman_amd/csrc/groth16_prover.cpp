@@ -303,7 +303,12 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     // Issue order = order of the bucket accumulations on the device (the accumulation chain, common.hpp): the G2
     // multiexp first - the longest job, its reduction tail then runs beside the G1 accumulations - and H last, by which
     // time the h block (enqueued first when nothing on the host delays it) has long finished beside the others.
-    if (!src.host) enqueue_h_block();
+    if (!src.host) {
+      enqueue_h_block();
+      // the accumulations wait for the h block (their digit / sort stages run beside it): behind the G2 accumulation's
+      // 5 ms workgroups an FFT pass waits for a free SIMD, and the h block took 17 ms (profiles/r3_call4_proof_timeline.txt)
+      check(bh_ctx_accumulations_after(ctx, ps.st));
+    }
     issue_seven(true);
     if (src.host) enqueue_h_block();
     issue_h();

@@ -665,6 +665,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       if (!job.res.acc_event) BH_HIP_CHECK(hipEventCreateWithFlags(&job.res.acc_event, hipEventDisableTiming));
       chain_lock.lock();
       if (c.last_acc_event) BH_HIP_CHECK(hipStreamWaitEvent(st, c.last_acc_event, 0));
+      for (hipEvent_t ev : c.pending_barriers) BH_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));   // bh_ctx_accumulations_after
+      c.pending_barriers.clear();
     }
     if constexpr (F::LANES == 1) {
       if (lds_acc)

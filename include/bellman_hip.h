@@ -104,6 +104,13 @@ int bh_stream_synchronize(bh_ctx *ctx, void *stream);
 int bh_dev_upload_on(bh_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int bh_dev_zero_on(bh_ctx *ctx, void *dev_ptr, size_t bytes, void *stream);
 int bh_ctx_synchronize(bh_ctx *ctx);
+/* Scheduling hint.  Bucket accumulations that fill the chip run one after the other in issue order (two of them side by
+ * side take twice as long each and every job's latency-bound tail ends up at the end).  This call makes the NEXT such
+ * accumulation - and through that chain every later one - start after everything enqueued on `stream` so far:
+ * create_proof puts its h block (a short chain of FFT passes that would otherwise crawl behind the accumulations' long
+ * workgroups, with the H multiexp waiting for it) in front of its multiexps' accumulations this way, while their digit
+ * and sort stages still run beside it.  Results never depend on it. */
+int bh_ctx_accumulations_after(bh_ctx *ctx, void *stream);
 /* returns the context's idle cached device memory (recycled job workspaces, FFT twiddle tables) to the
  * driver; waits for the device to be idle first.  Purely a memory-footprint control; call it while no
  * other thread is inside a call on this context. */

@@ -119,6 +119,7 @@ extern "C" {
     pub fn bh_dev_upload_on(ctx: *mut BhCtx, dev_dst: *mut c_void, host_src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
     pub fn bh_dev_zero_on(ctx: *mut BhCtx, dev_ptr: *mut c_void, bytes: usize, stream: *mut c_void) -> c_int;
     pub fn bh_ctx_synchronize(ctx: *mut BhCtx) -> c_int;
+    pub fn bh_ctx_accumulations_after(ctx: *mut BhCtx, stream: *mut c_void) -> c_int;
     pub fn bh_ctx_trim(ctx: *mut BhCtx) -> c_int;
     pub fn bh_fft_fr(ctx: *mut BhCtx, data_host: *mut c_void, log_n: u32, mode: c_int) -> c_int;
     pub fn bh_fft_fr_dev(ctx: *mut BhCtx, data_dev: *mut c_void, log_n: u32, mode: c_int, stream: *mut c_void) -> c_int;
