@@ -21,7 +21,7 @@ EXPORTS = [
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
-    "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after",
+    "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after", "bh_msm_start",
     "bh_msm_sharded_async", "bh_msm_sharded_wait",
     "bh_fixed_base_mul_dev",
     "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
@@ -133,6 +133,7 @@ def load():
     lib.bh_scalars_dev_ptr.restype = vp
     lib.bh_msm_async_scalars.argtypes = [vp, vp, sz, vp, sz, sz, vp, sz, vp, c.POINTER(vp)]
     lib.bh_msm_async_dev_after.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, vp, c.POINTER(vp)]
+    lib.bh_msm_start.argtypes = [vp]
     lib.bh_h_poly_fr_scalars.argtypes = [vp, vp, vp, vp, sz, c.POINTER(vp)]
     lib.bh_msm_sharded_async.argtypes = [vp, vp, sz, sz, vp, sz, i32, vp, sz, c.POINTER(vp)]
     lib.bh_msm_sharded_wait.argtypes = [vp, vp]

@@ -27,6 +27,7 @@ int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 ski
                     int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
 void msm_job_track(MsmJobImpl &job);
+int msm_job_start(MsmJobImpl &job);
 bool msm_slot_try_reserve(Context &c);
 void msm_slot_release(Context &c);
 bool msm_complete_oldest(Context &c);
@@ -355,6 +356,7 @@ void bh_ctx_destroy(bh_ctx *ctx) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
     if (r.dep_event) (void)hipEventDestroy(r.dep_event);
     if (r.acc_event) (void)hipEventDestroy(r.acc_event);
+    if (r.sort_event) (void)hipEventDestroy(r.sort_event);
     if (r.pinned) (void)hipHostFree(r.pinned);
     if (r.hp_event) (void)hipEventDestroy(r.hp_event);
     if (r.hp_stream) (void)hipStreamDestroy(r.hp_stream);
@@ -1121,6 +1123,11 @@ int bh_msm_async_dev_after(bh_ctx *ctx, const bh_bases *bases, size_t skip, cons
   if (!after_stream) return BH_ERR_INVALID_ARG;
   return msm_common(ctx, bases, skip, scalars_dev, false, n, fmt, density_words_dev, false, density_len, opts, job, 0,
                     after_stream);
+}
+int bh_msm_start(bh_msm_job *job) {
+  if (!job) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(job->impl->ctx->device));
+  return msm_job_start(*job->impl);
 }
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;

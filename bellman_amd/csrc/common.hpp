@@ -124,6 +124,7 @@ struct JobResources {
   // high-priority stream, ordered after the accumulation by an event
   hipStream_t hp_stream = nullptr;
   hipEvent_t hp_event = nullptr;
+  hipEvent_t sort_event = nullptr; // lazily created: end of the digit / sort stage of a held job (BH_MSM_HOLD)
   hipEvent_t acc_event = nullptr;  // lazily created: recorded after the job's bucket accumulation launch (the accumulation chain)
   hipEvent_t dep_event = nullptr;  // lazily created: orders the job after another stream (bh_msm_async_dev_after)
   void *pinned = nullptr;          // host-pinned landing buffer for the job's result

@@ -216,6 +216,13 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // skipped scalars would have consumed (all of them without a density map, the set bits with one)
   DevBuf dscratch(ctx, log_m > 11 ? m * 32 : 32);   // FFT ping-pong vector of the h block
   StreamDrain drain2{ps};                            // (drains before dscratch is released)
+  // Large proofs issue their multiexps in two phases (BH_MSM_HOLD / bh_msm_start): first every job's digit + sort stage
+  // (and, beside them, the h block), then the bucket accumulations in chain order - G2 (the longest job, whose reduction
+  // tail then overlaps the G1 accumulations), L, A, B_g1, and H last.  A sort that runs beside an accumulation takes
+  // its SIMDs: the G2 accumulation took 6.7 ms inside a proof against 5.5 alone (profiles/r3_call5_proof_timeline.txt).
+  // BELLMAN_HIP_PROOF_HOLD=0 restores the single-phase issue.
+  static const bool hold_env = [] { const char *e = getenv("BELLMAN_HIP_PROOF_HOLD"); return !(e && *e == '0'); }();
+  const bool hold_jobs = hold_env && log_m > 16;
   auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
                    const uint64_t *dens_host, bh_msm_job **job, const void *scalars_host = nullptr) {
     const Slice sl = slice_of(n, part, parts);
@@ -228,8 +235,9 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
       BH_TRACE("  multiexp of %zu terms answered on the host", sl.hi - sl.lo);
       return;
     }
-    check(bh_msm_async_dev(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
-                           dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, job));
+    const bh_msm_opts held = {0, 0, hold_jobs ? BH_MSM_HOLD : 0u};
+    check(bh_msm_async_dev_opts(ctx, bases, base_skip, (const char *)scalars + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT,
+                                dens_dev ? dens_dev + sl.lo / 64 : nullptr, dens_dev ? sl.hi - sl.lo : 0, &held, job));
     BH_TRACE("  multiexp of %zu terms issued", sl.hi - sl.lo);
   };
   auto issue_seven = [&](bool longest_first) {
@@ -297,8 +305,9 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     // host stages a, b, c (96 MiB of pageable memory at 2^20).
     auto issue_h = [&] {
       const Slice sl = slice_of(m - 1, part, parts);   // a.len() - 1, :238-244
+      const bh_msm_opts held = {0, 0, hold_jobs ? BH_MSM_HOLD : 0u};
       check(bh_msm_async_dev_after(ctx, params.h, sl.lo, (const char *)da.p + sl.lo * 32, sl.hi - sl.lo, BH_SCALARS_MONT, nullptr,
-                                   0, nullptr, ps.st, &h_job));
+                                   0, &held, ps.st, &h_job));
     };
     // Issue order = order of the bucket accumulations on the device (the accumulation chain, common.hpp): the G2
     // multiexp first - the longest job, its reduction tail then runs beside the G1 accumulations - and H last, by which
@@ -312,6 +321,8 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     issue_seven(true);
     if (src.host) enqueue_h_block();
     issue_h();
+    if (hold_jobs)   // second phase, in chain order
+      for (bh_msm_job *j : {b2_aux_job, l_job, a_aux_job, b1_aux_job, h_job, a_in_job, b1_in_job, b2_in_job}) check(bh_msm_start(j));
     BH_TRACE("7 multiexps + h block + H issued; n_cons=%zu m=%zu", n_cons, m);
     t1 = now_ms();
   }

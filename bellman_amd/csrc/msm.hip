@@ -140,6 +140,14 @@ static void msm_job_untrack(MsmJobImpl &job) {
   std::lock_guard<std::mutex> g(job.ctx->job_mu);
   job.ctx->inflight.remove(&job);
 }
+// starts a job that was issued with BH_MSM_HOLD (no-op otherwise)
+int msm_job_start(MsmJobImpl &job) {
+  std::lock_guard<std::mutex> g(job.mu);
+  if (job.done || !job.resume) return BH_OK;
+  const int rc = job.resume();
+  job.resume = nullptr;
+  return rc;
+}
 size_t msm_jobs_in_flight(Context &c) {
   std::lock_guard<std::mutex> g(c.job_mu);
   return c.inflight.size();

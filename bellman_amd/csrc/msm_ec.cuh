@@ -652,6 +652,22 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     if (rc) return rc;
   }
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_sorted, st));
+  const bool hold = (opts.flags & BH_MSM_HOLD) != 0;
+  if (hold) {
+    // the digit / sort stage of a held job joins the barrier set of the accumulation chain: whichever accumulation is
+    // started first waits for the sorts of ALL jobs issued so far (create_proof issues its multiexps held, then starts
+    // them in chain order - no sort runs beside an accumulation and steals its SIMDs)
+    if (!job.res.sort_event) BH_HIP_CHECK(hipEventCreateWithFlags(&job.res.sort_event, hipEventDisableTiming));
+    BH_HIP_CHECK(hipEventRecord(job.res.sort_event, st));
+    std::lock_guard<std::mutex> g(c.acc_mu);
+    if (c.pending_barriers.size() < 32) c.pending_barriers.push_back(job.res.sort_event);
+  }
+  // everything after the sort: run now, or when the job is started (bh_msm_start / its wait)
+  Context *cp = &c;
+  MsmJobImpl *jp = &job;
+  job.resume = [=]() mutable -> int {
+  Context &c = *cp;
+  MsmJobImpl &job = *jp;
   // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
   {
     const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
@@ -786,6 +802,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   if (job.host_result_bytes > job.res.pinned_bytes) return BH_ERR_INVALID_ARG;
   BH_HIP_CHECK(hipMemcpyAsync(job.host_result, ws + o_err, job.host_result_bytes, hipMemcpyDeviceToHost, st));
   return BH_OK;
+  };   // job.resume
+  if (hold) return BH_OK;
+  const int rc2 = job.resume();
+  job.resume = nullptr;
+  return rc2;
 }
 
 template <> struct HostOf<FpOps> { typedef HostFpOps type; };
@@ -836,6 +857,10 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     memset(out_affine, 0, sizeof(Affine<F>));
     if (ms) ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
     return job.early_rc;
+  }
+  if (job.resume) {   // held and never started: start it now
+    rc = job.resume();
+    job.resume = nullptr;
   }
   if (hipStreamSynchronize(job.stream) != hipSuccess) rc = BH_ERR_HIP;
   if (job.hp_stream && hipStreamSynchronize(job.hp_stream) != hipSuccess) rc = BH_ERR_HIP;

@@ -90,6 +90,7 @@ struct MsmJobImpl {
   u64 ref_n = 0;                     // MsmOpts::ref_n
   bool always_resolve_ident = false;
   bool saw_eof = false, saw_ident = false, saw_ident_top = false;   // after completion
+  std::function<int()> resume;       // the stages after the sort of a job issued with BH_MSM_HOLD (until it is started)
   std::mutex mu;
   bool done = false;
   int done_rc = BH_OK;

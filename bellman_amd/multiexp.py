@@ -184,7 +184,7 @@ class MsmOpts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_uint32), ("chunk", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
 
 
-ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES = 1, 2, 4, 8, 16, 32, 64
+ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES, HOLD = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,
@@ -223,7 +223,9 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
         check(lib.bh_msm_wait_profile(job, out.ctypes.data_as(ctypes.c_void_p), ms), "multiexp.wait")
         return (out, list(ms)) if timed else out
 
-    return Waiter(fn=finish)
+    w_ = Waiter(fn=finish)
+    w_.start = lambda: check(lib.bh_msm_start(job), "multiexp.start")   # for jobs issued with flags=HOLD
+    return w_
 
 
 class Scalars:

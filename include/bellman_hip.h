@@ -241,6 +241,7 @@ typedef struct {
 #define BH_MSM_NO_TABLE 4u      /* ignore a window table attached to the bases */
 #define BH_MSM_NO_SMALL_PATH 8u /* run the full pipeline even for a handful of terms */
 #define BH_MSM_STAGE_TIMES 64u  /* record the per-stage HIP events bh_msm_wait_profile reports (4 extra API calls) */
+#define BH_MSM_HOLD 128u        /* enqueue only the digit / sort stage; bh_msm_start (or the job's wait) enqueues the rest */
 #define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default from 2^18 terms) */
 #define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^18 terms) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
@@ -249,6 +250,12 @@ int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
 int bh_msm_async_dev_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_dev,
                           size_t n_scalars, int scalar_fmt, const uint64_t *density_words_dev,
                           size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);
+/* Two-phase issue (scheduling only; results never depend on it): a job issued with BH_MSM_HOLD enqueues its digit and
+ * sort stages and stops; bh_msm_start enqueues bucket accumulation, reductions and the result copy.  Chip-filling
+ * accumulations run in the order they are started, and the first one started waits for the sort stages of every held
+ * job issued before it: create_proof issues its multiexps held and starts them longest first, so that no sort runs
+ * beside an accumulation.  bh_msm_wait on a job that was never started starts it. */
+int bh_msm_start(bh_msm_job *job);
 
 /* as bh_msm_async_dev_opts, with the job ORDERED AFTER everything enqueued so far on `after_stream` (a stream of
  * bh_stream_create, or any hipStream_t of this device): the scalars may still be being produced there - create_proof's

@@ -150,6 +150,7 @@ extern "C" {
     pub fn bh_point_lincomb(group: c_int, r: *mut c_void, points: *const c_void, scalars_canonical: *const c_void, n: usize);
     pub fn bh_msm_async_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_host: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
     pub fn bh_msm_async_dev_opts(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_dev: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words_dev: *const u64, density_len: usize, opts: *const BhMsmOpts, job: *mut *mut BhMsmJob) -> c_int;
+    pub fn bh_msm_start(job: *mut BhMsmJob) -> c_int;
     pub fn bh_msm_async_dev_after(ctx: *mut BhCtx, bases: *const BhBases, skip: usize, scalars_dev: *const c_void, n_scalars: usize, scalar_fmt: c_int, density_words_dev: *const u64, density_len: usize, opts: *const BhMsmOpts, after_stream: *mut c_void, job: *mut *mut BhMsmJob) -> c_int;
     pub fn bh_scalars_register(ctx: *mut BhCtx, scalars_host: *const c_void, n: usize, scalar_fmt: c_int, out: *mut *mut BhScalars) -> c_int;
     pub fn bh_scalars_adopt_dev(ctx: *mut BhCtx, scalars_dev: *mut c_void, n: usize, scalar_fmt: c_int, take_ownership: c_int, out: *mut *mut BhScalars) -> c_int;

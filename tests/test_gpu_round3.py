@@ -428,3 +428,28 @@ def test_async_proofs_two_deep_equal_the_synchronous_ones(worker):
         wait()
     assert worker.info()["jobs_in_flight"] == 0
     r1cs.release()
+
+
+def test_held_jobs_two_phase_issue(worker):
+    """BH_MSM_HOLD / bh_msm_start: jobs issued held (digit + sort stage only), started in another order or not at all
+    (the wait starts them) - the results are those of the plain call, whatever the plan (classic, window table, G2)."""
+    import bellman_amd
+    from bellman_amd.multiexp import HOLD
+
+    cases = []
+    for i, (g, n) in enumerate([(1, 1 << 17), (2, 1 << 13), (1, 3000), (2, 1 << 16), (1, 5)]):
+        bases = cref.gen_bases(g, n, a=i + 3, b=7)
+        sc = cref.random_fr(n, 4000 + i)
+        cases.append((bellman_amd.Bases(worker, g, bases), sc, cref.multiexp(g, bases, 0, None, sc)[1]))
+    for order in ("reverse", "none", "forward"):
+        jobs = [bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=HOLD) for hb, sc, _ in cases]
+        if order == "reverse":
+            for j in reversed(jobs):
+                j.start()
+        elif order == "forward":
+            for j in jobs:
+                j.start()
+                j.start()   # idempotent
+        for j, (_, _, want) in zip(jobs, cases):
+            assert np.array_equal(j.wait(), want), order
+    assert worker.info()["jobs_in_flight"] == 0
