@@ -216,12 +216,12 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // skipped scalars would have consumed (all of them without a density map, the set bits with one)
   DevBuf dscratch(ctx, log_m > 11 ? m * 32 : 32);   // FFT ping-pong vector of the h block
   StreamDrain drain2{ps};                            // (drains before dscratch is released)
-  // Large proofs issue their multiexps in two phases (BH_MSM_HOLD / bh_msm_start): first every job's digit + sort stage
-  // (and, beside them, the h block), then the bucket accumulations in chain order - G2 (the longest job, whose reduction
-  // tail then overlaps the G1 accumulations), L, A, B_g1, and H last.  A sort that runs beside an accumulation takes
-  // its SIMDs: the G2 accumulation took 6.7 ms inside a proof against 5.5 alone (profiles/r3_call5_proof_timeline.txt).
-  // BELLMAN_HIP_PROOF_HOLD=0 restores the single-phase issue.
-  static const bool hold_env = [] { const char *e = getenv("BELLMAN_HIP_PROOF_HOLD"); return !(e && *e == '0'); }();
+  // Optional two-phase issue (BH_MSM_HOLD / bh_msm_start, BELLMAN_HIP_PROOF_HOLD=1): first every job's digit + sort
+  // stage, then the bucket accumulations in chain order.  Measured (profiles/r3_call6_hold_ab.txt): no gain for one proof
+  // - the accumulations are as slow with nothing beside them, 6.35 ms for G2 against 5.46 in a warm back-to-back loop:
+  // the chip has just left idle clocks after the host's 51 ms of witness generation - and 12 % less throughput with
+  // twelve proofs in flight (the sorts of one proof no longer fill the gaps of another).  Off by default.
+  static const bool hold_env = [] { const char *e = getenv("BELLMAN_HIP_PROOF_HOLD"); return e && *e == '1'; }();
   const bool hold_jobs = hold_env && log_m > 16;
   auto issue = [&](bh_bases *bases, size_t skip, const void *scalars, size_t n, const uint64_t *dens_dev,
                    const uint64_t *dens_host, bh_msm_job **job, const void *scalars_host = nullptr) {
