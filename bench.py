@@ -775,10 +775,10 @@ def main():
             if args.c5_proof_log_n:
                 out["create_proof_c5"] = bench_create_proof_c5(worker, args.c5_proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of this same command
-        # (tools/gpu_final.sh -> profiles/r2_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
+        # (tools/gpu_r3_final.sh -> profiles/r3_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
         # read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte
         # pieces, so `traffic` carries the read-corrected (doubled FETCH_SIZE) figure and the note the raw one.
-        for name in ("r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
+        for name in ("r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             except Exception:

@@ -79,6 +79,28 @@ int main(int argc, char **argv) {
     auto rng = [&state] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
     groth16::Proof q1 = groth16::create_random_proof(circuit, params, rng), q2 = groth16::create_random_proof(circuit, params, rng);
     if (memcmp(&q1, &q2, sizeof q1) == 0 || memcmp(&q1, &p, sizeof p) == 0) { fprintf(stderr, "create_random_proof is not random\n"); rc = 6; }
+    // one caller, proofs back to back (groth16::ProofPipeline): synthesis of proof k+1 beside the device part of proof k;
+    // every proof must equal create_proof's for the same x, r, s
+    {
+      groth16::ProofPipeline pipe(params, &r1cs, 2);
+      groth16::ProofPipeline pipe_host(params, nullptr, 2);
+      std::vector<groth16::Proof> want;
+      for (int i = 0; i < 5; i++) {
+        CubicDemo c;
+        c.x = x + Fr::from_u64((uint64_t)i);
+        want.push_back(groth16::create_proof(c, params, r + Fr::from_u64((uint64_t)i), s));
+        pipe.submit(c, r + Fr::from_u64((uint64_t)i), s);
+        pipe_host.submit(c, r + Fr::from_u64((uint64_t)i), s);
+      }
+      for (int i = 0; i < 5; i++) {
+        groth16::Proof a1 = pipe.next(), a2 = pipe_host.next();
+        if (memcmp(&a1, &want[i], sizeof a1) != 0 || memcmp(&a2, &want[i], sizeof a2) != 0) {
+          fprintf(stderr, "pipelined proof %d differs\n", i);
+          rc = 7;
+        }
+      }
+      if (pipe.pending() || pipe_host.pending()) rc = 8;
+    }
   } catch (const SynthesisError &e) {
     fprintf(stderr, "SynthesisError %d: %s\n", e.code, e.what());
     rc = 10 + e.code;
