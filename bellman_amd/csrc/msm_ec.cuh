@@ -189,6 +189,115 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   if (saw_identity) atomicOr(&err->ident, 1u);
 }
 
+// ============================================================================================
+// 4'. small multiexps over bases with a window table: digits + bucket accumulation in ONE launch, no sort
+// ============================================================================================
+// create_proof on a small circuit (MiMC-322: multiexps of 322-1023 terms) is bound by the number of launches - a job
+// was ~17 of them, ~8 us of host time each.  For up to SMALL_MAX_SCALARS scalars whose Wd digits all go to the one
+// bucket set of a window table, every workgroup recodes ALL scalars into signed digits in its LDS (a few scalars per
+// thread, redundantly per workgroup) and then each worker owns one bucket and scans the digit table for its entries:
+// density prefix, digits, radix sort, zero count, accumulation and the three merge kernels become one launch.
+// (profiles/r3_call7_small_fused.txt)
+constexpr u32 SMALL_MAX_SCALARS = 2048, SMALL_MAX_ENTRIES = 20480 + 1024, SMALL_MAX_PER_BUCKET = 16, SMALL_LIST_CAP = 24;
+constexpr u32 SMALL_THREADS = 256;
+// dynamic LDS of the kernel: base indices, digit table, per-bucket entry lists of the workgroup's buckets
+inline size_t small_fill_lds_bytes(u32 nd, u32 n_entries) {
+  return (size_t)nd * 4 + (((size_t)n_entries * 2 + 3) & ~size_t(3)) + SMALL_THREADS * 4 + (size_t)SMALL_THREADS * SMALL_LIST_CAP * 2;
+}
+template <class F>
+__global__ __launch_bounds__(SMALL_THREADS) void msm_small_fill_kernel(const void *scalars, int fmt, u32 nd, const u64 *density,
+                                                             u32 *word_prefix_out, u64 skip, u64 n_bases, u32 c, u32 Wd,
+                                                             u64 base_stride, const Affine<typename F::Mem> *table,
+                                                             XYZZ<typename F::Mem> *pts, ErrFlags *err) {
+  extern __shared__ u32 small_lds[];
+  const u32 n_entries = nd * Wd;
+  u32 *kidx = small_lds;                                   // [nd] base index of scalar i, ~0u = contributes nothing
+  short *dig = reinterpret_cast<short *>(small_lds + nd);  // [Wd][nd] signed digits
+  u32 *cnt = small_lds + nd + ((n_entries * 2 + 3) >> 2);  // [SMALL_THREADS] entries seen per bucket of this workgroup
+  unsigned short *lists = reinterpret_cast<unsigned short *>(cnt + SMALL_THREADS);   // [SMALL_THREADS][SMALL_LIST_CAP] entry ids
+  const u32 nwords = (nd + 63) / 64;
+  cnt[threadIdx.x] = 0;
+  // (a) every workgroup recodes all scalars (a few per thread)
+  for (u32 i = threadIdx.x; i < nd; i += blockDim.x) {
+    bool dense = true;
+    u64 k = skip + i;
+    if (density) {
+      const u64 word = density[i >> 6];
+      dense = (word >> (i & 63)) & 1;
+      u32 before = 0;
+      for (u32 w = 0; w < (i >> 6); w++) before += (u32)__popcll(density[w]);   // <= 32 words
+      k = skip + before + __popcll(word & (((u64)1 << (i & 63)) - 1));
+    }
+    bool live = dense;
+    if (dense && k >= n_bases) {   // every dense entry checks EOF first, whatever its scalar (multiexp.rs:55-61,74-80)
+      if (blockIdx.x == 0) atomicOr(&err->eof, 1u);
+      live = false;
+    }
+    fr_t s;
+    if (live) load_scalar(scalars, i, fmt, s);
+    const u32 half = 1u << (c - 1);
+    u32 carry = 0;
+    for (u32 w = 0; w < Wd; w++) {
+      u32 v = (live ? extract_bits(s, w * c, c) : 0) + carry;
+      carry = 0;
+      int d = (int)v;
+      if (v > half) { d = (int)v - (int)(1u << c); carry = 1; }
+      dig[w * nd + i] = (short)d;
+    }
+    kidx[i] = live ? (u32)k : 0xffffffffu;
+  }
+  if (blockIdx.x == 0 && density && word_prefix_out)   // the (rare) error-resolution pass wants the word prefix
+    for (u32 t = threadIdx.x; t <= nwords; t += blockDim.x) {
+      u32 before = 0;
+      for (u32 w = 0; w < t && w < nwords; w++) before += (u32)__popcll(density[w]);
+      word_prefix_out[t] = before;
+    }
+  __syncthreads();
+  // (b) the entries of this workgroup's buckets, one list per bucket (order within a list does not matter)
+  const u32 wpb = workers_per_block<F>(SMALL_THREADS, default_per_wave<F>());
+  const u32 bucket_lo = blockIdx.x * wpb;   // buckets [bucket_lo, bucket_lo + wpb), bucket index = |digit| - 1
+  for (u32 e = threadIdx.x; e < n_entries; e += blockDim.x) {
+    const int d = dig[e];
+    if (d == 0) continue;
+    const u32 bkt = (u32)(d < 0 ? -d : d) - 1;
+    if (bkt < bucket_lo || bkt >= bucket_lo + wpb) continue;
+    const u32 slot = atomicAdd(&cnt[bkt - bucket_lo], 1u);
+    if (slot < SMALL_LIST_CAP) lists[(bkt - bucket_lo) * SMALL_LIST_CAP + slot] = (unsigned short)e;
+  }
+  __syncthreads();
+  // (c) one worker per bucket
+  u32 in_block, worker;
+  const bool has_worker = worker_index<F>(default_per_wave<F>(), in_block, worker);
+  const u32 nb = 1u << (c - 1);
+  if (!has_worker || worker >= nb) return;
+  const u32 total = cnt[in_block];
+  XYZZ<F> acc;
+  xyzz_set_identity(acc);
+  bool saw_identity = false;
+  auto add_entry = [&](u32 e) {
+    const u32 w = e / nd, i = e - w * nd;
+    const u32 k = kidx[i];
+    if (k == 0xffffffffu) return;   // (cannot happen: such scalars have all-zero digits)
+    Affine<F> q;
+    load_affine<F>(q, table + ((u64)w * base_stride + k));
+    if (aff_is_identity(q)) { saw_identity = true; return; }
+    if (dig[e] < 0) F::neg(q.y, q.y);
+    xyzz_madd(acc, q);
+  };
+  if (total <= SMALL_LIST_CAP) {
+    for (u32 t = 0; t < total; t++) add_entry(lists[in_block * SMALL_LIST_CAP + t]);
+  } else {
+    // a bucket fuller than its list (many equal scalars - boolean witnesses put every 1 into bucket 1): scan the table
+    const int bucket = (int)worker + 1;
+    for (u32 e = 0; e < n_entries; e++) {
+      const int d = dig[e];
+      if (d == bucket || d == -bucket) add_entry(e);
+    }
+  }
+  store_xyzz<F>(&pts[worker], acc);
+  if (saw_identity) atomicOr(&err->ident, 1u);
+}
+
 // Last chunk that holds a head partial of the run with digit d, given that the run continues from chunk `lane`
 // into chunk lane + 1: the last chunk whose FIRST entry has digit d.  Galloping + binary search over the chunk
 // starts (8-byte probes of the sorted stream): one or two probes for the usual two-chunk run.
@@ -647,7 +756,19 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_begin, st));
   BH_HIP_CHECK(hipMemsetAsync(ws, 0, zero_bytes, st));
   const u64 *sorted = nullptr;
-  {
+  // small multiexps over a window table: one launch for everything up to the filled buckets (msm_small_fill_kernel)
+  static const bool small_on = [] { const char *e = getenv("BELLMAN_HIP_SMALL_FUSED"); return !(e && *e == '0'); }();
+  const bool small_fused = small_on && use_table && p.W == 1 && p.nd <= SMALL_MAX_SCALARS && p.n <= SMALL_MAX_ENTRIES &&
+                           (u64)p.n <= (u64)SMALL_MAX_PER_BUCKET * p.nb && p.c <= 15 && small_fill_lds_bytes(p.nd, p.n) <= 64 * 1024 &&
+                           !(opts.flags & BH_MSM_NO_SMALL_PATH);
+  if (small_fused) {
+    const u32 wpb = workers_per_block<F>(SMALL_THREADS, default_per_wave<F>());
+    const size_t lds = small_fill_lds_bytes(p.nd, p.n);
+    hipLaunchKernelGGL(msm_small_fill_kernel<F>, dim3((p.nb + wpb - 1) / wpb), dim3(SMALL_THREADS), lds, st, scalars_dev, fmt, p.nd,
+                       density_dev, b.word_prefix, (u64)skip, (u64)n_bases, p.c, p.Wd, p.base_stride,
+                       (const Affine<M> *)bases_dev, pts, err);
+    BH_HIP_CHECK(hipGetLastError());
+  } else {
     int rc = msm_run_stages(p, b, scalars_dev, fmt, density_dev, skip, n_bases, st, &sorted);
     if (rc) return rc;
   }
@@ -669,7 +790,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   Context &c = *cp;
   MsmJobImpl &job = *jp;
   // 4. accumulate equal chunks, then fold the buckets that straddle chunk boundaries
-  {
+  if (small_fused) {
+    if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_accum, st));
+  } else {
     const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
     const dim3 grid((p.chunks_per_window + wpb - 1) / wpb, p.W);
     const Affine<M> *bases = (const Affine<M> *)bases_dev;

@@ -453,3 +453,54 @@ def test_held_jobs_two_phase_issue(worker):
         for j, (_, _, want) in zip(jobs, cases):
             assert np.array_equal(j.wait(), want), order
     assert worker.info()["jobs_in_flight"] == 0
+
+
+@pytest.mark.parametrize("n", [9, 64, 322, 645, 1023])
+def test_small_multiexp_single_launch_path(worker, n):
+    """the one-launch path of small multiexps over a window table (msm_small_fill_kernel: MiMC-sized jobs) against the
+    oracle AND against the full pipeline (BH_MSM_NO_SMALL_PATH), with: a density map + skip, Montgomery scalars, the
+    scalars 0 / 1 / q-1, a bucket far fuller than its list (every other scalar equal: the table-scan fallback), EOF and
+    identity errors with the reference's precedence."""
+    import bellman_amd
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+    from bellman_amd.multiexp import NO_SMALL_PATH
+
+    rnd = np.random.default_rng(n)
+    bases = cref.gen_bases(1, n + 3, a=n, b=3)
+    hb = bellman_amd.Bases(worker, 1, bases)
+    assert hb.table_info()[1] > 0          # registered with its window table: the fused path applies
+    sc = cref.random_fr(n, 9000 + n)
+    sc[0] = 0
+    sc[1] = cref.ints_to_arr([1], 4)[0]
+    sc[2] = cref.ints_to_arr([cref.Q - 1], 4)[0]
+    sc[3::2] = cref.ints_to_arr([0x123456789ABCDEF], 4)[0]      # ~n/2 equal scalars: their buckets overflow the lists
+    bits = rnd.random(n) < 0.7
+    dt = bellman_amd.DensityTracker()
+    dt.bv = bits
+    for dens, dens_c, skip in ((bellman_amd.FullDensity(), None, 3), (dt, cref.density_bitmap(bits), 2)):
+        rc, want = cref.multiexp(1, bases, skip, dens_c, sc)
+        assert rc == 0
+        got = bellman_amd.multiexp(worker, hb, dens, sc, skip=skip).wait()
+        full = bellman_amd.multiexp(worker, hb, dens, sc, skip=skip, flags=NO_SMALL_PATH).wait()
+        mont = bellman_amd.multiexp(worker, hb, dens, cref.fr_to_mont(sc), skip=skip, mont=True).wait()
+        assert np.array_equal(got, want) and np.array_equal(full, want) and np.array_equal(mont, want)
+    # errors: identity under a non-zero scalar; EOF; both (top-window precedence); identity under a zero scalar is unseen
+    b2 = bases.copy()
+    b2[5] = 0
+    hb2 = bellman_amd.Bases(worker, 1, b2)
+    short = bellman_amd.Bases(worker, 1, b2[: n - 1])
+    for handle, arr, s in ((hb2, b2, sc), (short, b2[: n - 1], sc), (short, bases[: n - 1], sc)):
+        rc, want = cref.multiexp(1, arr, 0, None, s)
+        try:
+            got = bellman_amd.multiexp(worker, handle, bellman_amd.FullDensity(), s).wait()
+            assert rc == 0 and np.array_equal(got, want)
+        except UnexpectedIdentity:
+            assert rc == 1
+        except UnexpectedEof:
+            assert rc == 2
+    s0 = sc.copy()
+    s0[5] = 0
+    rc, want = cref.multiexp(1, b2, 0, None, s0)
+    assert rc == 0 and np.array_equal(bellman_amd.multiexp(worker, hb2, bellman_amd.FullDensity(), s0).wait(), want)
+    for h in (hb, hb2, short):
+        h.release()
