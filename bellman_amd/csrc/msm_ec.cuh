@@ -198,8 +198,10 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
 // thread, redundantly per workgroup) and then each worker owns one bucket and scans the digit table for its entries:
 // density prefix, digits, radix sort, zero count, accumulation and the three merge kernels become one launch.
 // (profiles/r3_call7_small_fused.txt)
+template <class F>
+__device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub);   // defined with the merge kernels
 constexpr u32 SMALL_MAX_SCALARS = 2048, SMALL_MAX_ENTRIES = 20480 + 1024, SMALL_MAX_PER_BUCKET = 16, SMALL_LIST_CAP = 24;
-constexpr u32 SMALL_THREADS = 256;
+constexpr u32 SMALL_THREADS = 256, SMALL_LANES_PER_BUCKET = 4;
 // dynamic LDS of the kernel: base indices, digit table, per-bucket entry lists of the workgroup's buckets
 inline size_t small_fill_lds_bytes(u32 nd, u32 n_entries) {
   return (size_t)nd * 4 + (((size_t)n_entries * 2 + 3) & ~size_t(3)) + SMALL_THREADS * 4 + (size_t)SMALL_THREADS * SMALL_LIST_CAP * 2;
@@ -254,23 +256,29 @@ __global__ __launch_bounds__(SMALL_THREADS) void msm_small_fill_kernel(const voi
     }
   __syncthreads();
   // (b) the entries of this workgroup's buckets, one list per bucket (order within a list does not matter)
-  const u32 wpb = workers_per_block<F>(SMALL_THREADS, default_per_wave<F>());
-  const u32 bucket_lo = blockIdx.x * wpb;   // buckets [bucket_lo, bucket_lo + wpb), bucket index = |digit| - 1
+  constexpr u32 PW = tree_per_wave<F>();                        // workers per wavefront (a power of two)
+  const u32 wpb = workers_per_block<F>(SMALL_THREADS, PW);
+  const u32 bpb = wpb / SMALL_LANES_PER_BUCKET;                 // buckets per workgroup
+  const u32 bucket_lo = blockIdx.x * bpb;   // buckets [bucket_lo, bucket_lo + bpb), bucket index = |digit| - 1
   for (u32 e = threadIdx.x; e < n_entries; e += blockDim.x) {
     const int d = dig[e];
     if (d == 0) continue;
     const u32 bkt = (u32)(d < 0 ? -d : d) - 1;
-    if (bkt < bucket_lo || bkt >= bucket_lo + wpb) continue;
+    if (bkt < bucket_lo || bkt >= bucket_lo + bpb) continue;
     const u32 slot = atomicAdd(&cnt[bkt - bucket_lo], 1u);
     if (slot < SMALL_LIST_CAP) lists[(bkt - bucket_lo) * SMALL_LIST_CAP + slot] = (unsigned short)e;
   }
   __syncthreads();
-  // (c) one worker per bucket
+  // (c) SMALL_LANES_PER_BUCKET workers per bucket: every worker adds every 4th entry of the list, then a shuffle tree.
+  // (One worker per bucket made the launch as long as the FULLEST bucket of a wavefront - 12 entries where the average
+  // is 5 - at 15 us per addition; the chip is nearly empty during these launches, so lanes are free.)
   u32 in_block, worker;
-  const bool has_worker = worker_index<F>(default_per_wave<F>(), in_block, worker);
+  const bool has_worker = worker_index<F>(PW, in_block, worker);
   const u32 nb = 1u << (c - 1);
-  if (!has_worker || worker >= nb) return;
-  const u32 total = cnt[in_block];
+  const u32 local = in_block / SMALL_LANES_PER_BUCKET, sub = in_block % SMALL_LANES_PER_BUCKET;
+  const u32 bkt = bucket_lo + local;
+  const bool active = has_worker && local < bpb && bkt < nb;
+  const u32 total = active ? cnt[local] : 0;
   XYZZ<F> acc;
   xyzz_set_identity(acc);
   bool saw_identity = false;
@@ -285,16 +293,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void msm_small_fill_kernel(const voi
     xyzz_madd(acc, q);
   };
   if (total <= SMALL_LIST_CAP) {
-    for (u32 t = 0; t < total; t++) add_entry(lists[in_block * SMALL_LIST_CAP + t]);
+    for (u32 t = sub; t < total; t += SMALL_LANES_PER_BUCKET) add_entry(lists[local * SMALL_LIST_CAP + t]);
   } else {
     // a bucket fuller than its list (many equal scalars - boolean witnesses put every 1 into bucket 1): scan the table
-    const int bucket = (int)worker + 1;
+    const int bucket = (int)bkt + 1;
+    u32 seen = 0;
     for (u32 e = 0; e < n_entries; e++) {
       const int d = dig[e];
-      if (d == bucket || d == -bucket) add_entry(e);
+      if (d == bucket || d == -bucket) {
+        if (seen % SMALL_LANES_PER_BUCKET == sub) add_entry(e);
+        seen++;
+      }
     }
   }
-  store_xyzz<F>(&pts[worker], acc);
+  group_reduce_points<F>(acc, SMALL_LANES_PER_BUCKET, sub);   // every lane of the wavefront takes part in the shuffles
+  if (active && sub == 0) store_xyzz<F>(&pts[bkt], acc);
   if (saw_identity) atomicOr(&err->ident, 1u);
 }
 
@@ -762,9 +775,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                            (u64)p.n <= (u64)SMALL_MAX_PER_BUCKET * p.nb && p.c <= 15 && small_fill_lds_bytes(p.nd, p.n) <= 64 * 1024 &&
                            !(opts.flags & BH_MSM_NO_SMALL_PATH);
   if (small_fused) {
-    const u32 wpb = workers_per_block<F>(SMALL_THREADS, default_per_wave<F>());
+    const u32 bpb = workers_per_block<F>(SMALL_THREADS, tree_per_wave<F>()) / SMALL_LANES_PER_BUCKET;   // buckets per workgroup
     const size_t lds = small_fill_lds_bytes(p.nd, p.n);
-    hipLaunchKernelGGL(msm_small_fill_kernel<F>, dim3((p.nb + wpb - 1) / wpb), dim3(SMALL_THREADS), lds, st, scalars_dev, fmt, p.nd,
+    hipLaunchKernelGGL(msm_small_fill_kernel<F>, dim3((p.nb + bpb - 1) / bpb), dim3(SMALL_THREADS), lds, st, scalars_dev, fmt, p.nd,
                        density_dev, b.word_prefix, (u64)skip, (u64)n_bases, p.c, p.Wd, p.base_stride,
                        (const Affine<M> *)bases_dev, pts, err);
     BH_HIP_CHECK(hipGetLastError());
