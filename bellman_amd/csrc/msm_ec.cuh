@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include <array>
 #include <cmath>
@@ -573,6 +574,154 @@ __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void
   if (live && sub == 0 && g < d.groups) store_xyzz<F>(&out[g], acc);
 }
 
+// ============================================================================================
+// 5'. G1 point additions on lane PAIRS ("K2") for the latency-bound reductions
+// ============================================================================================
+// A reduction launch of a small or medium job uses a fraction of the chip and is a chain of dependent point additions
+// (~14 deep for 4096 buckets), each 8.2 K instructions = 20 us on a wavefront that has its SIMD to itself.  Lanes are free
+// there, so a point is split over two neighbouring lanes - the even lane holds (X, ZZ), the odd lane (Y, ZZZ) - and the
+// general addition add-2008-s runs as SEVEN lane-local product slots instead of fourteen products:
+//     slot   even lane (x side)        odd lane (y side)
+//      1     U1 = X1 ZZ2               S1 = Y1 ZZZ2
+//      2     U2 = X2 ZZ1               S2 = Y2 ZZZ1            then  P = U2 - U1 | R = S2 - S1
+//      3     PP = P^2                  RR = R^2                exchange: x gets RR, y gets PP
+//      4     PPP = P PP                ZT = ZZZ1 ZZZ2          exchange: y gets PPP
+//      5     Q = U1 PP                 S1P = S1 PPP            x: X3 = RR - PPP - 2Q, D = Q - X3; exchange: y gets D
+//      6     T = ZZ1 ZZ2               ZZZ3 = ZT PPP
+//      7     ZZ3 = T PP                Y3 = R D - S1P
+// (three 12-word DPP exchanges, quad_perm [1,0,3,2]); an addition has about half the latency of the one-lane form, and a
+// worker holds 24 words of state instead of 48.  The rare equal-points case falls back to the one-lane doubling,
+// computed redundantly by both lanes.  Only the reduction kernels of G1 use it, and only for launches that leave at
+// least half of the SIMDs empty (msm_enqueue).
+struct HalfPt {
+  fp_t u, v;   // even lane: X, ZZ    odd lane: Y, ZZZ
+};
+__device__ __forceinline__ u32 k2_role() { return k3_lane() & 1u; }
+__device__ __forceinline__ fp_t k2_swap(const fp_t &x) {   // the value held by the other lane of my pair
+  fp_t r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.l[i], 0xB1, 0xf, 0xf, false);
+  return r;
+}
+__device__ __forceinline__ bool k2_flag_from(bool mine, u32 want_role) {   // the predicate as the `want_role` lane of my pair sees it
+  const u32 lane = k3_lane();
+  const u64 m = __ballot(mine);
+  return (m >> ((lane & ~1u) | want_role)) & 1;
+}
+__device__ __forceinline__ fp_t k2_sel(bool odd, const fp_t &even_v, const fp_t &odd_v) {
+  fp_t r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = odd ? odd_v.l[i] : even_v.l[i];
+  return r;
+}
+__device__ __forceinline__ void k2_load(HalfPt &h, const XYZZ<FpOps> *p) {
+  const bool odd = k2_role();
+  h.u = odd ? p->y : p->x;
+  h.v = odd ? p->zzz : p->zz;
+}
+__device__ __forceinline__ void k2_store(XYZZ<FpOps> *p, const HalfPt &h) {
+  if (k2_role()) { p->y = h.u; p->zzz = h.v; } else { p->x = h.u; p->zz = h.v; }
+}
+__device__ __forceinline__ void k2_set_identity(HalfPt &h) { fe_zero(h.u); fe_zero(h.v); }
+__device__ __forceinline__ bool k2_is_identity(const HalfPt &h) { return k2_flag_from(fpl_is_zero(h.v), 0u); }   // ZZ == 0
+// r = a + b; r may alias a.  Every lane of a pair takes the same branches.
+__device__ __forceinline__ void k2_add(HalfPt &r, const HalfPt &a, const HalfPt &b) {
+  const bool odd = k2_role();
+  if (k2_is_identity(a)) { r = b; return; }
+  if (k2_is_identity(b)) { r = a; return; }
+  fp_t t1 = fp_mul_call(a.u, b.v);          // U1 | S1
+  fp_t t2 = fp_mul_call(b.u, a.v);          // U2 | S2
+  fp_t d;
+  fpl_sub(d, t2, t1);                       // P | R
+  const bool dz = fpl_is_zero(d);
+  if (k2_flag_from(dz, 0u)) {               // P == 0: the same x coordinate
+    if (k2_flag_from(dz, 1u)) {             // ... and R == 0: the same point - one-lane doubling, both lanes redundantly
+      XYZZ<FpOps> full, dbl;
+      const fp_t ou = k2_swap(a.u), ov = k2_swap(a.v);
+      full.x = odd ? ou : a.u; full.y = odd ? a.u : ou;
+      full.zz = odd ? ov : a.v; full.zzz = odd ? a.v : ov;
+      xyzz_dbl(dbl, full);
+      r.u = odd ? dbl.y : dbl.x;
+      r.v = odd ? dbl.zzz : dbl.zz;
+    } else {
+      k2_set_identity(r);                   // opposite points
+    }
+    return;
+  }
+  const fp_t sq = fp_sqr_call(d);           // PP | RR
+  const fp_t osq = k2_swap(sq);             // x lane: RR    y lane: PP
+  const fp_t pp = odd ? osq : sq;           // PP in both lanes
+  // slot 4: P PP | ZZZ1 ZZZ2
+  const fp_t m4 = fp_mul_call(k2_sel(odd, d, a.v), k2_sel(odd, sq, b.v));
+  const fp_t om4 = k2_swap(m4);
+  const fp_t ppp = odd ? om4 : m4;          // PPP in both lanes
+  // slot 5: U1 PP | S1 PPP
+  const fp_t m5 = fp_mul_call(t1, k2_sel(odd, pp, ppp));        // Q | S1P
+  fp_t x3, dq;
+  fpl_sub(x3, osq, ppp);                    // x lane: RR - PPP (the y lane computes garbage it never uses)
+  fpl_sub(x3, x3, m5);
+  fpl_sub(x3, x3, m5);                      // X3 = RR - PPP - 2Q
+  fpl_sub(dq, m5, x3);                      // Q - X3
+  const fp_t odq = k2_swap(dq);             // y lane: Q - X3
+  // slot 6: ZZ1 ZZ2 | ZT PPP
+  const fp_t m6 = fp_mul_call(k2_sel(odd, a.v, m4), k2_sel(odd, b.v, ppp));   // T | ZZZ3
+  // slot 7: T PP | R (Q - X3)
+  const fp_t m7 = fp_mul_call(k2_sel(odd, m6, d), k2_sel(odd, pp, odq));      // ZZ3 | R (Q - X3)
+  fp_t y3;
+  fpl_sub(y3, m7, m5);                      // y lane: Y3 = R (Q - X3) - S1P
+  r.u = odd ? y3 : x3;
+  r.v = odd ? m6 : m7;
+}
+// shuffle tree over groups of G consecutive lane pairs of one wavefront (G a power of two <= 32)
+__device__ __forceinline__ void k2_group_reduce(HalfPt &acc, u32 G, u32 sub) {
+  for (u32 off = G >> 1; off >= 1; off >>= 1) {
+    HalfPt o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      o.u.l[i] = __shfl_down(acc.u.l[i], off * 2);
+      o.v.l[i] = __shfl_down(acc.v.l[i], off * 2);
+    }
+    if (sub < off) k2_add(acc, acc, o);   // pairs take the branch together (sub is a property of the pair)
+  }
+}
+// msm_sum_kernel for G1 with lane-pair workers: one wavefront = 32 workers per block
+template <class FK>   // always FpOps: a template only so that both translation units may see the definition
+__global__ __launch_bounds__(64) void msm_sum_k2_kernel(SumJobs<FK> jobs) {
+  u32 blk = blockIdx.x;
+  u32 which = 0;
+  if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
+  const SumDesc d = jobs.j[which].d;
+  const XYZZ<FpOps> *in = jobs.j[which].in;
+  XYZZ<FpOps> *out = jobs.j[which].out;
+  const u32 t = threadIdx.x >> 1;           // worker inside the block
+  const u32 G = d.lanes;                    // workers per output (<= 32)
+  const u32 g = (blk * 32 + t) / G;
+  const u32 sub = t & (G - 1);
+  HalfPt acc;
+  k2_set_identity(acc);
+  if (g < d.groups) {
+    const u32 outer = g / d.inner, in_idx = g % d.inner;
+    const XYZZ<FpOps> *base = in + ((u64)outer << d.group_shift);
+    if (d.mode == SUM_STRIDED) {
+      for (u32 k = sub; k < d.count; k += G) {
+        HalfPt o;
+        k2_load(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
+        k2_add(acc, acc, o);
+      }
+    } else {  // SUM_BITS: in_idx = bit position
+      for (u32 i = sub; i < d.count; i += G) {
+        if ((i >> in_idx) & 1) {
+          HalfPt o;
+          k2_load(o, base + i);
+          k2_add(acc, acc, o);
+        }
+      }
+    }
+  }
+  k2_group_reduce(acc, G, sub);
+  if (sub == 0 && g < d.groups) k2_store(&out[g], acc);
+}
+
 // Resident wavefronts per SIMD the lane cost model assumes for the reduction kernels: [0] G1, [1] G2 one lane per
 // point, [2] G2 lane triples.  One each: a second resident wavefront does NOT interleave for free in these mad-bound
 // chains (profiles/r2_call8_slots.txt: G1 2^17-2^20 reduce 0.73-0.99 ms with 1, 0.92-1.19 ms with 2; G2 within noise).
@@ -886,6 +1035,27 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     j.nblocks = blocks_for(d.groups, d.lanes);
     return j;
   };
+  // G1 launches that leave at least half of the SIMDs empty run on lane pairs (K2, above): half the latency per
+  // addition for twice the lanes.  BELLMAN_HIP_SUM_K2=0 switches it off.
+  static const bool k2_on = [] { const char *e = getenv("BELLMAN_HIP_SUM_K2"); return !(e && *e == '0'); }();
+  auto launch_sums = [&](SumJobs<FR> js) -> bool {
+    const u32 total = js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks;
+    if (!total) return true;
+    if constexpr (std::is_same<FR, FpOps>::value) {
+      if (k2_on && (u64)total * 2 <= (u64)c.num_cus * 4) {   // blocks are single wavefronts
+        for (int q = 0; q < 3; q++) {
+          SumJob<FR> &j = js.j[q];
+          if (!j.nblocks) continue;
+          if (j.d.lanes > 32) j.d.lanes = 32;                  // a wavefront carries 32 lane pairs
+          j.nblocks = (u32)(((u64)j.d.groups * j.d.lanes + 31) / 32);
+        }
+        hipLaunchKernelGGL(msm_sum_k2_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
+        return hipGetLastError() == hipSuccess;
+      }
+    }
+    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(total), dim3(sum_block_threads<FR>()), 0, st, js);
+    return hipGetLastError() == hipSuccess;
+  };
   {
     const u32 cb = p.c - 1;   // bits of a bucket index
     SumDesc dr, dc;
@@ -911,8 +1081,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       js.j[0].d.lanes = best_r; js.j[0].nblocks = blocks_for(dr.groups, best_r);
       js.j[1].d.lanes = best_c; js.j[1].nblocks = blocks_for(dc.groups, best_c);
     }
-    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks), dim3(sum_block_threads<FR>()), 0, st, js);
-    BH_HIP_CHECK(hipGetLastError());
+    if (!launch_sums(js)) return BH_ERR_HIP;
     // sum_idx (idx+1) B[idx] = sum_p 2^p U[p] + T, idx = hi*2^l + lo:
     //   U[w][p], p < lo_bits from the column sums (weights lo), p >= lo_bits from the row sums (weights hi),
     //   T[w] = plain sum of all buckets = sum of the row sums.
@@ -928,9 +1097,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     js.j[0] = make_job(cols, bits, bl);
     js.j[1] = make_job(rows, bits + (u64)p.W * p.lo_bits, bh_);
     js.j[2] = make_job(t_from_cols ? cols : rows, bits + (u64)p.W * cb, bt);
-    hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(sum_block_threads<FR>()), 0,
-                       st, js);
-    BH_HIP_CHECK(hipGetLastError());
+    if (!launch_sums(js)) return BH_ERR_HIP;
   }
   if (job.timed) BH_HIP_CHECK(hipEventRecord(job.ev_end, st));
   // status words + results to pinned host memory, one copy: [ErrFlags slot (256 B)][bit sums]

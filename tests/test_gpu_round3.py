@@ -504,3 +504,26 @@ def test_small_multiexp_single_launch_path(worker, n):
     assert rc == 0 and np.array_equal(bellman_amd.multiexp(worker, hb2, bellman_amd.FullDensity(), s0).wait(), want)
     for h in (hb, hb2, short):
         h.release()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_reductions_with_equal_and_opposite_partial_sums(worker, group):
+    """every base the SAME point and small scalars k, 2^c - k: different buckets then hold equal points (P, P, ...) and
+    opposite points (P, -P), so the row / column / bit sums of the reduction add equal points (the doubling case - on lane
+    pairs the one-lane fallback) and opposite points (-> identity) at every tree level.  Window-table and classic plans."""
+    import bellman_amd
+    from bellman_amd.multiexp import NO_TABLE, NO_SMALL_PATH
+
+    gen = cref.g1_generator() if group == 1 else cref.g2_generator()
+    pt = cref.point_mul(group, gen, 0xC0FFEE)
+    for n, c in ((200, 13), (1500, 13), (40000, 16)):
+        bases = np.repeat(pt[None, :], n, axis=0)
+        ks = list(range(1, n // 2 + 1)) + [(1 << c) - k for k in range(1, n - n // 2 + 1)]
+        sc = cref.ints_to_arr(ks, 4)
+        rc, want = cref.multiexp(group, bases, 0, None, sc)
+        assert rc == 0
+        hb = bellman_amd.Bases(worker, group, bases)
+        for flags in (0, NO_SMALL_PATH, NO_TABLE | NO_SMALL_PATH):
+            got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=flags).wait()
+            assert np.array_equal(got, want), (n, flags)
+        hb.release()
