@@ -2,7 +2,7 @@
 # Round-3 final GPU run: the whole -m gpu suite, smoke, bench.py (default flags), and the rocprofv3 evidence that
 # DESIGN.md / bench.py cite (kernel stats of the timed-steps-only bench command, PMC passes of the dominant kernel)
 cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3final2
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
@@ -27,6 +27,6 @@ for i in 1 2 3; do python tools/profile_suite.py proof 20 7 12 2>&1 | grep creat
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o p -- python tools/profile_suite.py proof 20 3 1 > $OUT/trace.log 2>&1
 f=$(ls $OUT/trace/*kernel_trace.csv | head -1); (head -1 $f; tail -3000 $f) > $OUT/proof_trace.csv; rm -rf $OUT/trace
 # BASELINE configs[4], proof leg: the 2^24-constraint proof against the C restatement of the prover on all host cores
-timeout 1500 python tools/check_proof_large.py 24 > $OUT/proof_2p24_oracle.txt 2>&1; tail -3 $OUT/proof_2p24_oracle.txt
+# (the 2^24 full-oracle comparison ran once in the first final run: profiles/r3_proof_2p24.txt; the 2^24 parity tests of the suite above cover this commit)
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
