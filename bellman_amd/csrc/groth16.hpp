@@ -30,20 +30,104 @@
 namespace bellman {
 
 // ---- scalar field element (bls12_381::Scalar): 4x64 Montgomery limbs, little-endian -------------
+// The arithmetic a circuit and the linear-combination evaluation use per constraint (+, -, *, comparisons) is defined
+// INLINE here: as calls into the library they were a third of the synthesis time of a 2^20-constraint circuit
+// (profiles/r3_host_synthesis.txt).
+namespace fr_detail {
+typedef unsigned __int128 u128;
+constexpr uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+constexpr uint64_t INV = 0xfffffffeffffffffULL;
+constexpr uint64_t R[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
+constexpr uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+inline bool geq_mod(const uint64_t *a) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] > MOD[i]) return true;
+    if (a[i] < MOD[i]) return false;
+  }
+  return true;
+}
+inline void sub_mod(uint64_t *a) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - MOD[i] - (uint64_t)br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+// 4x64 CIOS Montgomery product, fully unrolled (synthesis is the serial part of create_proof)
+__attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define BH_FR_ROW(bi)                                                                     \
+  {                                                                                       \
+    u128 c = (u128)a[0] * (bi) + t0; t0 = (uint64_t)c; c >>= 64;                          \
+    c += (u128)a[1] * (bi) + t1; t1 = (uint64_t)c; c >>= 64;                              \
+    c += (u128)a[2] * (bi) + t2; t2 = (uint64_t)c; c >>= 64;                              \
+    c += (u128)a[3] * (bi) + t3; t3 = (uint64_t)c; c >>= 64;                              \
+    c += t4; t4 = (uint64_t)c; const uint64_t t5 = (uint64_t)(c >> 64);                   \
+    const uint64_t m = t0 * INV;                                                          \
+    c = ((u128)m * MOD[0] + t0) >> 64;                                                    \
+    c += (u128)m * MOD[1] + t1; t0 = (uint64_t)c; c >>= 64;                               \
+    c += (u128)m * MOD[2] + t2; t1 = (uint64_t)c; c >>= 64;                               \
+    c += (u128)m * MOD[3] + t3; t2 = (uint64_t)c; c >>= 64;                               \
+    c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                             \
+  }
+  BH_FR_ROW(b[0]) BH_FR_ROW(b[1]) BH_FR_ROW(b[2]) BH_FR_ROW(b[3])
+#undef BH_FR_ROW
+  uint64_t t[4] = {t0, t1, t2, t3};
+  if (t4 || geq_mod(t)) sub_mod(t);
+  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+}
+}  // namespace fr_detail
+
 struct Fr {
   uint64_t l[4];
-  static Fr zero();
-  static Fr one();
-  static Fr from_u64(uint64_t v);
+  static Fr zero() { return Fr{{0, 0, 0, 0}}; }
+  static Fr one() { return Fr{{fr_detail::R[0], fr_detail::R[1], fr_detail::R[2], fr_detail::R[3]}}; }
+  static Fr from_u64(uint64_t v) {
+    const uint64_t c[4] = {v, 0, 0, 0};
+    Fr r;
+    fr_detail::mont_mul(r.l, c, fr_detail::R2);
+    return r;
+  }
   static Fr from_u512(const uint64_t limbs_le[8]);   // wide reduction, as ff's Field::random does
   bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
-  bool operator==(const Fr &o) const { return memcmp(l, o.l, sizeof l) == 0; }
+  bool operator==(const Fr &o) const { return ((l[0] ^ o.l[0]) | (l[1] ^ o.l[1]) | (l[2] ^ o.l[2]) | (l[3] ^ o.l[3])) == 0; }
   bool operator!=(const Fr &o) const { return !(*this == o); }
-  Fr operator+(const Fr &o) const;
-  Fr operator-(const Fr &o) const;
-  Fr operator*(const Fr &o) const;
-  Fr neg() const;
-  void to_canonical(uint64_t out[4]) const;   // the bits of Exponent::Bits (multiexp.rs:179)
+  Fr operator+(const Fr &o) const {
+    Fr r;
+    fr_detail::u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (fr_detail::u128)l[i] + o.l[i];
+      r.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (fr_detail::geq_mod(r.l)) fr_detail::sub_mod(r.l);
+    return r;
+  }
+  Fr operator-(const Fr &o) const {
+    Fr r;
+    fr_detail::u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+      fr_detail::u128 d = (fr_detail::u128)l[i] - o.l[i] - (uint64_t)br;
+      r.l[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+    if (br) {
+      fr_detail::u128 c = 0;
+      for (int i = 0; i < 4; i++) {
+        c += (fr_detail::u128)r.l[i] + fr_detail::MOD[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    return r;
+  }
+  Fr operator*(const Fr &o) const { Fr r; fr_detail::mont_mul(r.l, l, o.l); return r; }
+  Fr neg() const { return Fr::zero() - *this; }
+  void to_canonical(uint64_t out[4]) const {   // the bits of Exponent::Bits (multiexp.rs:179)
+    const uint64_t one_[4] = {1, 0, 0, 0};
+    fr_detail::mont_mul(out, l, one_);
+  }
   Fr pow_vartime(uint64_t e) const;
   Fr invert() const;                          // *this must not be zero
 };
@@ -77,13 +161,15 @@ class LinearCombination {
   static LinearCombination zero() { return LinearCombination(); }
   LinearCombination() : n_(0) {}
   LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one()); return r; }
-  LinearCombination operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
+  LinearCombination &&operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
   LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
-  LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
+  LinearCombination &&operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
   LinearCombination operator+(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
-  LinearCombination operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
+  LinearCombination &&operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
   LinearCombination operator-(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
-  LinearCombination operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  LinearCombination &&operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  // (a temporary is extended in place and handed on BY REFERENCE: the chain `lc + a + b + c` builds one object instead of
+  //  move-constructing a 220-byte object per `+`)
   size_t size() const { return n_; }
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
 
@@ -148,6 +234,7 @@ class DensityTracker {
     const uint64_t bit = uint64_t(1) << (idx & 63);
     if (!(w & bit)) { w |= bit; total_++; }
   }
+  void clear() { words_.clear(); len_ = 0; total_ = 0; }   // keeps the capacity (recycled assignments)
   size_t get_total_density() const { return total_; }
   size_t get_query_size() const { return len_; }
   const uint64_t *words() const { return words_.data(); }
@@ -308,7 +395,7 @@ struct AsyncProof {
   std::exception_ptr error;
   std::unique_ptr<WitnessAssignment> witness;     // device-evaluated constraints (r1cs != null)
   std::unique_ptr<ProvingAssignment> assignment;  // host-evaluated constraints, as in the reference
-  ~AsyncProof() { if (worker.joinable()) worker.join(); }
+  ~AsyncProof();   // joins the helper thread; the assignment buffers go back to the recycling pool
   Proof wait(ProveTimings *tm = nullptr);          // joins; rethrows what the device part threw
 };
 // synthesises `circuit` on the calling thread (into a WitnessAssignment when `r1cs` is given, else into a

@@ -235,8 +235,23 @@ double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mo
   Fr wit[2] = {Fr::from_u64(123456789), Fr::from_u64(987654321)};
   double ms = -1.0;
   with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &c) -> int {
+    // modes 2 / 3: the same into a RECYCLED assignment (cleared, capacity kept), as create_proof does from the second
+    // proof on
+    static ProvingAssignment kept_pa;
+    static WitnessAssignment kept_w;
+    if (mode == 2) {
+      kept_pa.a.clear(); kept_pa.b.clear(); kept_pa.c.clear(); kept_pa.input_assignment.clear(); kept_pa.aux_assignment.clear();
+      kept_pa.a_aux_density.clear(); kept_pa.b_input_density.clear(); kept_pa.b_aux_density.clear();
+    }
+    if (mode == 3) { kept_w.input_assignment.clear(); kept_w.aux_assignment.clear(); }
     const auto t0 = std::chrono::steady_clock::now();
-    if (mode == 0) {
+    if (mode == 2) {
+      kept_pa.alloc_input([] { return Fr::one(); });
+      c.synthesize(kept_pa);
+    } else if (mode == 3) {
+      kept_w.alloc_input([] { return Fr::one(); });
+      c.synthesize(kept_w);
+    } else if (mode == 0) {
       ProvingAssignment pa;
       pa.alloc_input([] { return Fr::one(); });
       c.synthesize(pa);

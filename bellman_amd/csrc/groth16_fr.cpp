@@ -6,95 +6,10 @@
 
 namespace bellman {
 namespace {
-typedef unsigned __int128 u128;
-const uint64_t FR_MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
-const uint64_t FR_INV = 0xfffffffeffffffffULL;
-const uint64_t FR_R[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
-const uint64_t FR_R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
-
-inline bool geq_mod(const uint64_t *a) {
-  for (int i = 3; i >= 0; i--) {
-    if (a[i] > FR_MOD[i]) return true;
-    if (a[i] < FR_MOD[i]) return false;
-  }
-  return true;
-}
-inline void sub_mod(uint64_t *a) {
-  u128 br = 0;
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)a[i] - FR_MOD[i] - (uint64_t)br;
-    a[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-}
-// 4x64 CIOS Montgomery product, fully unrolled (synthesis is the serial part of create_proof)
-__attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
-  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-#define BH_ROW(bi)                                                                        \
-  {                                                                                       \
-    u128 c = (u128)a[0] * (bi) + t0; t0 = (uint64_t)c; c >>= 64;                          \
-    c += (u128)a[1] * (bi) + t1; t1 = (uint64_t)c; c >>= 64;                              \
-    c += (u128)a[2] * (bi) + t2; t2 = (uint64_t)c; c >>= 64;                              \
-    c += (u128)a[3] * (bi) + t3; t3 = (uint64_t)c; c >>= 64;                              \
-    c += t4; t4 = (uint64_t)c; const uint64_t t5 = (uint64_t)(c >> 64);                   \
-    const uint64_t m = t0 * FR_INV;                                                       \
-    c = ((u128)m * FR_MOD[0] + t0) >> 64;                                                 \
-    c += (u128)m * FR_MOD[1] + t1; t0 = (uint64_t)c; c >>= 64;                            \
-    c += (u128)m * FR_MOD[2] + t2; t1 = (uint64_t)c; c >>= 64;                            \
-    c += (u128)m * FR_MOD[3] + t3; t2 = (uint64_t)c; c >>= 64;                            \
-    c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                             \
-  }
-  BH_ROW(b[0]) BH_ROW(b[1]) BH_ROW(b[2]) BH_ROW(b[3])
-#undef BH_ROW
-  uint64_t t[4] = {t0, t1, t2, t3};
-  if (t4 || geq_mod(t)) sub_mod(t);
-  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
-}
+const uint64_t *const FR_R2 = fr_detail::R2;
+const uint64_t *const FR_MOD = fr_detail::MOD;
 }  // namespace
 
-Fr Fr::zero() { Fr r; memset(r.l, 0, sizeof r.l); return r; }
-Fr Fr::one() { Fr r; memcpy(r.l, FR_R, sizeof FR_R); return r; }
-Fr Fr::from_u64(uint64_t v) {
-  uint64_t c[4] = {v, 0, 0, 0};
-  Fr r;
-  mont_mul(r.l, c, FR_R2);
-  return r;
-}
-Fr Fr::operator+(const Fr &o) const {
-  Fr r;
-  u128 c = 0;
-  for (int i = 0; i < 4; i++) {
-    c += (u128)l[i] + o.l[i];
-    r.l[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  if (geq_mod(r.l)) sub_mod(r.l);
-  return r;
-}
-Fr Fr::operator-(const Fr &o) const {
-  Fr r;
-  u128 br = 0;
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)l[i] - o.l[i] - (uint64_t)br;
-    r.l[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-  if (br) {
-    u128 c = 0;
-    for (int i = 0; i < 4; i++) {
-      c += (u128)r.l[i] + FR_MOD[i];
-      r.l[i] = (uint64_t)c;
-      c >>= 64;
-    }
-  }
-  return r;
-}
-Fr Fr::operator*(const Fr &o) const { Fr r; mont_mul(r.l, l, o.l); return r; }
-Fr Fr::neg() const { return Fr::zero() - *this; }
-void Fr::to_canonical(uint64_t out[4]) const {
-  const uint64_t one[4] = {1, 0, 0, 0};
-  mont_mul(out, l, one);
-}
 // little-endian 512-bit integer -> Fr (ff's wide reduction behind Field::random): lo + hi * 2^256 mod q
 Fr Fr::from_u512(const uint64_t limbs[8]) {
   Fr lo, hi, r2;

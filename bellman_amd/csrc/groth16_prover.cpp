@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -18,27 +19,81 @@ using namespace bellman;
 using namespace detail;
 
 // ---- prover.rs:19-55 ------------------------------------------------------------------------------
-static Fr eval(const LinearCombination &lc, DensityTracker *input_density, DensityTracker *aux_density,
-               const std::vector<Fr> &input_assignment, const std::vector<Fr> &aux_assignment) {
+static inline Fr eval(const LinearCombination &lc, DensityTracker *input_density, DensityTracker *aux_density,
+                      const std::vector<Fr> &input_assignment, const std::vector<Fr> &aux_assignment) {
   Fr acc = Fr::zero();
   const Fr one = Fr::one();
-  for (size_t t = 0; t < lc.size(); t++) {
+  const size_t n = lc.size();
+  for (size_t t = 0; t < n; t++) {
     const Variable &var = lc[t].first;
     const Fr &coeff = lc[t].second;
     if (coeff.is_zero()) continue;          // zero coefficients count for neither value nor density (:31)
-    Fr tmp;
+    const Fr *value;
     if (var.kind == Index::Input) {
-      tmp = input_assignment[var.idx];
+      value = &input_assignment[var.idx];
       if (input_density) input_density->inc(var.idx);
     } else {
-      tmp = aux_assignment[var.idx];
+      value = &aux_assignment[var.idx];
       if (aux_density) aux_density->inc(var.idx);
     }
-    if (tmp == one) tmp = coeff;            // 1 * coeff (the ubiquitous `(c, CS::one())` terms)
-    else if (coeff != one) tmp = tmp * coeff;
-    acc = acc + tmp;
+    // most terms carry the coefficient one (`lc + x`), then the ubiquitous `(c, CS::one())` terms: value one
+    if (coeff == one) acc = acc + *value;
+    else if (*value == one) acc = acc + coeff;
+    else acc = acc + *value * coeff;
   }
   return acc;
+}
+
+// ---- recycled assignments ----------------------------------------------------------------------------------------
+// A 2^20-constraint ProvingAssignment is five vectors of 32 MiB.  Grown by push_back from empty and freed after every
+// proof they cost reallocation copies and ~40 000 first-touch page faults per proof - a third of the synthesis time
+// (profiles/r3_host_synthesis.txt).  Finished assignments are cleared (capacity kept) and handed to the next proof.
+namespace {
+template <class T>
+class Recycler {
+ public:
+  std::unique_ptr<T> get() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (!free_.empty()) {
+        std::unique_ptr<T> p = std::move(free_.back());
+        free_.pop_back();
+        return p;
+      }
+    }
+    return std::unique_ptr<T>(new T());
+  }
+  void put(std::unique_ptr<T> p) {
+    if (!p) return;
+    reset(*p);
+    std::lock_guard<std::mutex> g(mu_);
+    if (free_.size() < 16) free_.push_back(std::move(p));   // at most 16 idle assignments are kept
+  }
+
+ private:
+  static void reset(ProvingAssignment &a) {
+    a.a.clear(); a.b.clear(); a.c.clear(); a.input_assignment.clear(); a.aux_assignment.clear();
+    a.a_aux_density.clear(); a.b_input_density.clear(); a.b_aux_density.clear();
+  }
+  static void reset(WitnessAssignment &w) { w.input_assignment.clear(); w.aux_assignment.clear(); }
+  std::mutex mu_;
+  std::vector<std::unique_ptr<T>> free_;
+};
+Recycler<ProvingAssignment> g_assignments;
+Recycler<WitnessAssignment> g_witnesses;
+template <class T>
+struct Recycled {   // returns the object to its pool on scope exit, exceptions included
+  Recycler<T> &pool;
+  std::unique_ptr<T> p;
+  explicit Recycled(Recycler<T> &r) : pool(r), p(r.get()) {}
+  ~Recycled() { pool.put(std::move(p)); }
+  T &operator*() { return *p; }
+};
+}  // namespace
+AsyncProof::~AsyncProof() {
+  if (worker.joinable()) worker.join();
+  g_assignments.put(std::move(assignment));
+  g_witnesses.put(std::move(witness));
 }
 
 // ---- prover.rs:73-162 -----------------------------------------------------------------------------
@@ -570,7 +625,8 @@ Variable WitnessAssignment::alloc_input(ValueFn f) {
 
 Proof create_proof(Circuit &circuit, const R1cs &r1cs, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   const double t0 = now_ms();
-  WitnessAssignment w;
+  Recycled<WitnessAssignment> wr(g_witnesses);
+  WitnessAssignment &w = *wr;
   w.input_assignment.reserve(r1cs.num_inputs);
   w.aux_assignment.reserve(r1cs.num_aux);
   w.alloc_input([] { return Fr::one(); });
@@ -598,14 +654,14 @@ std::unique_ptr<AsyncProof> create_proof_async(Circuit &circuit, const R1cs *r1c
   std::unique_ptr<AsyncProof> job(new AsyncProof());
   const double t0 = now_ms();
   if (r1cs) {
-    job->witness.reset(new WitnessAssignment());
+    job->witness = g_witnesses.get();
     WitnessAssignment &w = *job->witness;
     w.input_assignment.reserve(r1cs->num_inputs);
     w.aux_assignment.reserve(r1cs->num_aux);
     w.alloc_input([] { return Fr::one(); });
     circuit.synthesize(w);
   } else {
-    job->assignment.reset(new ProvingAssignment());
+    job->assignment = g_assignments.get();
     ProvingAssignment &pa = *job->assignment;
     pa.alloc_input([] { return Fr::one(); });
     circuit.synthesize(pa);
@@ -663,7 +719,8 @@ Proof ProofPipeline::next(ProveTimings *tm) {
 // ---- prover.rs:182-215 ----------------------------------------------------------------------------
 Proof create_proof(Circuit &circuit, Parameters &params, const Fr &r, const Fr &s, ProveTimings *tm) {
   const double t0 = now_ms();
-  ProvingAssignment prover;
+  Recycled<ProvingAssignment> pr(g_assignments);
+  ProvingAssignment &prover = *pr;
   prover.alloc_input([] { return Fr::one(); });
   circuit.synthesize(prover);
   for (size_t i = 0; i < prover.input_assignment.size(); i++) {

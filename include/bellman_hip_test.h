@@ -38,7 +38,8 @@ void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t
  * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */
 int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
 /* host-only: milliseconds to synthesise a demo circuit (kind/size/seed as bh_groth16_prove_demo) into a
- * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); no device involved */
+ * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); modes 2 / 3: the same into a recycled (cleared, capacity
+ * kept) assignment, as create_proof does from the second proof on; no device involved */
 double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
 /* host only: the ProvingAssignment create_proof synthesises for a demo circuit (arguments as bh_groth16_prove_demo; input
  * constraints of prover.rs:208-215 appended).  counts3 = [n_constraints, n_inputs, n_aux]; with a == NULL only the counts
