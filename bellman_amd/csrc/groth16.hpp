@@ -152,14 +152,70 @@ struct Variable {
   static Variable new_unchecked(Index k, size_t i) { return Variable{k, i}; }
 };
 
+// ---- src/multiexp.rs:117-157 --------------------------------------------------------------------
+class DensityTracker {
+ public:
+  void add_element() {
+    if ((len_ & 63) == 0) words_.push_back(0);
+    len_++;
+  }
+  void inc(size_t idx) {
+    uint64_t &w = words_[idx >> 6];
+    const uint64_t bit = uint64_t(1) << (idx & 63);
+    if (!(w & bit)) { w |= bit; total_++; }
+  }
+  void clear() { words_.clear(); len_ = 0; total_ = 0; }   // keeps the capacity (recycled assignments)
+  size_t get_total_density() const { return total_; }
+  size_t get_query_size() const { return len_; }
+  const uint64_t *words() const { return words_.data(); }
+
+ private:
+  std::vector<uint64_t> words_;   // LSB0, like BitVec<usize, Lsb0>
+  size_t len_ = 0, total_ = 0;
+};
+
+
 // ---- src/lib.rs:190-300: ordered (variable, coeff) list, duplicates are NOT merged ---------------
 // Terms live inline for the common short combinations (no heap traffic during synthesis, which is
 // the serial part of create_proof); longer ones spill to a vector.
+//
+// EVALUATING combinations.  create_proof's ConstraintSystem (ProvingAssignment, prover.rs:105-145) never looks at the
+// terms of a constraint's combinations again: it evaluates them and updates the query densities (prover.rs:19-55).  It
+// therefore hands the closures a combination that is bound to an LcSink and does exactly that as each term is added -
+// nothing is stored, the object that travels through `|lc| lc + a + b` is 56 bytes instead of 230, and there is no
+// second pass.  Same values, same densities, same term order (profiles/r3_host_synthesis.txt).
+struct LcSink {
+  const Fr *inputs, *aux;                         // input_assignment / aux_assignment
+  DensityTracker *input_density, *aux_density;    // either may be null (prover.rs:119-141)
+};
 class LinearCombination {
  public:
-  typedef std::pair<Variable, Fr> Term;
+  struct Term { Variable first; Fr second; };     // (variable, coefficient); an aggregate, so copies are plain memcpy
   static LinearCombination zero() { return LinearCombination(); }
-  LinearCombination() : n_(0) {}
+  static LinearCombination evaluating(const LcSink *sink) {
+    LinearCombination r;
+    r.sink_ = sink;
+    r.acc_ = Fr::zero();
+    return r;
+  }
+  LinearCombination() : n_(0), sink_(nullptr) {}
+  LinearCombination(const LinearCombination &o) : n_(o.n_), sink_(o.sink_) {
+    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+  }
+  LinearCombination(LinearCombination &&o) noexcept : n_(o.n_), sink_(o.sink_) {
+    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+  }
+  LinearCombination &operator=(const LinearCombination &o) {
+    n_ = o.n_; sink_ = o.sink_;
+    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+    return *this;
+  }
+  LinearCombination &operator=(LinearCombination &&o) noexcept {
+    n_ = o.n_; sink_ = o.sink_;
+    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+    return *this;
+  }
+  // lvalue operands are copied (value semantics); a temporary is extended in place and handed on by reference
   LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one()); return r; }
   LinearCombination &&operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
   LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
@@ -168,20 +224,40 @@ class LinearCombination {
   LinearCombination &&operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
   LinearCombination operator-(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
   LinearCombination &&operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
-  // (a temporary is extended in place and handed on BY REFERENCE: the chain `lc + a + b + c` builds one object instead of
-  //  move-constructing a 220-byte object per `+`)
   size_t size() const { return n_; }
+  // stored combinations only
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
+  bool is_evaluating() const { return sink_ != nullptr; }
+  const Fr &value() const { return acc_; }   // evaluating combinations only
 
  private:
   static constexpr size_t INLINE = 4;
   void push(Variable v, const Fr &c) {
-    if (n_ < INLINE) inl_[n_] = Term(v, c); else more_.push_back(Term(v, c));
     n_++;
+    if (sink_) {   // prover.rs:19-55 for this one term
+      if (c.is_zero()) return;            // zero coefficients count for neither value nor density (:31)
+      const Fr *value;
+      if (v.kind == Index::Input) {
+        value = sink_->inputs + v.idx;
+        if (sink_->input_density) sink_->input_density->inc(v.idx);
+      } else {
+        value = sink_->aux + v.idx;
+        if (sink_->aux_density) sink_->aux_density->inc(v.idx);
+      }
+      const Fr one = Fr::one();
+      // most terms carry the coefficient one (`lc + x`), then the ubiquitous `(c, CS::one())` terms: value one
+      if (c == one) acc_ = acc_ + *value;
+      else if (*value == one) acc_ = acc_ + c;
+      else acc_ = acc_ + *value * c;
+      return;
+    }
+    if (n_ <= INLINE) inl_[n_ - 1] = Term{v, c}; else more_.push_back(Term{v, c});
   }
   Term inl_[INLINE];
   std::vector<Term> more_;
   size_t n_;
+  const LcSink *sink_;
+  Fr acc_;
 };
 
 // Non-owning callable reference (two pointers, never allocates): the C++ stand-in for the
@@ -220,28 +296,6 @@ class Circuit {
  public:
   virtual ~Circuit() {}
   virtual void synthesize(ConstraintSystem &cs) = 0;
-};
-
-// ---- src/multiexp.rs:117-157 --------------------------------------------------------------------
-class DensityTracker {
- public:
-  void add_element() {
-    if ((len_ & 63) == 0) words_.push_back(0);
-    len_++;
-  }
-  void inc(size_t idx) {
-    uint64_t &w = words_[idx >> 6];
-    const uint64_t bit = uint64_t(1) << (idx & 63);
-    if (!(w & bit)) { w |= bit; total_++; }
-  }
-  void clear() { words_.clear(); len_ = 0; total_ = 0; }   // keeps the capacity (recycled assignments)
-  size_t get_total_density() const { return total_; }
-  size_t get_query_size() const { return len_; }
-  const uint64_t *words() const { return words_.data(); }
-
- private:
-  std::vector<uint64_t> words_;   // LSB0, like BitVec<usize, Lsb0>
-  size_t len_ = 0, total_ = 0;
 };
 
 }  // namespace bellman

@@ -109,12 +109,18 @@ Variable ProvingAssignment::alloc_input(ValueFn f) {
   return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
 }
 void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
-  const LinearCombination la = fa(LinearCombination::zero()), lb = fb(LinearCombination::zero()),
-                          lc = fc(LinearCombination::zero());
-  // inputs have full density in the A query; there is no C query (prover.rs:119-141)
-  a.push_back(eval(la, nullptr, &a_aux_density, input_assignment, aux_assignment));
-  b.push_back(eval(lb, &b_input_density, &b_aux_density, input_assignment, aux_assignment));
-  c.push_back(eval(lc, nullptr, nullptr, input_assignment, aux_assignment));
+  // inputs have full density in the A query; there is no C query (prover.rs:119-141).  The closures get combinations
+  // that evaluate each term as it is added (groth16.hpp); a closure that returns some other, stored combination is
+  // evaluated the classic way.
+  const Fr *in = input_assignment.data(), *ax = aux_assignment.data();
+  const LcSink sa{in, ax, nullptr, &a_aux_density}, sb{in, ax, &b_input_density, &b_aux_density}, sc{in, ax, nullptr, nullptr};
+  auto run = [&](LcFn &f, const LcSink &sink) -> Fr {
+    const LinearCombination r = f(LinearCombination::evaluating(&sink));
+    return r.is_evaluating() ? r.value() : eval(r, sink.input_density, sink.aux_density, input_assignment, aux_assignment);
+  };
+  a.push_back(run(fa, sa));
+  b.push_back(run(fb, sb));
+  c.push_back(run(fc, sc));
 }
 
 namespace {
