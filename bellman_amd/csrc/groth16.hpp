@@ -187,6 +187,10 @@ class DensityTracker {
 struct LcSink {
   const Fr *inputs, *aux;                         // input_assignment / aux_assignment
   DensityTracker *input_density, *aux_density;    // either may be null (prover.rs:119-141)
+  // set instead of the four fields above: every term is handed to `hook` as it is added (a ConstraintSystem that
+  // records the structure of the circuit - the R1CS capture - takes the terms straight into its matrices)
+  void (*hook)(void *self, Variable v, const Fr &coeff) = nullptr;
+  void *self = nullptr;
 };
 class LinearCombination {
  public:
@@ -236,6 +240,7 @@ class LinearCombination {
     n_++;
     if (sink_) {   // prover.rs:19-55 for this one term
       if (c.is_zero()) return;            // zero coefficients count for neither value nor density (:31)
+      if (sink_->hook) { sink_->hook(sink_->self, v, c); return; }
       const Fr *value;
       if (v.kind == Index::Input) {
         value = sink_->inputs + v.idx;

@@ -562,6 +562,7 @@ class ShapeAssembly : public ConstraintSystem {
   std::vector<Term> terms[3];
   std::vector<Fr> coeffs;
   std::unordered_map<Fr, uint32_t, FrHash> coeff_index;
+  const Fr one_ = Fr::one();
   ShapeAssembly() {
     coeffs.push_back(Fr::one());
     coeff_index.emplace(Fr::one(), 0);
@@ -569,25 +570,38 @@ class ShapeAssembly : public ConstraintSystem {
   }
   Variable alloc(ValueFn) override { return Variable::new_unchecked(Index::Aux, num_aux++); }
   Variable alloc_input(ValueFn) override { return Variable::new_unchecked(Index::Input, num_inputs++); }
+  void add_term(int m, const Variable &v, const Fr &k) {
+    if (k.is_zero()) return;     // prover.rs:31: no value, no density
+    if (k == one_) {             // the usual `lc + x` term: coefficient table entry 0, no hash lookup
+      terms[m].push_back(Term{v.kind, (uint32_t)v.idx, 0});
+      return;
+    }
+    auto it = coeff_index.find(k);
+    uint32_t ci;
+    if (it == coeff_index.end()) {
+      ci = (uint32_t)coeffs.size();
+      coeffs.push_back(k);
+      coeff_index.emplace(k, ci);
+    } else {
+      ci = it->second;
+    }
+    terms[m].push_back(Term{v.kind, (uint32_t)v.idx, ci});
+  }
+  struct Hooked { ShapeAssembly *cs; int m; };
+  static void hook(void *self, Variable v, const Fr &k) {
+    Hooked *h = static_cast<Hooked *>(self);
+    h->cs->add_term(h->m, v, k);
+  }
   void enforce(LcFn fa, LcFn fb, LcFn fc) override {
-    const LinearCombination lcs[3] = {fa(LinearCombination::zero()), fb(LinearCombination::zero()),
-                                      fc(LinearCombination::zero())};
+    // the closures get combinations whose terms go straight into the matrices (LcSink::hook); a closure that returns
+    // some other, stored combination is walked the classic way
+    LcFn *fs[3] = {&fa, &fb, &fc};
     for (int m = 0; m < 3; m++) {
-      for (size_t i = 0; i < lcs[m].size(); i++) {
-        const Variable &v = lcs[m][i].first;
-        const Fr &k = lcs[m][i].second;
-        if (k.is_zero()) continue;   // prover.rs:31: no value, no density
-        auto it = coeff_index.find(k);
-        uint32_t ci;
-        if (it == coeff_index.end()) {
-          ci = (uint32_t)coeffs.size();
-          coeffs.push_back(k);
-          coeff_index.emplace(k, ci);
-        } else {
-          ci = it->second;
-        }
-        terms[m].push_back(Term{v.kind, (uint32_t)v.idx, ci});
-      }
+      Hooked h{this, m};
+      LcSink sink{nullptr, nullptr, nullptr, nullptr, &ShapeAssembly::hook, &h};
+      const LinearCombination r = (*fs[m])(LinearCombination::evaluating(&sink));
+      if (!r.is_evaluating())
+        for (size_t i = 0; i < r.size(); i++) add_term(m, r[i].first, r[i].second);
       row_ptr[m].push_back((uint32_t)terms[m].size());
     }
   }
