@@ -59,3 +59,25 @@ def test_patch_applies_to_the_reference_tree(tmp_path):
     r = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=dst, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "src/hip.rs" in r.stdout and "src/multiexp.rs" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference tree not present (GPU box)")
+def test_patched_rust_files_are_balanced(tmp_path):
+    """No Rust toolchain here: at least the patched files must keep their brackets balanced outside strings and
+    comments (a truncated hunk or a lost brace is the kind of damage a hand-maintained patch suffers)."""
+    dst = tmp_path / "ref"
+    shutil.copytree("/root/reference", dst, ignore=shutil.ignore_patterns(".git", "target"))
+    patch = os.path.join(ROOT, "shim", "patches", "bellman-hip.patch")
+    r = subprocess.run(["patch", "-p1", "-s", "-i", patch], cwd=dst, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    files = [dst / "src" / f for f in ("hip.rs", "multiexp.rs", "domain.rs", "multicore.rs", "lib.rs")] + \
+            [dst / "groth16" / "src" / "prover.rs"] + \
+            [os.path.join(ROOT, "shim", "bellman-hip", "src", f) for f in ("lib.rs", "ffi.rs", "layout.rs")]
+    for f in files:
+        text = open(f).read()
+        text = re.sub(r"//[^\n]*", "", text)                       # line comments
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)           # block comments
+        text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)             # string literals
+        text = re.sub(r"'(?:\\.|[^'\\])'", "''", text)              # char literals (lifetimes stay, they carry no brackets)
+        for o, c in ("{}", "()", "[]"):
+            assert text.count(o) == text.count(c), (str(f), o, text.count(o), text.count(c))
