@@ -304,3 +304,54 @@ def test_proof_slices_partition_the_scalar_range_host():
                 assert hi.value % 64 == 0 or hi.value == n
                 prev = hi.value
             assert prev == n
+
+
+def test_montgomery_reduction_whole_columns_with_maximal_limbs(lib):
+    """ff.cuh adds the product column c[k] WHOLE wherever Radix30::NOSPLIT proves that the column sum stays below 2^64
+    (all 18 columns of Fr, 21 of 26 of Fp).  Operands whose 30-bit limbs are all ones drive every column to the
+    bound the compile-time proof uses; results against big-integer arithmetic (multiexp.rs / domain.rs rely on exact
+    field products everywhere)."""
+    p, q = bls.P, bls.Q
+    R = 1 << 384
+
+    def arr(v, n):
+        return np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(n)], dtype=np.uint64)
+
+    def val(a):
+        return sum(int(x) << (64 * i) for i, x in enumerate(a))
+
+    def lazy(op, a, b=None):
+        out = np.zeros(6, dtype=np.uint64)
+        xa, xb = arr(a, 6), (arr(b, 6) if b is not None else None)
+        lib.bh_test_fp_lazy_host(op, _p(out), _p(xa), _p(xb) if xb is not None else None)
+        return val(out)
+
+    ones = (1 << 384) - 1
+    rnd = random.Random(77)
+    big = [ones, ones >> 1, (1 << 383) - 1, (1 << 382) - 1, 2 * p - 1, 2 * p - 2, p - 1, p, p + 1,
+           int("3fffffff" * 13, 16) & ones, (1 << 381) | ((1 << 381) - 1)]
+    # the result of a Montgomery product is < a*b*2^6 / 2^390 + p: pairs whose result fits 384 bits
+    for a in big + [rnd.randrange(ones) for _ in range(20)]:
+        for b in big + [rnd.randrange(ones) for _ in range(5)]:
+            if a * b // R + p >= R:
+                continue
+            r = lazy(5, a, b)
+            assert (r * R - a * b) % p == 0 and r < a * b // R + p + 1, (hex(a), hex(b))
+        if a * a // R + p < R:
+            r = lazy(6, a)
+            assert (r * R - a * a) % p == 0 and r < a * a // R + p + 1, hex(a)
+    # Fr: any 256-bit words (the reduction is exact for every input; results below 2^256 are compared)
+    Rq = 1 << 256
+    ones_q = (1 << 256) - 1
+    avals = [ones_q, ones_q >> 1, q - 1, q, 2 * q - 1, int("3fffffff" * 9, 16) & ones_q] + [rnd.randrange(ones_q) for _ in range(30)]
+    bvals = [ones_q >> 2, q - 1, (1 << 254) - 1, int("3fffffff" * 9, 16) & (ones_q >> 2)] + [rnd.randrange(q) for _ in range(10)]
+    pairs = [(a, b) for a in avals for b in bvals if a * b // Rq + q < Rq]
+    A = np.stack([arr(a, 4) for a, _ in pairs])
+    B = np.stack([arr(b, 4) for _, b in pairs])
+    out = np.zeros_like(A)
+    lib.bh_test_fr_mul_host(_p(out), _p(A), _p(B), len(pairs))
+    out2 = np.zeros_like(A)
+    lib.bh_test_fr_mul_bform_host(_p(out2), _p(A), _p(B), len(pairs))
+    for (a, b), r, r2 in zip(pairs, out, out2):
+        want = a * b * pow(Rq, -1, q) % q
+        assert val(r) == want and val(r2) == want, (hex(a), hex(b))
