@@ -10,7 +10,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbellman_hip.so")
+# BELLMAN_HIP_LIB: another build of the SAME library (A/B runs of a kernel experiment against the shipped build,
+# tools/gpu_r4_fused_y3.sh); never a different implementation - there is no fallback of any kind
+LIB_PATH = os.environ.get("BELLMAN_HIP_LIB") or os.path.join(_HERE, "lib", "libbellman_hip.so")
 
 # every symbol include/bellman_hip.h declares, then the test hooks of include/bellman_hip_test.h
 EXPORTS = [

@@ -140,6 +140,11 @@ BH_HD void order_after(T &v) {
   (void)v;
 #endif
 }
+// which field bundles take the fused last line of the formula (see the end of xyzz_madd below)
+template <class F> struct fused_y3 { static constexpr bool value = false; };
+#ifdef BH_FUSED_Y3
+template <> struct fused_y3<FpOps> { static constexpr bool value = true; };
+#endif
 template <class F, class PF>
 BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   typedef typename F::T T;
@@ -176,13 +181,23 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   F::sub(t, t, ppp);
   F::sub(t, t, qq);
   F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
-  F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
-  F::sub(qq, qq, t);
-  acc.x = t;
-  order_after(ppp);
-  prefetch();
-  F::mul_tail(qq, r, qq);             // R*(Q - X3)            (r dead); inline, see above
-  F::sub(acc.y, qq, ppp);
+  if constexpr (fused_y3<F>::value) {
+    // EXPERIMENT (-DBH_FUSED_Y3, off by default, never run on the device): Y3 = R*(Q - X3) - Y1*PPP as two products
+    // under one reduction (ff.cuh fe_mul2: 169 mads, one out-of-line call and one subtraction fewer per addition)
+    F::sub(qq, qq, t);
+    acc.x = t;
+    order_after(qq);
+    prefetch();
+    F::mul2_sub_tail(acc.y, r, qq, acc.y, ppp);
+  } else {
+    F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
+    F::sub(qq, qq, t);
+    acc.x = t;
+    order_after(ppp);
+    prefetch();
+    F::mul_tail(qq, r, qq);             // R*(Q - X3)            (r dead); inline, see above
+    F::sub(acc.y, qq, ppp);
+  }
 }
 template <class F>
 BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
@@ -216,10 +231,15 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
   F::sub(t, t, ppp);
   F::sub(t, t, qq);
   F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
-  F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
-  F::sub(qq, qq, t);
-  F::mul(qq, r, qq);                  // R*(Q - X3)            (r dead)
-  F::sub(acc.y, qq, ppp);
+  if constexpr (fused_y3<F>::value) {   // EXPERIMENT, see the overload above
+    F::sub(qq, qq, t);
+    F::mul2_sub(acc.y, r, qq, acc.y, ppp);
+  } else {
+    F::mul(ppp, acc.y, ppp);            // Y1*PPP                (reuses ppp)
+    F::sub(qq, qq, t);
+    F::mul(qq, r, qq);                  // R*(Q - X3)            (r dead)
+    F::sub(acc.y, qq, ppp);
+  }
   acc.x = t;
 }
 

@@ -232,11 +232,11 @@ BH_HD u32 fe_limb30(const Fe<P> &x, int i) {
 }
 
 // column-wise Montgomery reduction of the 2L product columns c[] + repack + final subtraction
-template <class P, bool CANONICAL = true>
+template <class P, bool CANONICAL = true, u32 WHOLE = Radix30<P>::NOSPLIT>
 BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
   typedef Radix30<P> R;
   constexpr int N = P::N, L = R::L;
-  // Column k holds c[k] + carry + sum m[i]*mod[k-i].  Where that can pass 2^64 (the middle columns of Fp: R::NOSPLIT)
+  // Column k holds c[k] + carry + sum m[i]*mod[k-i].  Where that can pass 2^64 (the middle columns of Fp: WHOLE = R::NOSPLIT)
   // the high part of c[k] goes straight into the next carry (t < 2^30 + carry + L*2^60 with carry < 2^35); everywhere
   // else c[k] is added whole.  Both forms give the same t mod 2^30 and the same carry.
   static_assert(2 * L <= 32, "one bit of NOSPLIT per column");
@@ -244,7 +244,7 @@ BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
   u64 carry = 0;
 #pragma unroll
   for (int k = 0; k < L; k++) {
-    const bool whole = (R::NOSPLIT >> k) & 1;
+    const bool whole = (WHOLE >> k) & 1;
     u64 t = (whole ? c[k] : (c[k] & R::MASK)) + carry;
 #pragma unroll
     for (int i = 0; i < k; i++) t += (u64)m[i] * R::mod(k - i);
@@ -254,7 +254,7 @@ BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
-    const bool whole = (R::NOSPLIT >> k) & 1;
+    const bool whole = (WHOLE >> k) & 1;
     u64 t = (whole ? c[k] : (c[k] & R::MASK)) + carry;
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) t += (u64)m[i] * R::mod(k - i);
@@ -331,6 +331,105 @@ BH_HD void fe_mul_b(Fe<P> &r, const Fe<P> &a, const u32 *B) {
     for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
   }
   fe_mont_reduce30<P, CANONICAL>(r, c);
+}
+
+// r = (a*b + c*d) * 2^(-32N): two products under ONE reduction (L*L fewer mads than two separate products: 169 of
+// Fp's 676).  Both products accumulate into the same 2L columns; a column that could pass 2^64 under the second
+// product (or in the reduction afterwards) first sends its high part to its neighbour - Radix30Fused decides per column
+// at compile time, with every limb of all four operands at 2^30 - 1.  Result < (a*b + c*d) / 2^(32N) + m.
+// EXPERIMENT (BH_FUSED_Y3, ec.cuh): validated on the host against the separate products, never timed on the device.
+template <class P>
+struct Radix30Fused {
+  typedef Radix30<P> R;
+  static constexpr int L = R::L;
+  struct Plan { u32 relieve, whole; };
+  BH_HD static constexpr Plan plan() {
+    Plan pl{0, 0};
+    unsigned __int128 col[2 * L] = {};
+    const unsigned __int128 MM = (unsigned __int128)R::MASK * R::MASK;
+    for (int k = 0; k < 2 * L; k++) col[k] = (unsigned __int128)(k < L ? k + 1 : 2 * L - 1 - k) * MM;   // first product
+    for (int k = 0; k < 2 * L - 1; k++) {
+      const unsigned __int128 second = (unsigned __int128)(k < L ? k + 1 : 2 * L - 1 - k) * MM;
+      // relieve only where the two products could pass 2^64 (9 columns of Fp; the reduction then splits 9 - relieving
+      // earlier, from 2^63, costs 17 + 5)
+      if (((col[k] + second) >> 64) != 0) {
+        pl.relieve |= 1u << k;
+        col[k + 1] += col[k] >> 30;
+        col[k] = R::MASK;
+      }
+    }
+    for (int k = 0; k < 2 * L; k++) col[k] += (unsigned __int128)(k < L ? k + 1 : 2 * L - 1 - k) * MM;   // second product
+    unsigned __int128 carry = 0;
+    for (int k = 0; k < 2 * L; k++) {
+      unsigned __int128 t = col[k] + carry + R::MASK;
+      for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); i++) t += (unsigned __int128)R::MASK * R::mod(k - i);
+      if ((t >> 64) == 0) pl.whole |= 1u << k;
+      carry = (t >> 30) + 1;
+    }
+    return pl;
+  }
+  static constexpr Plan PLAN = plan();
+  // no column may overflow BEFORE the reduction either: every column after both products stays below 2^64
+  BH_HD static constexpr bool columns_fit() {
+    unsigned __int128 col[2 * L] = {};
+    const unsigned __int128 MM = (unsigned __int128)R::MASK * R::MASK;
+    for (int k = 0; k < 2 * L; k++) col[k] = (unsigned __int128)(k < L ? k + 1 : 2 * L - 1 - k) * MM;
+    for (int k = 0; k < 2 * L - 1; k++)
+      if ((PLAN.relieve >> k) & 1) {
+        if ((col[k + 1] + (col[k] >> 30)) >> 64) return false;
+        col[k + 1] += col[k] >> 30;
+        col[k] = R::MASK;
+      }
+    for (int k = 0; k < 2 * L; k++) {
+      col[k] += (unsigned __int128)(k < L ? k + 1 : 2 * L - 1 - k) * MM;
+      if (col[k] >> 64) return false;
+    }
+    return true;
+  }
+};
+template <class P, bool CANONICAL = true>
+BH_HD void fe_mul2(Fe<P> &r, const Fe<P> &a, const Fe<P> &b, const Fe<P> &c2, const Fe<P> &d) {
+  typedef Radix30<P> R;
+  typedef Radix30Fused<P> RF;
+  constexpr int L = R::L;
+  static_assert(RF::columns_fit(), "a product column overflows before the reduction");
+  u64 c[2 * L];
+#pragma unroll
+  for (int k = 0; k < 2 * L; k++) c[k] = 0;
+  {
+    u32 A[L], B[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      A[i] = fe_limb30<P, 0>(a, i);
+      B[i] = fe_limb30<P, R::SHIFT>(b, i);
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+      for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; k++) {
+    if ((RF::PLAN.relieve >> k) & 1) {
+      c[k + 1] += c[k] >> 30;
+      c[k] &= R::MASK;
+    }
+  }
+  {
+    u32 A[L], B[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      A[i] = fe_limb30<P, 0>(c2, i);
+      B[i] = fe_limb30<P, R::SHIFT>(d, i);
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+#pragma unroll
+      for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
+    }
+  }
+  fe_mont_reduce30<P, CANONICAL, RF::PLAN.whole>(r, c);
 }
 
 // Also evaluated and rejected on the MI355X: the interleaved product-scanning form (retire each column
@@ -530,6 +629,34 @@ BH_HD fp_t fp_mul_call(const fp_t &a, const fp_t &b) {
                     u32x4{b.l[4], b.l[5], b.l[6], b.l[7]}, u32x4{b.l[8], b.l[9], b.l[10], b.l[11]});
 }
 
+// a*b - c*d out of line (EXPERIMENT, BH_FUSED_Y3_CALL): 48 argument words, of which the calling convention passes 32 in
+// registers and 16 through scratch memory
+BH_NOINLINE_HD static fp_t fp_mul2_sub_vec(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2, u32x4 c0, u32x4 c1,
+                                           u32x4 c2, u32x4 d0, u32x4 d1, u32x4 d2) {
+  fp_t a, b, c, d, nc, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w; a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w;
+  b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w; b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w;
+  b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w;
+  c.l[0] = c0.x; c.l[1] = c0.y; c.l[2] = c0.z; c.l[3] = c0.w; c.l[4] = c1.x; c.l[5] = c1.y; c.l[6] = c1.z; c.l[7] = c1.w;
+  c.l[8] = c2.x; c.l[9] = c2.y; c.l[10] = c2.z; c.l[11] = c2.w;
+  d.l[0] = d0.x; d.l[1] = d0.y; d.l[2] = d0.z; d.l[3] = d0.w; d.l[4] = d1.x; d.l[5] = d1.y; d.l[6] = d1.z; d.l[7] = d1.w;
+  d.l[8] = d2.x; d.l[9] = d2.y; d.l[10] = d2.z; d.l[11] = d2.w;
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) nc.l[i] = subb(fp_mod2(i), c.l[i], br, br);   // 2p - c in (0, 2p]
+  fe_mul2<FpParams, false>(r, a, b, nc, d);
+  return r;
+}
+BH_HD fp_t fp_mul2_sub_call(const fp_t &a, const fp_t &b, const fp_t &c, const fp_t &d) {
+  return fp_mul2_sub_vec(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]},
+                         u32x4{a.l[8], a.l[9], a.l[10], a.l[11]}, u32x4{b.l[0], b.l[1], b.l[2], b.l[3]},
+                         u32x4{b.l[4], b.l[5], b.l[6], b.l[7]}, u32x4{b.l[8], b.l[9], b.l[10], b.l[11]},
+                         u32x4{c.l[0], c.l[1], c.l[2], c.l[3]}, u32x4{c.l[4], c.l[5], c.l[6], c.l[7]},
+                         u32x4{c.l[8], c.l[9], c.l[10], c.l[11]}, u32x4{d.l[0], d.l[1], d.l[2], d.l[3]},
+                         u32x4{d.l[4], d.l[5], d.l[6], d.l[7]}, u32x4{d.l[8], d.l[9], d.l[10], d.l[11]});
+}
+
 // ---------------------------------------------------------------------------------------
 // Fp2
 // ---------------------------------------------------------------------------------------
@@ -558,6 +685,19 @@ struct FpOps {
   BH_HD static void sqr(T &r, const T &a) { r = fp_sqr_call(a); }
   // the same product INLINE (no call): for the one place where loads are in flight across it (ec.cuh, xyzz_madd)
   BH_HD static void mul_tail(T &r, const T &a, const T &b) { fe_mul<FpParams, false>(r, a, b); }
+  // r = a*b - c*d, inline, one reduction (fe_mul2 on 2p - c); operands in [0, 2p) -> r < 1.82 p
+  BH_HD static void mul2_sub_tail(T &r, const T &a, const T &b, const T &c, const T &d) {
+    T nc;
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) nc.l[i] = subb(fp_mod2(i), c.l[i], br, br);   // 2p - c in (0, 2p]
+    fe_mul2<FpParams, false>(r, a, b, nc, d);
+  }
+#ifndef BH_FUSED_Y3_CALL
+  BH_HD static void mul2_sub(T &r, const T &a, const T &b, const T &c, const T &d) { mul2_sub_tail(r, a, b, c, d); }
+#else
+  BH_HD static void mul2_sub(T &r, const T &a, const T &b, const T &c, const T &d) { r = fp_mul2_sub_call(a, b, c, d); }
+#endif
   BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
     T one2;
     fe_one(r);

@@ -110,3 +110,26 @@ def test_prover_rs_patch_and_shim_are_consistent():
     assert "impl Drop for MsmJob" in lib_rs and "impl Drop for Scalars" in lib_rs
     # `#[cfg]` never sits directly on an `if` (attributes on if-expressions are rejected by rustc)
     assert not re.search(r"#\[cfg\([^\n]*\)\]\n\+?\s*if ", added)
+
+
+def test_fused_y3_experiment_host_check(tmp_path):
+    """The EXPERIMENTAL fused last line of the mixed addition (-DBH_FUSED_Y3: R*(Q - X3) - Y1*PPP as two products under
+    one Montgomery reduction, ff.cuh fe_mul2) is off in the shipped build and has never run on a device; the curve and
+    field code is __host__ __device__, so the formula and the multiplier are checked here on the host with the switch
+    ON (tests/cpp/fused_y3_check.hip) - against the separate products and against the general addition, incl. operands
+    with every limb set, the doubling and the inverse case (src/multiexp.rs:39)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "tests", "cpp", "fused_y3_check.hip")
+    exe = str(tmp_path / "fused_y3_check.bin")
+    subprocess.run([hipcc, "--cuda-host-only", "-O2", "-std=c++17", "-DBH_FUSED_Y3=1", src, "-o", exe], check=True,
+                   capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "fused Y3: ok" in out.stdout, out.stdout + out.stderr
+    # ... and the product build does not switch it on
+    mk = open(os.path.join(ROOT, "bellman_amd", "csrc", "Makefile")).read()
+    assert "BH_FUSED_Y3" not in mk and "BH_FUSED_Y3" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
