@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 
+#ifndef BH_FUSED_Y3
+#define BH_FUSED_Y3 1   // this program IS the experiment's check: the switch is on whatever the command line says
+#endif
 #include "../../bellman_amd/csrc/ec.cuh"
 
 using namespace bh;
@@ -69,7 +72,7 @@ static bool same_point(const XYZZ<FpOps> &a, const XYZZ<FpOps> &b) {
 }
 
 int main() {
-  static_assert(fused_y3<FpOps>::value, "build this program with -DBH_FUSED_Y3=1");
+  static_assert(fused_y3<FpOps>::value, "the experiment must be switched on in this translation unit");
   int bad = 0;
   // ---- 1. the multiplier ----------------------------------------------------------------------------------------------
   fp_t allones, top;   // every 30-bit limb of the operand (and of its pre-shifted form) set

@@ -126,7 +126,7 @@ def test_fused_y3_experiment_host_check(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "tests", "cpp", "fused_y3_check.hip")
     exe = str(tmp_path / "fused_y3_check.bin")
-    subprocess.run([hipcc, "--cuda-host-only", "-O2", "-std=c++17", "-DBH_FUSED_Y3=1", src, "-o", exe], check=True,
+    subprocess.run([hipcc, "--cuda-host-only", "-O2", "-std=c++17", src, "-o", exe], check=True,
                    capture_output=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "fused Y3: ok" in out.stdout, out.stdout + out.stderr
