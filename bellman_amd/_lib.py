@@ -33,7 +33,7 @@ EXPORTS = [
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
-    "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class",
+    "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
 
 
@@ -92,6 +92,8 @@ def load():
     lib.bh_test_proof_slice.restype = None
     lib.bh_test_synthesis_ms.argtypes = [i32, sz, c.c_uint64, i32]
     lib.bh_test_synthesis_ms.restype = c.c_double
+    lib.bh_test_capture_check.argtypes = [i32, sz, c.c_uint64, c.POINTER(sz)]
+    lib.bh_test_capture_check.restype = c.c_double
     lib.bh_fft_fr.argtypes = [vp, vp, u32, i32]
     lib.bh_fft_fr_dev.argtypes = [vp, vp, u32, i32, vp]
     lib.bh_fr_mul_assign_dev.argtypes = [vp, vp, vp, sz, vp]

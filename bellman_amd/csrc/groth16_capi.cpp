@@ -265,6 +265,23 @@ double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mo
   });
   return ms;
 }
+double bh_test_capture_check(int circuit_kind, size_t size, uint64_t seed, size_t out4[4]) {
+  // host only: the structure capture (R1cs's constructor without the upload) of a demo circuit, checked against the
+  // ProvingAssignment of the same circuit - captured A, B, C times the assignment == its a, b, c rows
+  using namespace groth16;
+  if (!out4) return -1.0;
+  std::vector<Fr> constants(circuit_kind == 0 ? size : 0);
+  for (size_t i = 0; i < constants.size(); i++) constants[i] = Fr::from_u64(0x9E3779B97F4A7C15ULL * (i % 7 + 1));   // repeats: the table must share them
+  Fr wit[2] = {Fr::from_u64(123456789), Fr::from_u64(987654321)};
+  double ms = -1.0;
+  with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &shape) -> int {
+    return with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &proved) -> int {
+      ms = capture_check_for_tests(shape, proved, out4);
+      return 0;
+    });
+  });
+  return ms;
+}
 int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const void *witness, const void *constants,
                             size_t counts3[3], void *a, void *b, void *c, void *inputs, void *aux, uint64_t *a_aux_density,
                             uint64_t *b_input_density, uint64_t *b_aux_density) {

@@ -39,4 +39,5 @@ inline double now_ms() {
 
 }  // namespace detail
 void proof_slice_for_tests(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);   // groth16_prover.cpp
+double capture_check_for_tests(bellman::Circuit &shape_of, bellman::Circuit &proved, size_t out4[4]);   // groth16_prover.cpp
 }  // namespace groth16

