@@ -145,6 +145,9 @@ template <class F> struct fused_y3 { static constexpr bool value = false; };
 #ifdef BH_FUSED_Y3
 template <> struct fused_y3<FpOps> { static constexpr bool value = true; };
 #endif
+#ifdef BH_FUSED_Y3_G2
+template <> struct fused_y3<Fp2Ops> { static constexpr bool value = true; };   // fused only in the prefetching overload
+#endif
 template <class F, class PF>
 BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   typedef typename F::T T;

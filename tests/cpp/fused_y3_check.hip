@@ -11,7 +11,10 @@
 #include <cstring>
 
 #ifndef BH_FUSED_Y3
-#define BH_FUSED_Y3 1   // this program IS the experiment's check: the switch is on whatever the command line says
+#define BH_FUSED_Y3 1   // this program IS the experiment's check: the switches are on whatever the command line says
+#endif
+#ifndef BH_FUSED_Y3_G2
+#define BH_FUSED_Y3_G2 1
 #endif
 #include "../../bellman_amd/csrc/ec.cuh"
 
@@ -71,9 +74,90 @@ static bool same_point(const XYZZ<FpOps> &a, const XYZZ<FpOps> &b) {
   return memcmp(&x, &y, sizeof x) == 0;
 }
 
+// ---- G2: the same two checks over Fp2 (prefetching overload of xyzz_madd only: the one-lane accumulate kernel) ------
+static const u32 G2W[48] = {
+    0x02940a10u, 0xf5f28fa2u, 0x87b4961au, 0xb3f5fb26u, 0x3e2ae580u, 0xa1a893b5u, 0x1a3caee9u, 0x9894999du, 0x1863366bu, 0x6f67b763u, 0x4350bcd7u, 0x05819192u,
+    0x9e23f606u, 0xa5a9c075u, 0xbccd60c3u, 0xaaa0c59du, 0xe2867806u, 0x3bb17e18u, 0x8541b367u, 0x1b1ab6ccu, 0xf2158547u, 0xc2b6ed0eu, 0x7360edf3u, 0x11922a09u,
+    0x60494c4au, 0x4c730af8u, 0x5e369c5au, 0x597cfa1fu, 0xaa0a635au, 0xe7e6856cu, 0x6e0d495fu, 0xbbefb5e9u, 0xf0ef25a2u, 0x07d3a975u, 0x7e80dae5u, 0x0083fd8eu,
+    0xdf64b05du, 0xadc0fc92u, 0x2b1461dcu, 0x18aa270au, 0x3be4eba0u, 0x86adac6au, 0xc93da33au, 0x79495c4eu, 0xa43ccaedu, 0xe7175850u, 0x63de1bf2u, 0x0b2bc2a1u};
+static Affine<Fp2Ops> to_affine2(const XYZZ<Fp2Ops> &p) {
+  Affine<Fp2Ops> a;
+  if (xyzz_is_identity(p)) { Fp2Ops::zero(a.x); Fp2Ops::zero(a.y); return a; }
+  fp2_t izz, izzz;
+  Fp2Ops::inv(izz, p.zz);
+  Fp2Ops::inv(izzz, p.zzz);
+  Fp2Ops::mul(a.x, p.x, izz);
+  Fp2Ops::mul(a.y, p.y, izzz);
+  Fp2Ops::canon(a.x);
+  Fp2Ops::canon(a.y);
+  return a;
+}
+static bool same_point2(const XYZZ<Fp2Ops> &a, const XYZZ<Fp2Ops> &b) {
+  const Affine<Fp2Ops> x = to_affine2(a), y = to_affine2(b);
+  return memcmp(&x, &y, sizeof x) == 0;
+}
+static int check_g2() {
+  static_assert(fused_y3<Fp2Ops>::value, "the G2 experiment must be switched on in this translation unit");
+  int bad = 0;
+  for (int it = 0; it < 2000; it++) {
+    fp2_t a, b, c, d, ab, cd, dif, g;
+    a.c0 = random_below_2p(); a.c1 = random_below_2p(); b.c0 = random_below_2p(); b.c1 = random_below_2p();
+    c.c0 = random_below_2p(); c.c1 = random_below_2p(); d.c0 = random_below_2p(); d.c1 = random_below_2p();
+    Fp2Ops::mul(ab, a, b);
+    Fp2Ops::mul(cd, c, d);
+    Fp2Ops::sub(dif, ab, cd);
+    Fp2Ops::mul2_sub_tail(g, a, b, c, d);
+    if (!same(g.c0, dif.c0) || !same(g.c1, dif.c1) || !below_2p(g.c0) || !below_2p(g.c1)) {
+      if (bad++ < 5) printf("Fp2 mul2_sub_tail mismatch at %d\n", it);
+    }
+  }
+  Affine<Fp2Ops> gen;
+  memcpy(&gen, G2W, sizeof gen);
+  constexpr int NP = 24;
+  Affine<Fp2Ops> pts[NP];
+  {
+    XYZZ<Fp2Ops> g1, acc;
+    xyzz_from_affine(g1, gen);
+    acc = g1;
+    for (int i = 0; i < NP; i++) {
+      pts[i] = to_affine2(acc);
+      XYZZ<Fp2Ops> t;
+      for (int r = 0; r < 1 + (i % 3); r++) { xyzz_add(t, acc, g1); acc = t; }
+      if (i % 5 == 3) { xyzz_dbl(t, acc); acc = t; }
+    }
+  }
+  auto nop = [] {};
+  XYZZ<Fp2Ops> acc, ref;
+  xyzz_set_identity(acc);
+  xyzz_set_identity(ref);
+  for (int round = 0; round < 2; round++) {
+    for (int i = 0; i < NP; i++) {
+      Affine<Fp2Ops> q = pts[(i * 5 + round) % NP];
+      if ((i + round) % 4 == 1) { Fp2Ops::neg(q.y, q.y); Fp2Ops::canon(q.y); }
+      XYZZ<Fp2Ops> qx, t;
+      xyzz_from_affine(qx, q);
+      xyzz_add(t, ref, qx);
+      ref = t;
+      xyzz_madd(acc, q, nop);
+      if (!same_point2(acc, ref)) { if (bad++ < 5) printf("G2 madd mismatch round %d i %d\n", round, i); }
+    }
+  }
+  Affine<Fp2Ops> same_pt = to_affine2(acc);
+  XYZZ<Fp2Ops> d2 = acc, r2;
+  xyzz_madd(d2, same_pt, nop);
+  xyzz_dbl(r2, acc);
+  if (!same_point2(d2, r2)) { bad++; printf("G2 doubling path\n"); }
+  Affine<Fp2Ops> neg_pt = same_pt;
+  Fp2Ops::neg(neg_pt.y, neg_pt.y);
+  XYZZ<Fp2Ops> z = acc;
+  xyzz_madd(z, neg_pt, nop);
+  if (!xyzz_is_identity(z)) { bad++; printf("G2 inverse path\n"); }
+  return bad;
+}
+
 int main() {
   static_assert(fused_y3<FpOps>::value, "the experiment must be switched on in this translation unit");
-  int bad = 0;
+  int bad = check_g2();
   // ---- 1. the multiplier ----------------------------------------------------------------------------------------------
   fp_t allones, top;   // every 30-bit limb of the operand (and of its pre-shifted form) set
   for (int i = 0; i < 12; i++) allones.l[i] = 0xffffffffu;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # NEXT GPU SESSION, first call: A/B of the fused last line of the G1 mixed addition (-DBH_FUSED_Y3).
 # Before calling gpurun, build the experimental library HERE (it travels with the snapshot):
-#     make -C bellman_amd/csrc -j8 OUT=../lib_exp EXTRA=-DBH_FUSED_Y3=1
+#     make -C bellman_amd/csrc -j8 OUT=../lib_exp EXTRA="-DBH_FUSED_Y3=1 -DBH_FUSED_Y3_G2=1"
+# (G1 and the one-lane G2 accumulate kernel; build two libraries to price them separately)
 # Then:  gpurun --timeout 600 -- 'bash tools/gpu_r4_fused_y3.sh'
 # Parity first (the experiment has only ever run on the host), then timing against the shipped build.
 cd "$GRAFT_REPO_ROOT"
@@ -16,6 +17,11 @@ for rep in 1 2; do
   BELLMAN_HIP_LIB=$EXP python tools/profile_suite.py sizes 1 16 20 > $OUT/sizes_exp_$rep.txt 2>&1
 done
 paste -d'\n' $OUT/sizes_base_2.txt $OUT/sizes_exp_2.txt
+for rep in 1 2; do
+  python tools/profile_suite.py sizes 2 18 20 > $OUT/sizes_g2_base_$rep.txt 2>&1
+  BELLMAN_HIP_LIB=$EXP python tools/profile_suite.py sizes 2 18 20 > $OUT/sizes_g2_exp_$rep.txt 2>&1
+done
+paste -d'\n' $OUT/sizes_g2_base_2.txt $OUT/sizes_g2_exp_2.txt
 BENCH="python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-proof --timed-steps-only"
 $BENCH > $OUT/bench_base.json 2>/dev/null; BELLMAN_HIP_LIB=$EXP $BENCH > $OUT/bench_exp.json 2>/dev/null
 python - <<'PY'
