@@ -1,7 +1,7 @@
 #!/bin/bash
 # NEXT GPU SESSION, first call: A/B of the fused last line of the G1 mixed addition (-DBH_FUSED_Y3).
 # Before calling gpurun, build the experimental library HERE (it travels with the snapshot):
-#     make -C bellman_amd/csrc -j8 OUT=../lib_exp EXTRA="-DBH_FUSED_Y3=1 -DBH_FUSED_Y3_G2=1"
+#     make -C bellman_amd/csrc -j8 OUT=../lib_exp EXTRA="-DBH_FUSED_Y3=1 -DBH_FUSED_Y3_G2=1 -DBH_FAST_ZERO=1"
 # (G1 and the one-lane G2 accumulate kernel; build two libraries to price them separately)
 # Then:  gpurun --timeout 600 -- 'bash tools/gpu_r4_fused_y3.sh'
 # Parity first (the experiment has only ever run on the host), then timing against the shipped build.
