@@ -568,11 +568,6 @@ BH_HD void fpl_add2(fp_t &r0, const fp_t &a0, const fp_t &b0, fp_t &r1, const fp
   }
 }
 BH_HD bool fpl_is_zero(const fp_t &a) {
-#ifdef BH_FAST_ZERO
-  // EXPERIMENT (off by default, host-checked only): a lazily reduced zero is 0 or p, so a low word that is neither
-  // settles it - the twelve-word comparison runs for one value in 2^31
-  if (a.l[0] != 0u && a.l[0] != FpParams::mod(0)) return false;
-#endif
   u32 o = 0, q = 0;
 #pragma unroll
   for (int i = 0; i < 12; i++) { o |= a.l[i]; q |= a.l[i] ^ FpParams::mod(i); }

@@ -16,9 +16,6 @@
 #ifndef BH_FUSED_Y3_G2
 #define BH_FUSED_Y3_G2 1
 #endif
-#ifndef BH_FAST_ZERO
-#define BH_FAST_ZERO 1   // the zero test that looks at one word first (ff.cuh fpl_is_zero)
-#endif
 #include "../../bellman_amd/csrc/ec.cuh"
 
 using namespace bh;
@@ -161,19 +158,6 @@ static int check_g2() {
 int main() {
   static_assert(fused_y3<FpOps>::value, "the experiment must be switched on in this translation unit");
   int bad = check_g2();
-  {   // fpl_is_zero: 0 and p are zero; values sharing their low word are not
-    fp_t z, pm, t;
-    fe_zero(z);
-    for (int i = 0; i < 12; i++) pm.l[i] = FpParams::mod(i);
-    if (!fpl_is_zero(z) || !fpl_is_zero(pm)) { bad++; printf("is_zero misses a zero\n"); }
-    for (int i = 1; i < 12; i++) {
-      t = z; t.l[i] = 1u << (i % 31);
-      if (fpl_is_zero(t)) { bad++; printf("is_zero: false positive (low word 0)\n"); }
-      t = pm; t.l[i] ^= 1u << (i % 31);
-      if (fpl_is_zero(t)) { bad++; printf("is_zero: false positive (low word of p)\n"); }
-    }
-    for (int it = 0; it < 1000; it++) { t = random_below_2p(); if (fpl_is_zero(t)) { bad++; printf("is_zero: random\n"); } }
-  }
   // ---- 1. the multiplier ----------------------------------------------------------------------------------------------
   fp_t allones, top;   // every 30-bit limb of the operand (and of its pre-shifted form) set
   for (int i = 0; i < 12; i++) allones.l[i] = 0xffffffffu;

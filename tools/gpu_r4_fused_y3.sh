@@ -1,10 +1,9 @@
 #!/bin/bash
-# NEXT GPU SESSION, first call: A/B of the host-checked, never-run kernel experiments of DESIGN.md 8.8 (d), (e).
+# NEXT GPU SESSION, first call: A/B of the host-checked, never-run kernel experiments of DESIGN.md 8.8 (d).
 # Before calling gpurun, build the experimental libraries HERE (they travel with the snapshot, ~3 MB each):
 #     make -C bellman_amd/csrc -j8 OUT=../lib_exp_y3   EXTRA=-DBH_FUSED_Y3=1        # G1: Y3 as one fused product
 #     make -C bellman_amd/csrc -j8 OUT=../lib_exp_y3g2 EXTRA=-DBH_FUSED_Y3_G2=1     # one-lane G2 accumulate kernel
-#     make -C bellman_amd/csrc -j8 OUT=../lib_exp_zero EXTRA=-DBH_FAST_ZERO=1       # zero test on one word first
-#     make -C bellman_amd/csrc -j8 OUT=../lib_exp_all  EXTRA="-DBH_FUSED_Y3=1 -DBH_FUSED_Y3_G2=1 -DBH_FAST_ZERO=1"
+#     make -C bellman_amd/csrc -j8 OUT=../lib_exp_all  EXTRA="-DBH_FUSED_Y3=1 -DBH_FUSED_Y3_G2=1"
 # Then:  gpurun --timeout 900 -- 'bash tools/gpu_r4_fused_y3.sh'
 # For every library found: parity first (the experiments have only ever run on the host), then G1 / G2 stage times
 # beside the shipped build's, alternating.
