@@ -31,7 +31,7 @@ EXPORTS = [
     "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
     "bh_groth16_prove_demo_async", "bh_groth16_proof_wait",
     "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
-    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_msm_stages",
+    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
     "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
@@ -183,6 +183,7 @@ def load():
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]
     lib.bh_test_msm_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp]
     lib.bh_test_g2_k3_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+    lib.bh_test_g2_pairs_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_fr_mul_bform_host"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz]
         getattr(lib, name).restype = None

@@ -1175,6 +1175,12 @@ int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   return test_g2_k3(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
 }
+int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
+                         const void *b_dev, size_t n) {
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return test_g2_pairs(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
+}
 int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
                        uint64_t *pairs_out_host, uint32_t *zstart_out_host) {
   return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, zstart_out_host);

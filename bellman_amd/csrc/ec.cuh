@@ -140,14 +140,6 @@ BH_HD void order_after(T &v) {
   (void)v;
 #endif
 }
-// which field bundles take the fused last line of the formula (see the end of xyzz_madd below)
-template <class F> struct fused_y3 { static constexpr bool value = false; };
-#ifdef BH_FUSED_Y3
-template <> struct fused_y3<FpOps> { static constexpr bool value = true; };
-#endif
-#ifdef BH_FUSED_Y3_G2
-template <> struct fused_y3<Fp2Ops> { static constexpr bool value = true; };   // fused only in the prefetching overload
-#endif
 template <class F, class PF>
 BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   typedef typename F::T T;
@@ -184,9 +176,9 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   F::sub(t, t, ppp);
   F::sub(t, t, qq);
   F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
-  if constexpr (fused_y3<F>::value) {
-    // EXPERIMENT (-DBH_FUSED_Y3, off by default, never run on the device): Y3 = R*(Q - X3) - Y1*PPP as two products
-    // under one reduction (ff.cuh fe_mul2: 169 mads, one out-of-line call and one subtraction fewer per addition)
+  if constexpr (F::FUSED_Y3_TAIL) {
+    // Y3 = R*(Q - X3) - Y1*PPP as two products under ONE reduction (ff.cuh fe_mul2: 169 mads, one out-of-line call and
+    // one subtraction fewer per Fp-level product pair; profiles/r4_call1_fused_y3.txt: G1 accumulate -4.3 %, G2 -6 %)
     F::sub(qq, qq, t);
     acc.x = t;
     order_after(qq);
@@ -234,7 +226,7 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
   F::sub(t, t, ppp);
   F::sub(t, t, qq);
   F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
-  if constexpr (fused_y3<F>::value) {   // EXPERIMENT, see the overload above
+  if constexpr (F::FUSED_Y3) {   // see the overload above
     F::sub(qq, qq, t);
     F::mul2_sub(acc.y, r, qq, acc.y, ppp);
   } else {

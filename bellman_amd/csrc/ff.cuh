@@ -337,7 +337,7 @@ BH_HD void fe_mul_b(Fe<P> &r, const Fe<P> &a, const u32 *B) {
 // Fp's 676).  Both products accumulate into the same 2L columns; a column that could pass 2^64 under the second
 // product (or in the reduction afterwards) first sends its high part to its neighbour - Radix30Fused decides per column
 // at compile time, with every limb of all four operands at 2^30 - 1.  Result < (a*b + c*d) / 2^(32N) + m.
-// EXPERIMENT (BH_FUSED_Y3, ec.cuh): validated on the host against the separate products, never timed on the device.
+// Used for the last line of the mixed addition (ec.cuh, Y3) and for the lane-pair Fp2 product (fp2pair.cuh).
 template <class P>
 struct Radix30Fused {
   typedef Radix30<P> R;
@@ -629,34 +629,6 @@ BH_HD fp_t fp_mul_call(const fp_t &a, const fp_t &b) {
                     u32x4{b.l[4], b.l[5], b.l[6], b.l[7]}, u32x4{b.l[8], b.l[9], b.l[10], b.l[11]});
 }
 
-// a*b - c*d out of line (EXPERIMENT, BH_FUSED_Y3_CALL): 48 argument words, of which the calling convention passes 32 in
-// registers and 16 through scratch memory
-BH_NOINLINE_HD static fp_t fp_mul2_sub_vec(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2, u32x4 c0, u32x4 c1,
-                                           u32x4 c2, u32x4 d0, u32x4 d1, u32x4 d2) {
-  fp_t a, b, c, d, nc, r;
-  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w; a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
-  a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w;
-  b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w; b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w;
-  b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w;
-  c.l[0] = c0.x; c.l[1] = c0.y; c.l[2] = c0.z; c.l[3] = c0.w; c.l[4] = c1.x; c.l[5] = c1.y; c.l[6] = c1.z; c.l[7] = c1.w;
-  c.l[8] = c2.x; c.l[9] = c2.y; c.l[10] = c2.z; c.l[11] = c2.w;
-  d.l[0] = d0.x; d.l[1] = d0.y; d.l[2] = d0.z; d.l[3] = d0.w; d.l[4] = d1.x; d.l[5] = d1.y; d.l[6] = d1.z; d.l[7] = d1.w;
-  d.l[8] = d2.x; d.l[9] = d2.y; d.l[10] = d2.z; d.l[11] = d2.w;
-  u32 br = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) nc.l[i] = subb(fp_mod2(i), c.l[i], br, br);   // 2p - c in (0, 2p]
-  fe_mul2<FpParams, false>(r, a, b, nc, d);
-  return r;
-}
-BH_HD fp_t fp_mul2_sub_call(const fp_t &a, const fp_t &b, const fp_t &c, const fp_t &d) {
-  return fp_mul2_sub_vec(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]},
-                         u32x4{a.l[8], a.l[9], a.l[10], a.l[11]}, u32x4{b.l[0], b.l[1], b.l[2], b.l[3]},
-                         u32x4{b.l[4], b.l[5], b.l[6], b.l[7]}, u32x4{b.l[8], b.l[9], b.l[10], b.l[11]},
-                         u32x4{c.l[0], c.l[1], c.l[2], c.l[3]}, u32x4{c.l[4], c.l[5], c.l[6], c.l[7]},
-                         u32x4{c.l[8], c.l[9], c.l[10], c.l[11]}, u32x4{d.l[0], d.l[1], d.l[2], d.l[3]},
-                         u32x4{d.l[4], d.l[5], d.l[6], d.l[7]}, u32x4{d.l[8], d.l[9], d.l[10], d.l[11]});
-}
-
 // ---------------------------------------------------------------------------------------
 // Fp2
 // ---------------------------------------------------------------------------------------
@@ -669,7 +641,10 @@ struct FpOps {
   typedef fp_t T;
   typedef FpOps Mem;                   // record format in memory == what a lane holds
   static constexpr int WORDS = 12;
-  static constexpr int LANES = 1;      // lanes per group element (3 for the K3 form of Fp2, fp2k3.cuh)
+  static constexpr int LANES = 1;      // lanes per group element (3 for the K3 form of Fp2, fp2k3.cuh; 2: fp2pair.cuh)
+  // the last line of the mixed addition as ONE fused product a*b - c*d (ec.cuh xyzz_madd): in the overload that
+  // prefetches (..._TAIL) / in the plain one
+  static constexpr bool FUSED_Y3_TAIL = true, FUSED_Y3 = true;
   BH_HD static void load(T &r, const T *p) { r = *p; }
   BH_HD static void store(T *p, const T &v) { *p = v; }
   BH_HD static void zero(T &r) { fe_zero(r); }
@@ -693,11 +668,7 @@ struct FpOps {
     for (int i = 0; i < 12; i++) nc.l[i] = subb(fp_mod2(i), c.l[i], br, br);   // 2p - c in (0, 2p]
     fe_mul2<FpParams, false>(r, a, b, nc, d);
   }
-#ifndef BH_FUSED_Y3_CALL
   BH_HD static void mul2_sub(T &r, const T &a, const T &b, const T &c, const T &d) { mul2_sub_tail(r, a, b, c, d); }
-#else
-  BH_HD static void mul2_sub(T &r, const T &a, const T &b, const T &c, const T &d) { r = fp_mul2_sub_call(a, b, c, d); }
-#endif
   BH_HD static void curve_b(T &r) {   // G1: y^2 = x^3 + 4
     T one2;
     fe_one(r);
@@ -724,6 +695,9 @@ struct Fp2Ops {
   typedef Fp2Ops Mem;
   static constexpr int WORDS = 24;
   static constexpr int LANES = 1;
+  // fused only where it was measured to pay: the software-pipelined accumulation (one lane per point, inline tail);
+  // the other one-lane G2 kernels keep Karatsuba over out-of-line products (code size)
+  static constexpr bool FUSED_Y3_TAIL = true, FUSED_Y3 = false;
   BH_HD static void load(T &r, const T *p) { r = *p; }
   BH_HD static void store(T *p, const T &v) { *p = v; }
   BH_HD static void zero(T &r) { fe_zero(r.c0); fe_zero(r.c1); }
@@ -759,8 +733,8 @@ struct Fp2Ops {
     fpl_sub(r.c1, t2, t1);
     fpl_sub(r.c0, t0, t1);
   }
-  // r = a*b - c*d (EXPERIMENT, BH_FUSED_Y3_G2): Karatsuba whose three lanes are each ONE fused product (fe_mul2) -
-  // three reductions instead of six; inline like mul_tail
+  // r = a*b - c*d: Karatsuba whose three products are each ONE fused product (fe_mul2) - three reductions instead of
+  // six; inline like mul_tail
   BH_HD static void mul2_sub_tail(T &r, const T &a, const T &b, const T &c, const T &d) {
     fp_t l0, l1, l2, sa, sb, sc, sd;
     FpOps::mul2_sub_tail(l0, a.c0, b.c0, c.c0, d.c0);

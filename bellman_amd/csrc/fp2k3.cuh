@@ -92,6 +92,7 @@ struct Fp2K3Ops {
   typedef Fp2Ops Mem;    // the record format in memory (c0 | c1)
   static constexpr int WORDS = 12;
   static constexpr int LANES = 3;
+  static constexpr bool FUSED_Y3_TAIL = false, FUSED_Y3 = false;
 
   __device__ __forceinline__ static void zero(T &r) { fe_zero(r); }
   __device__ __forceinline__ static void one(T &r) {   // 1 = (1, 0, 1)

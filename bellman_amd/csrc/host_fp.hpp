@@ -116,6 +116,7 @@ static inline void inv(hfp_t &r, const hfp_t &a) {  // a^(p-2)
 
 struct HostFpOps {
   typedef hfp_t T;
+  static constexpr bool FUSED_Y3_TAIL = false, FUSED_Y3 = false;   // (the fused last line of ec.cuh's mixed addition: device only)
   static void zero(T &r) { memset(&r, 0, sizeof r); }
   static void one(T &r) { memcpy(r.l, hostfp::ONE, sizeof hostfp::ONE); }
   static bool is_zero(const T &a) { return hostfp::is_zero(a); }
@@ -133,6 +134,7 @@ struct HostFpOps {
 struct HostFp2Ops {
   typedef hfp2_t T;
   typedef HostFpOps B;
+  static constexpr bool FUSED_Y3_TAIL = false, FUSED_Y3 = false;
   static void zero(T &r) { memset(&r, 0, sizeof r); }
   static void one(T &r) { B::one(r.c0); B::zero(r.c1); }
   static bool is_zero(const T &a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }

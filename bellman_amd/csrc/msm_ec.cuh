@@ -10,7 +10,7 @@
 #include <array>
 #include <cmath>
 
-#include "fp2k3.cuh"
+#include "fp2pair.cuh"
 #include "host_fp.hpp"
 #include "msm_scalar.cuh"
 #include "msm_types.hpp"
@@ -19,18 +19,25 @@ namespace bh {
 
 // ---------------------------------------------------------------------------------------------------------
 // Logical workers.  A kernel below is written for "workers": one thread when a lane holds a whole group
-// element (F::LANES == 1: G1, single-lane G2) or one lane TRIPLE for the K3 form of G2 (fp2k3.cuh), where a
-// wavefront carries PER_WAVE triples - 21, or 16 where shuffle trees want a power of two.  All lanes of a
-// triple see the same worker index and take the same branches (every predicate of the curve code is
-// triple-uniform).
+// element (F::LANES == 1: G1, single-lane G2), one lane TRIPLE for the K3 form of G2 (fp2k3.cuh), where a
+// wavefront carries PER_WAVE triples - 21, or 16 where shuffle trees want a power of two - or one lane PAIR
+// (fp2pair.cuh, 32 per wavefront).  All lanes of a worker see the same worker index and take the same branches
+// (every predicate of the curve code is uniform over the worker's lanes).
 // ---------------------------------------------------------------------------------------------------------
 template <class F>
-constexpr u32 default_per_wave() { return F::LANES == 3 ? 21u : 64u; }
+constexpr u32 default_per_wave() { return F::LANES == 3 ? 21u : F::LANES == 2 ? 32u : 64u; }
 template <class F>
-constexpr u32 tree_per_wave() { return F::LANES == 3 ? 16u : 64u; }
+constexpr u32 tree_per_wave() { return F::LANES == 3 ? 16u : F::LANES == 2 ? 32u : 64u; }
 template <class F>
 constexpr u32 workers_per_block(u32 threads, u32 per_wave) { return F::LANES == 1 ? threads : (threads / 64u) * per_wave; }
 
+// which of its worker's lanes a thread is (0 = the lane that speaks for the worker)
+template <class F>
+__device__ __forceinline__ u32 worker_role() {
+  if constexpr (F::LANES == 1) return 0u;
+  else if constexpr (F::LANES == 2) return pair_role();
+  else return k3_role();
+}
 // false for lanes that carry no worker (lane 63 of a K3 wavefront, lanes beyond PER_WAVE triples)
 template <class F>
 __device__ __forceinline__ bool worker_index(u32 per_wave, u32 &in_block, u32 &global) {
@@ -39,7 +46,7 @@ __device__ __forceinline__ bool worker_index(u32 per_wave, u32 &in_block, u32 &g
     global = blockIdx.x * blockDim.x + threadIdx.x;
     return true;
   } else {
-    const u32 t = k3_triple(threadIdx.x & 63u);
+    const u32 t = F::LANES == 3 ? k3_triple(threadIdx.x & 63u) : (threadIdx.x & 63u) >> 1;
     const u32 wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
     in_block = wave * per_wave + t;
     global = (blockIdx.x * waves_per_block + wave) * per_wave + t;
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
                                                              XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
                                                              u32 chunks_per_window, ErrFlags *err) {
   static_assert(!LDS_ACC || F::LANES == 1, "the LDS accumulator belongs to the single-lane kernels");
+  static_assert(F::LANES == 1 || F::LANES == 2 || F::LANES == 3, "one lane, a lane pair or a lane triple per group element");
   const u32 w = blockIdx.y;
   u32 in_block, lane;
   if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs,
   const u32 d = v.d_last;
   const u32 last = run_last_chunk(src, n, z, K, lane, d);
   if (last - lane > walk) {
-    if (F::LANES == 1 || k3_role() == 0) {   // one entry per worker
+    if (worker_role<F>() == 0) {   // one entry per worker
       const u32 slot = atomicAdd(&err->nlong, 1u);
       if (slot < max_long) { LongRun lr = {w, lane, d, last}; long_runs[slot] = lr; }
     }
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(64) void msm_merge_runs_kernel(XYZZ<typename F::Mem
     LongRun lr = {0, 0, 0, 0};
     if (valid) lr = runs[e];
     if (valid && lr.last - lr.lane > BIG_RUN_CHUNKS) {
-      if (k == 0 && (F::LANES == 1 || k3_role() == 0)) {
+      if (k == 0 && worker_role<F>() == 0) {
         const u32 slot = atomicAdd(&err->nbig, 1u);
         if (slot < max_big) big_runs[slot] = lr;
       }
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typen
   u32 wid, gid;
   const bool live = worker_index<F>(PW, wid, gid);   // idle lanes stay for the barriers
   const u32 wave = threadIdx.x >> 6, t_in_wave = wid - wave * PW;
-  const u32 role = F::LANES == 1 ? 0u : k3_role();
+  const u32 role = worker_role<F>();
   for (u32 e = blockIdx.x; e < nruns; e += gridDim.x) {
     const LongRun lr = runs[e];
     const u64 slot0 = (u64)lr.w * chunks_per_window;
@@ -504,7 +512,7 @@ struct SumJobs {
 // K3 reduction can also put up to 64 workers on one output (the tree then crosses wavefronts through LDS); with 16
 // the 256-element column sums of a window table's 2^15 buckets were 16 + 4 additions deep.
 template <class F>
-constexpr u32 sum_block_threads() { return F::LANES == 3 ? 256u : 64u; }
+constexpr u32 sum_block_threads() { return F::LANES == 3 ? 256u : F::LANES == 2 ? 128u : 64u; }
 template <class F>
 __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void msm_sum_kernel(SumJobs<F> jobs) {
   u32 blk = blockIdx.x;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void
     group_reduce_points<F>(acc, G, sub);
   } else {
     // the group spans G / PW wavefronts: tree inside each wavefront, partials through LDS, tree over the partials
-    const u32 wave = threadIdx.x >> 6, t_in_wave = t - wave * PW, role = F::LANES == 1 ? 0u : k3_role();
+    const u32 wave = threadIdx.x >> 6, t_in_wave = t - wave * PW, role = worker_role<F>();
     group_reduce_points<F>(acc, PW, t_in_wave);
     if (live && t_in_wave == 0) wave_part[wave][role] = acc;
     __syncthreads();
@@ -1384,27 +1392,9 @@ template <class F> static void devhdr_point_add_t(void *r, const void *a, const 
 }
 template <class F> static void devhdr_point_mul_t(void *r, const void *a, const u32 *k) { generic_point_mul<F>(r, a, k); }
 
-// OPS = the record format in memory (FpOps / Fp2Ops); KOPS / ALT = the two kernel bundles of the group.  The
-// accumulation runs ALT on jobs of more than ALT_ABOVE terms; merge + reduction run ALT when the plan has more than
-// ALT_RED_ABOVE buckets (throughput-bound); bh_msm_opts.flags KOPS_FLAG / ALT_FLAG force one bundle for both.
-#define BH_INSTANTIATE_MSM(SUFFIX, OPS, KOPS, ALT, KOPS_FLAG, ALT_FLAG, ALT_ABOVE, ALT_RED_ABOVE)             \
-  int msm_enqueue_##SUFFIX(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip,                    \
-                           const void *scalars_dev, u64 n, int fmt, const u64 *density_dev,                 \
-                           const MsmOpts &opts, const WindowTable *table) {                                  \
-    const bool force_alt = (opts.flags & (ALT_FLAG)) != 0, force_k = !force_alt && (opts.flags & (KOPS_FLAG)) != 0; \
-    const bool with_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c);  \
-    const MsmPlan pl = with_table ? make_table_plan(n, *table, opts.chunk, OPS::WORDS == 24, 256)             \
-                                  : make_plan(n, opts.c, opts.chunk, OPS::WORDS == 24);                       \
-    const bool acc_alt = force_alt ? true : force_k ? false : n > (ALT_ABOVE);                                \
-    const bool red_alt = force_alt ? true : force_k ? false : (u64)pl.NB > (ALT_RED_ABOVE);                   \
-    if (acc_alt && red_alt)                                                                                   \
-      return msm_enqueue<ALT, ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
-    if (acc_alt)                                                                                              \
-      return msm_enqueue<ALT, KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);  \
-    if (red_alt)                                                                                              \
-      return msm_enqueue<KOPS, ALT>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);  \
-    return msm_enqueue<KOPS, KOPS>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);   \
-  }                                                                                                           \
+// OPS = the record format in memory (FpOps / Fp2Ops).  msm_enqueue_<group> itself (which kernel bundle accumulates,
+// which one merges and reduces) is written out in msm_g1.hip / msm_g2.hip.
+#define BH_INSTANTIATE_MSM_SUPPORT(SUFFIX, OPS)                                                               \
   int window_table_##SUFFIX(void *table_dev, u64 n, u32 c, u32 W, hipStream_t st) {                           \
     return window_table_t<OPS>(table_dev, n, c, W, st);                                                       \
   }                                                                                                           \

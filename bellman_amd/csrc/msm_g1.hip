@@ -1,5 +1,9 @@
 // G1 (Fp) instantiation of the MSM pipeline: one lane per point (a single kernel bundle: no flag, no size switch)
 #include "msm_ec.cuh"
 namespace bh {
-BH_INSTANTIATE_MSM(g1, FpOps, FpOps, FpOps, 0u, 0u, ~(u64)0, ~(u64)0)
+int msm_enqueue_g1(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n, int fmt,
+                   const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
+  return msm_enqueue<FpOps, FpOps>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table);
+}
+BH_INSTANTIATE_MSM_SUPPORT(g1, FpOps)
 }

@@ -125,6 +125,7 @@ int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int
 int test_point_add_g1(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 int test_point_add_g2(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 int test_g2_k3(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n);   // msm_g2.hip
+int test_g2_pairs(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n);
 // per-point status word of the uncompressed-point loader (api.hip decode kernel + point_check_kernel)
 enum PointStatus : u32 {
   PT_COMPRESSED = 1,        // compression flag set on an uncompressed point

@@ -184,7 +184,7 @@ class MsmOpts(ctypes.Structure):
     _fields_ = [("window_bits", ctypes.c_uint32), ("chunk", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
 
 
-ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES, HOLD = 1, 2, 4, 8, 16, 32, 64, 128
+ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES, HOLD, G2_LANE_PAIRS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,

@@ -18,6 +18,9 @@ int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev
  * addition, by the mixed addition (a[i] stays when b[i] is the identity), and 2 a[i]; n affine records each, HOST */
 int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
                       const void *b_dev, size_t n);
+/* the same in the lane-pair form (csrc/fp2pair.cuh: schoolbook Fp2 products, one reduction per lane) */
+int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
+                         const void *b_dev, size_t n);
 /* runs MSM stages 1-3 (digits, radix sort, zero-digit count) for window size c and copies the
  * sorted (digit<<32|base) pairs [W*n] and the per-window count of zero digits [W] back (bring-up aid) */
 int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,

@@ -1,21 +1,17 @@
-// Host check of the EXPERIMENTAL fused last line of the mixed addition (-DBH_FUSED_Y3, bellman_amd/csrc/ec.cuh) and of the
-// two-products-one-reduction multiplier under it (ff.cuh fe_mul2).  The curve and field code is __host__ __device__: this
-// program compiles it for the host with the experiment switched ON and compares
+// Host check of the fused last line of the mixed addition (bellman_amd/csrc/ec.cuh: Y3 = R*(Q - X3) - Y1*PPP as ONE
+// product pair under one reduction) and of the two-products-one-reduction multiplier under it (ff.cuh fe_mul2, also the
+// lane-pair Fp2 product of fp2pair.cuh).  The curve and field code is __host__ __device__: this program compiles it for
+// the host and compares
 //   * fe_mul2 / FpOps::mul2_sub_tail with the separate products (random operands, operands with every 30-bit limb set),
-//   * both overloads of xyzz_madd with xyzz_add (the general addition, which the experiment does not touch) on chains of
+//   * both overloads of xyzz_madd with xyzz_add (the general addition, which has no fused line) on chains of
 //     additions that include the doubling and the inverse cases,
-// as canonical affine coordinates.  Nothing here runs on a device; built and run by tests/test_round3_cpu.py.
+// as canonical affine coordinates.  Nothing here runs on a device (the device runs the same code in every G1 and large G2
+// multiexp of the parity suite); built and run by tests/test_round3_cpu.py.
 // Reference being restated by that code: src/multiexp.rs:39 (bucket += base).
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 
-#ifndef BH_FUSED_Y3
-#define BH_FUSED_Y3 1   // this program IS the experiment's check: the switches are on whatever the command line says
-#endif
-#ifndef BH_FUSED_Y3_G2
-#define BH_FUSED_Y3_G2 1
-#endif
 #include "../../bellman_amd/csrc/ec.cuh"
 
 using namespace bh;
@@ -97,7 +93,7 @@ static bool same_point2(const XYZZ<Fp2Ops> &a, const XYZZ<Fp2Ops> &b) {
   return memcmp(&x, &y, sizeof x) == 0;
 }
 static int check_g2() {
-  static_assert(fused_y3<Fp2Ops>::value, "the G2 experiment must be switched on in this translation unit");
+  static_assert(Fp2Ops::FUSED_Y3_TAIL, "the one-lane G2 accumulation takes the fused line");
   int bad = 0;
   for (int it = 0; it < 2000; it++) {
     fp2_t a, b, c, d, ab, cd, dif, g;
@@ -156,7 +152,7 @@ static int check_g2() {
 }
 
 int main() {
-  static_assert(fused_y3<FpOps>::value, "the experiment must be switched on in this translation unit");
+  static_assert(FpOps::FUSED_Y3_TAIL && FpOps::FUSED_Y3, "G1 takes the fused line in both overloads");
   int bad = check_g2();
   // ---- 1. the multiplier ----------------------------------------------------------------------------------------------
   fp_t allones, top;   // every 30-bit limb of the operand (and of its pre-shifted form) set

@@ -119,6 +119,34 @@ def test_g2_k3_group_law(worker):
     assert not outs[0][3].any() and not outs[0][4].any()
 
 
+def test_g2_lane_pair_group_law(worker):
+    """The lane-pair form of Fp2 the large G2 accumulations compute in (csrc/fp2pair.cuh: schoolbook products with one
+    reduction per lane, operands exchanged by DPP): the same cases as the lane-triple test above.  70 points: more than
+    two wavefronts of 32 pairs, and a ragged tail."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 70
+    A = cref.gen_bases(2, n, a=9, b=13)
+    B = cref.gen_bases(2, n, a=17, b=5)
+    B[0] = A[0]                                   # doubling through the addition paths
+    B[1] = 0                                      # + identity
+    A[2] = 0                                      # identity +
+    B[3] = cref.point_mul(2, A[3], Q - 1)         # P + (-P)
+    A[4] = 0
+    B[4] = 0
+    B[n - 1] = A[n - 1]
+    dA, dB = _dev(worker, A), _dev(worker, B)
+    outs = [np.zeros((n, 24), dtype=np.uint64) for _ in range(3)]
+    assert lib.bh_test_g2_pairs_dev(worker.ctx, _p(outs[0]), _p(outs[1]), _p(outs[2]), dA, dB, n) == 0
+    want_add = np.stack([cref.point_add(2, A[i], B[i]) for i in range(n)])
+    want_dbl = np.stack([cref.point_add(2, A[i], A[i]) for i in range(n)])
+    assert np.array_equal(outs[0], want_add)
+    assert np.array_equal(outs[1], want_add)      # mixed addition: same sums (identity B leaves A)
+    assert np.array_equal(outs[2], want_dbl)
+    assert not outs[0][3].any() and not outs[0][4].any()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 8])
 @pytest.mark.parametrize("group", [1, 2])
 def test_msm_tiny_host_path_matches_pipeline(worker, group, n):
@@ -175,7 +203,8 @@ def test_msm_tiny_host_path_matches_pipeline(worker, group, n):
 
 @pytest.mark.parametrize("n", [257, 5000])
 def test_msm_g2_single_lane_kernels_still_agree(worker, n):
-    """BH_MSM_G2_SINGLE_LANE: the one-lane-per-point G2 kernels (kept for comparison) == the default K3 kernels."""
+    """BH_MSM_G2_SINGLE_LANE / _LANE_PAIRS: the one-lane-per-point G2 kernels and the lane-pair accumulation (the default
+    of large jobs) == the default K3 kernels of small jobs."""
     import bellman_amd
     from bellman_amd.multiexp import NO_TABLE
 
@@ -184,7 +213,8 @@ def test_msm_g2_single_lane_kernels_still_agree(worker, n):
     hb = bellman_amd.Bases(worker, 2, bases)
     rc, want = cref.multiexp(2, bases, 0, None, sc)
     assert rc == 0
-    for flags in (0, 16, 32, NO_TABLE, 16 | NO_TABLE, 32 | NO_TABLE):   # 16: one lane per point, 32: lane triples
+    # 16: one lane per point, 32: lane triples, 256: lane pairs accumulate (merge + reduction as the other flag says)
+    for flags in (0, 16, 32, NO_TABLE, 16 | NO_TABLE, 32 | NO_TABLE, 256, 256 | NO_TABLE, 256 | 16, 256 | 16 | NO_TABLE):
         assert np.array_equal(bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=flags).wait(), want), flags
 
 

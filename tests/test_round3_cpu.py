@@ -113,12 +113,12 @@ def test_prover_rs_patch_and_shim_are_consistent():
     assert not re.search(r"#\[cfg\([^\n]*\)\]\n\+?\s*if ", added)
 
 
-def test_fused_y3_experiment_host_check(tmp_path):
-    """The EXPERIMENTAL fused last line of the mixed addition (-DBH_FUSED_Y3: R*(Q - X3) - Y1*PPP as two products under
-    one Montgomery reduction, ff.cuh fe_mul2) is off in the shipped build and has never run on a device; the curve and
-    field code is __host__ __device__, so the formula and the multiplier are checked here on the host with the switch
-    ON (tests/cpp/fused_y3_check.hip) - against the separate products and against the general addition, incl. operands
-    with every limb set, the doubling and the inverse case (src/multiexp.rs:39)."""
+def test_fused_y3_host_check(tmp_path):
+    """The fused last line of the mixed addition (R*(Q - X3) - Y1*PPP as two products under one Montgomery reduction,
+    ff.cuh fe_mul2; the default since round 4, profiles/r4_call1_fused_y3.txt): the curve and field code is
+    __host__ __device__, so the formula and the multiplier are also checked on the host (tests/cpp/fused_y3_check.hip) -
+    against the separate products and against the general addition, incl. operands with every limb set, the doubling
+    and the inverse case (src/multiexp.rs:39)."""
     import shutil
     import subprocess
 
@@ -131,9 +131,9 @@ def test_fused_y3_experiment_host_check(tmp_path):
                    capture_output=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "fused Y3: ok" in out.stdout, out.stdout + out.stderr
-    # ... and the product build does not switch it on
-    mk = open(os.path.join(ROOT, "bellman_amd", "csrc", "Makefile")).read()
-    assert "BH_FUSED_Y3" not in mk and "BH_FUSED_Y3" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    # ... and no build switch is left around it
+    for f in ("ff.cuh", "ec.cuh", "Makefile"):
+        assert "BH_FUSED" not in open(os.path.join(ROOT, "bellman_amd", "csrc", f)).read(), f
 
 
 @pytest.mark.parametrize("kind,size,table", [(0, 322, 9), (0, 4000, 9), (1, 1000, 2001), (1, (1 << 16) - 3, 131067)])

@@ -62,6 +62,9 @@ def run_msm(args):
           (group, log_n, c, k, walls[len(walls) // 2], walls[0], *best), flush=True)
 
 
+SUITE_FLAGS = int(os.environ.get("BH_SUITE_FLAGS", "0"), 0)   # bh_msm_opts.flags for `sizes` (A/B of kernel bundles)
+
+
 def run_sizes(args):
     group, lo, hi = int(args[0]), int(args[1]), int(args[2])
     lib = _lib.load()
@@ -77,7 +80,8 @@ def run_sizes(args):
         best, walls = None, []
         for it in range(7):
             t0 = time.perf_counter()
-            r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True).wait()
+            r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
+                                         flags=SUITE_FLAGS).wait()
             walls.append((time.perf_counter() - t0) * 1e3)
             if it and (best is None or ms[0] < best[0]):
                 best = ms
