@@ -179,8 +179,6 @@ int main() {
       fpl_sub(dif, ab, cd);
       FpOps::mul2_sub_tail(g, a, b, c, d);
       if (!same(g, dif) || !below_2p(g)) { if (bad++ < 5) printf("mul2_sub_tail mismatch at %d\n", it); }
-      const fp_t h = fp_mul2_sub_call(a, b, c, d);
-      if (memcmp(&h, &g, sizeof h) != 0) { if (bad++ < 5) printf("fp_mul2_sub_call differs at %d\n", it); }
     }
   }
   // ---- 2. the group law -----------------------------------------------------------------------------------------------

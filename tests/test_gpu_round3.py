@@ -527,3 +527,36 @@ def test_reductions_with_equal_and_opposite_partial_sums(worker, group):
             got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, flags=flags).wait()
             assert np.array_equal(got, want), (n, flags)
         hb.release()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_bucket_runs_of_every_length_class(worker, group):
+    """[r4] Bucket runs that straddle chunk boundaries are folded by the owner lane of the merge kernel (up to four
+    further chunks), by the wavefront-parallel merge (queued runs) or by the workgroup-parallel one (csrc/msm_ec.cuh).
+    Scalars drawn from a small set of values give every window a few dozen buckets whose runs are 1 ... 60 chunks long,
+    so with chunks of 8 / 16 / 32 entries every route and every kernel bundle (one lane, lane pairs, lane triples per G2
+    point) sees runs of every length class.  Against the restated multiexp (src/multiexp.rs:210-301).  (Written for the
+    round-4 experiment that folded runs inside the accumulation workgroup - measured slower, profiles/r4_call5_fold_ab.txt,
+    and removed - and kept because no other test forces these shapes.)"""
+    import random
+
+    import bellman_amd
+    from bellman_amd.multiexp import NO_TABLE, NO_SMALL_PATH
+
+    rnd = random.Random(4041)
+    n = 6000
+    bases = cref.gen_bases(group, n, a=11, b=29)
+    hb = bellman_amd.Bases(worker, group, bases)
+    for distinct in (3, 40, 700):
+        vals = [rnd.randrange(cref.Q) for _ in range(distinct)]
+        sc = cref.ints_to_arr([vals[min(int(rnd.expovariate(4.0 / distinct)), distinct - 1)] for _ in range(n)], 4)
+        rc, want = cref.multiexp(group, bases, 0, None, sc)
+        assert rc == 0
+        bundles = (0,) if group == 1 else (16, 32, 256, 256 | 16)
+        for chunk in (8, 16, 32):
+            for fl in bundles:
+                for c in (13, 16):
+                    got = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, window_bits=c, chunk=chunk,
+                                               flags=fl | NO_TABLE | NO_SMALL_PATH).wait()
+                    assert np.array_equal(got, want), (distinct, chunk, fl, c)
+    hb.release()

@@ -22,6 +22,9 @@ from bellman_amd import _lib  # noqa: E402
 from bench import G1_GEN_MONT, G2_GEN_MONT, splitmix_scalars  # noqa: E402
 
 
+SUITE_FLAGS = int(os.environ.get("BH_SUITE_FLAGS", "0"), 0)   # bh_msm_opts.flags for `msm` / `sizes` (A/B of kernel variants)
+
+
 def make_bases(w, lib, group, n):
     words = 12 if group == 1 else 24
     t = splitmix_scalars(n, 1)
@@ -51,7 +54,7 @@ def run_msm(args):
     for it in range(iters + 2):
         t0 = time.perf_counter()
         r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
-                                     window_bits=c, chunk=k).wait()
+                                     window_bits=c, chunk=k, flags=SUITE_FLAGS).wait()
         wall = (time.perf_counter() - t0) * 1e3
         if it >= 2:
             walls.append(wall)
@@ -60,9 +63,6 @@ def run_msm(args):
     walls.sort()
     print("G%d MSM 2^%d c=%d K=%d: wall median %.3f ms (min %.3f); device best total %.3f = sort %.3f + accumulate %.3f + reduce %.3f" %
           (group, log_n, c, k, walls[len(walls) // 2], walls[0], *best), flush=True)
-
-
-SUITE_FLAGS = int(os.environ.get("BH_SUITE_FLAGS", "0"), 0)   # bh_msm_opts.flags for `sizes` (A/B of kernel bundles)
 
 
 def run_sizes(args):
@@ -88,6 +88,40 @@ def run_sizes(args):
         walls = sorted(walls[1:])
         print("G%d log_n=%d  wall median %.3f ms  device total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" %
               (group, log_n, walls[len(walls) // 2], *best), flush=True)
+
+
+def run_sweep(args):
+    """sweep <group> <log_n> <c> <K list> <flags list> [reps]: every (K, flags) combination in ONE process, `reps` times
+    round-robin, so that variants are compared on the same box under the same conditions."""
+    group, log_n, c = int(args[0]), int(args[1]), int(args[2])
+    ks = [int(x) for x in args[3].split(",")]
+    fls = [int(x, 0) for x in args[4].split(",")]
+    reps = int(args[5]) if len(args) > 5 else 2
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    n = 1 << log_n
+    dout = make_bases(w, lib, group, n)
+    bases = bellman_amd.Bases.copy_device(w, group, dout, n)
+    s = splitmix_scalars(n, 2)
+    ds = w.alloc(n * 32)
+    w.upload(ds, s)
+    res = {}
+    for rep in range(reps):
+        for k in ks:
+            for fl in fls:
+                best, walls = None, []
+                for it in range(6):
+                    t0 = time.perf_counter()
+                    r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True,
+                                                 window_bits=c, chunk=k, flags=fl).wait()
+                    walls.append((time.perf_counter() - t0) * 1e3)
+                    if it and (best is None or ms[0] < best[0]):
+                        best = ms
+                res.setdefault((k, fl), []).append((sorted(walls[1:])[2], best))
+    for (k, fl), v in res.items():
+        for wall, best in v:
+            print("G%d 2^%d c=%d K=%3d flags=%4d: wall median %.3f ms; device best total %.3f = sort %.3f + accumulate %.3f + reduce %.3f" %
+                  (group, log_n, c, k, fl, wall, *best), flush=True)
 
 
 def run_fft(args):
@@ -181,4 +215,4 @@ def run_proof(args):
 
 
 if __name__ == "__main__":
-    {"msm": run_msm, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes, "proof": run_proof}[sys.argv[1]](sys.argv[2:])
+    {"msm": run_msm, "sweep": run_sweep, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes, "proof": run_proof}[sys.argv[1]](sys.argv[2:])
