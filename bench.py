@@ -579,9 +579,11 @@ def main():
     s_dev = torch.from_numpy(s_host.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
+    ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (tools/gpu_r4_*.sh)
+
     def step():
         w = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s_dev.data_ptr()),
-                                 n=n, timed=True)
+                                 n=n, timed=True, flags=ab_flags)
         part, ms = w.wait()
         if collective:   # one 96-byte all-gather over RCCL + local fold (bellman_amd/sharding.py)
             return sharding.fold_partials(part, 1, device=coll_dev if coll_dev == "cuda" else None), ms
@@ -619,7 +621,7 @@ def main():
     # latency-bound reduction of one MSM overlaps the bucket accumulation of the next
     def issue():
         return bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None,
-                                    scalars_dev=ctypes.c_void_p(s_dev.data_ptr()), n=n, timed=True)
+                                    scalars_dev=ctypes.c_void_p(s_dev.data_ptr()), n=n, timed=True, flags=ab_flags)
 
     pipelined_value = pcie_value = None
     extras = not args.timed_steps_only

@@ -209,9 +209,9 @@ def run_proof(args):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(one, range(threads * 3)))
     conc = threads * 3 / (time.perf_counter() - t0)
-    print("create_proof 2^%d (R1CS resident) REDUCE_PRIORITY=%s: wall median %.2f ms (min %.2f); host ms [witness %.2f, issue+h %.2f, "
+    print("create_proof 2^%d (R1CS resident): wall median %.2f ms (min %.2f); host ms [witness %.2f, issue+h %.2f, "
           "h multiexp + waits %.2f, total %.2f]; %d threads: %.2f proofs/s" %
-          (log_n, os.environ.get("BELLMAN_HIP_REDUCE_PRIORITY", "0"), walls[len(walls) // 2], walls[0], *med, threads, conc), flush=True)
+          (log_n, walls[len(walls) // 2], walls[0], *med, threads, conc), flush=True)
 
 
 if __name__ == "__main__":
