@@ -10,11 +10,16 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BELLMAN_HIP_LIB: another build of the SAME library (A/B runs of a kernel experiment against the shipped build,
-# tools/gpu_r4_fused_y3.sh); never a different implementation - there is no fallback of any kind
-LIB_PATH = os.environ.get("BELLMAN_HIP_LIB") or os.path.join(_HERE, "lib", "libbellman_hip.so")
+# BELLMAN_HIP_LIB: another build of the SAME library (A/B runs of a kernel experiment against the shipped build, e.g.
+# tools/gpu_r4_call1.sh) - honoured only together with BELLMAN_HIP_ALLOW_LIB_OVERRIDE=1, so that a stray variable cannot
+# swap the library under the tests or the bench (bench.py prints bh_version() and the library's path and hash into its
+# JSON line).  Never a different implementation - there is no fallback of any kind.
+_OVERRIDE = os.environ.get("BELLMAN_HIP_LIB") if os.environ.get("BELLMAN_HIP_ALLOW_LIB_OVERRIDE") == "1" else None
+LIB_PATH = _OVERRIDE or os.path.join(_HERE, "lib", "libbellman_hip.so")
 
-# every symbol include/bellman_hip.h declares, then the test hooks of include/bellman_hip_test.h
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libbellman_hip_test.so")
+
+# every symbol include/bellman_hip.h declares (libbellman_hip.so exports exactly these) ...
 EXPORTS = [
     "bh_version", "bh_ctx_create", "bh_ctx_destroy", "bh_ctx_log_num_cus", "bh_runtime_configure", "bh_ctx_set_limits", "bh_ctx_info",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_dev_zero", "bh_stream_create", "bh_stream_create_priority", "bh_stream_destroy", "bh_stream_synchronize", "bh_dev_upload_on",
@@ -26,15 +31,29 @@ EXPORTS = [
     "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after", "bh_msm_start",
     "bh_msm_sharded_async", "bh_msm_sharded_wait",
     "bh_fixed_base_mul_dev",
-    "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment", "bh_groth16_prove_demo",
+    "bh_groth16_params_create", "bh_groth16_params_read", "bh_groth16_generate", "bh_groth16_params_write", "bh_groth16_params_vk_ext", "bh_groth16_params_query", "bh_groth16_params_vk", "bh_proof_write", "bh_groth16_params_release", "bh_groth16_prove_assignment",
     "bh_r1cs_create", "bh_r1cs_release", "bh_r1cs_shape", "bh_r1cs_density", "bh_r1cs_eval_dev", "bh_r1cs_eval_transposed_dev", "bh_fr_powers_dev", "bh_fr_qap_ext_dev",
-    "bh_groth16_prove_witness", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs",
-    "bh_groth16_prove_demo_async", "bh_groth16_proof_wait",
-    "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble", "bh_groth16_prove_demo_r1cs_part",
+    "bh_groth16_prove_witness", "bh_groth16_prove_assignment_async", "bh_groth16_prove_witness_async", "bh_groth16_proof_wait",
+    "bh_groth16_prove_witness_part", "bh_groth16_sums_add", "bh_groth16_assemble",
+]
+# ... and what include/bellman_hip_test.h declares: test hooks and the built-in demo circuits, in libbellman_hip_test.so
+TEST_EXPORTS = [
+    "bh_groth16_prove_demo", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs", "bh_groth16_prove_demo_async", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev", "bh_test_msm_stages",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host",
     "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
+
+
+def library_identity():
+    """What was loaded: bh_version(), the path, the first 16 hex digits of the file's sha256 (bench.py's JSON line)."""
+    import hashlib
+
+    lib = load()
+    with open(LIB_PATH, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"version": lib.bh_version().decode(), "path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "sha256_16": digest,
+            "override": bool(_OVERRIDE)}
 
 
 def build(jobs=8):
@@ -43,6 +62,22 @@ def build(jobs=8):
 
 
 _lib = None
+
+
+class _Libs:
+    """The product library, with the test library behind it: an attribute that libbellman_hip.so does not export (a test
+    hook, a demo-circuit entry point) resolves in libbellman_hip_test.so, which links against the product library."""
+
+    def __init__(self, product, test):
+        self.product, self.test = product, test
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self.product, name)
+        except AttributeError:
+            if self.test is None:
+                raise
+            return getattr(self.test, name)
 
 
 def load():
@@ -57,7 +92,8 @@ def load():
     # more hardware queues than the runtime's 4: a proof runs 6-7 job streams at once (see api.hip); must be in the
     # environment before the process' first HIP call
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    lib = ctypes.CDLL(LIB_PATH)
+    product = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = _Libs(product, ctypes.CDLL(TEST_LIB_PATH) if os.path.exists(TEST_LIB_PATH) else None)
     lib.bh_runtime_configure()   # records that the request was made before this library's first HIP call
     c = ctypes
     vp, sz, u32, i32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_int
@@ -173,6 +209,8 @@ def load():
     lib.bh_groth16_prove_demo_r1cs.argtypes = [vp, vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.bh_groth16_prove_demo_async.argtypes = [vp, vp, i32, sz, c.c_uint64, vp, vp, vp, vp, c.POINTER(vp)]
     lib.bh_groth16_proof_wait.argtypes = [vp, vp, vp]
+    lib.bh_groth16_prove_assignment_async.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, c.POINTER(vp)]
+    lib.bh_groth16_prove_witness_async.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, c.POINTER(vp)]
     lib.bh_groth16_prove_witness_part.argtypes = [vp, vp, vp, sz, vp, sz, sz, sz, vp, vp]
     lib.bh_groth16_sums_add.argtypes = [vp, vp]
     lib.bh_groth16_sums_add.restype = None

@@ -6,9 +6,10 @@
 #include <memory>
 #include <thread>
 
-#include "../../include/bellman_hip_test.h"
+#include "../../include/bellman_hip.h"
 #include "common.hpp"
 #include "msm_types.hpp"
+#include "shard_cuts.hpp"
 
 namespace bh {
 // fft.hip
@@ -38,16 +39,9 @@ void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
                    hipStream_t st);
-int test_point_add(int group, void *r, const void *a, const void *b, u64 n, hipStream_t st);
-int test_fr_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
-int test_fp_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st);
 void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
-int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
-                    u32 *zstart_out);
 void host_point_mul(int group, void *r, const void *a, const void *k);
 void host_point_lincomb(int group, void *r, const void *pts, const void *scalars, u64 n);
-void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n);
-void devhdr_point_mul(int group, void *r, const void *a, const void *k);
 
 // packs strided host records (optionally with an `infinity` flag byte) into dense device records
 __global__ void pack_bases_kernel(const unsigned char *raw, size_t stride, long inf_offset, u32 rec_words,
@@ -147,6 +141,7 @@ struct bh_scalars {
 };
 struct bh_msm_job {
   MsmJobImpl *impl;
+  MsmJobImpl *second = nullptr;   // a multiexp over host scalars issued as two halves (msm_split_host): the upper half
 };
 
 // hipMalloc'ed block freed on scope exit unless released: the BH_HIP_CHECK early returns of the register /
@@ -235,7 +230,7 @@ static inline hipStream_t pick_stream(bh_ctx *ctx, void *stream) { return stream
 
 extern "C" {
 
-const char *bh_version(void) { return "bellman_hip 0.1 (gfx950)"; }
+const char *bh_version(void) { return "bellman_hip 0.4 (gfx950, built " __DATE__ " " __TIME__ ")"; }
 
 // A proof keeps 6-7 job streams in flight (one per multiexp + the h block); the HIP runtime multiplexes streams onto
 // GPU_MAX_HW_QUEUES hardware queues, 4 by default, and jobs that share a queue run one after the other (MiMC-322
@@ -327,15 +322,20 @@ int bh_ctx_trim(bh_ctx *ctx) {
   ctx->c.pool.release_all();
   {
     // window tables built automatically at registration are a cache too (the handles stay usable without them;
-    // bh_bases_precompute rebuilds one on request)
+    // bh_bases_precompute rebuilds one on request) - unless a multiexp is still in flight: a job issued with BH_MSM_HOLD
+    // and not yet started has captured its table pointer but enqueued nothing the device synchronise above could have
+    // waited for, so the tables stay until a trim finds the context idle
     std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    if (ctx->c.inflight.empty() && ctx->c.issuing == 0)
     for (bh_bases *b : ctx->c.tables) {
       if (b->table) (void)hipFree(b->table);
       b->table = nullptr;
       b->auto_table = false;
     }
-    ctx->c.tables.clear();
-    ctx->c.table_bytes = 0;
+    if (ctx->c.inflight.empty() && ctx->c.issuing == 0) {
+      ctx->c.tables.clear();
+      ctx->c.table_bytes = 0;
+    }
   }
   {
     std::lock_guard<std::mutex> g(ctx->c.fft_mu);
@@ -872,7 +872,47 @@ static bool tiny_msm_on_host(const bh_bases *bases, size_t skip, const void *sca
 
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0, void *after_stream = nullptr) {
+                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0, void *after_stream = nullptr);
+// [r4] A large multiexp over HOST scalars (what a Rust host with only multiexp.rs patched issues, 32 MiB per call at
+// 2^20 terms) spent 0.7 ms of PCIe time before its first kernel could start - the copy from pageable memory blocks the
+// issuing thread, and nothing of the pipeline before the sort can use partial data.  It is therefore issued as TWO
+// multiexps over the lower and the upper half of the exponents (the same bases handle, the second one skipping the
+// bases the first half consumes): the second half's copy runs while the first half sorts and accumulates, and the first
+// half's latency-bound reduction runs beside the second half's accumulation.  The two results are added on the host at
+// the wait, with the error precedence of ONE multiexp (src/multiexp.rs:295-300): a half reports whether an identity
+// base was consumed in the reference's top window (window size of the whole length) before its first EOF entry; if
+// the lower half ran out of bases its verdict stands (everything in the upper half comes later), otherwise an identity
+// in the top window of either half wins over the upper half's EOF.
+constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 19;
+static int msm_split_host(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, size_t n, int fmt,
+                          const uint64_t *density, const bh_msm_opts *o, bh_msm_job **out) {
+  const size_t m = ((n / 2) + 63) & ~(size_t)63;   // density words stay aligned
+  size_t dense_before = m;
+  if (density) {
+    dense_before = 0;
+    for (size_t w = 0; w < m / 64; w++) dense_before += (size_t)__builtin_popcountll(density[w]);
+  }
+  bh_msm_opts oo = {0, 0, 0};
+  if (o) oo = *o;
+  oo.flags |= BH_MSM_NO_SPLIT;
+  bh_msm_job *lo = nullptr, *hi = nullptr;
+  int rc = msm_common(ctx, bases, skip, scalars, true, m, fmt, density, true, density ? m : 0, &oo, &lo, n);
+  if (rc != BH_OK) return rc;
+  rc = msm_common(ctx, bases, skip + dense_before, (const char *)scalars + m * 32, true, n - m, fmt,
+                  density ? density + m / 64 : nullptr, true, density ? n - m : 0, &oo, &hi, n);
+  if (rc != BH_OK) {
+    unsigned char sink[192];
+    (void)bh_msm_wait(lo, sink);
+    return rc;
+  }
+  lo->second = hi->impl;
+  delete hi;
+  *out = lo;
+  return BH_OK;
+}
+static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
+                      size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
+                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n, void *after_stream) {
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
@@ -882,6 +922,10 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   }
   if (fmt != BH_SCALARS_CANONICAL && fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
   if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
+  static const bool split_on = [] { const char *e = getenv("BELLMAN_HIP_SPLIT_HOST_SCALARS"); return !(e && *e == '0'); }();
+  if (split_on && scalars_on_host && n >= MSM_SPLIT_MIN && !shard_ref_n && !after_stream && (!density || density_on_host) &&
+      !(opts.flags & (BH_MSM_NO_SPLIT | BH_MSM_HOLD | BH_MSM_STAGE_TIMES)))
+    return msm_split_host(ctx, bases, skip, scalars, n, fmt, density, o, out);
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   // back-pressure (src/multicore.rs:47-73): at the cap the issuing thread completes the oldest job itself
   while (!msm_slot_try_reserve(ctx->c))
@@ -1000,53 +1044,14 @@ struct bh_msm_sharded_job {
   std::vector<bh_msm_job *> jobs;                 // one per shard, in shard order
   std::vector<std::vector<uint64_t>> density;     // per-shard density words (re-based to bit 0), alive until the wait
 };
-// index of the t-th (0-based) set bit of an LSB0 bitmap of n bits; n when there are not that many
-static size_t select_bit(const uint64_t *words, size_t n, size_t t) {
-  const size_t nw = (n + 63) / 64;
-  for (size_t w = 0; w < nw; w++) {
-    uint64_t x = words[w];
-    if (w == nw - 1 && (n & 63)) x &= (((uint64_t)1 << (n & 63)) - 1);
-    const size_t pc = (size_t)__builtin_popcountll(x);
-    if (t < pc) {
-      for (;; x &= x - 1, t--)
-        if (t == 0) return w * 64 + (size_t)__builtin_ctzll(x);
-    }
-    t -= pc;
-  }
-  return n;
-}
-// scalar index at which shard k starts (cut[k]) and the shard's first base index (off[k]): shard k computes the
-// scalars [cut[k], cut[k+1]) - the dense entries whose base index skip + rank falls into [off[k], off[k+1]) plus the
-// non-dense entries between them; the last shard takes everything left (it is the one that can run out of bases)
-static void shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
-                       std::vector<size_t> &cut, std::vector<size_t> &off) {
-  cut.assign(n_shards + 1, 0);
-  off.assign(n_shards + 1, 0);
-  for (size_t k = 0; k < n_shards; k++) off[k + 1] = off[k] + lens[k];
-  for (size_t k = 1; k < n_shards; k++) {
-    if (off[k] <= skip) { cut[k] = 0; continue; }
-    const size_t t = off[k] - skip;   // dense entries that precede the shard
-    cut[k] = density_words ? select_bit(density_words, n_scalars, t) : (t < n_scalars ? t : n_scalars);
-  }
-  cut[n_shards] = n_scalars;
-}
-int bh_test_shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
-                       size_t *cuts_out) {
-  if (!lens || !n_shards || !cuts_out) return BH_ERR_INVALID_ARG;
-  std::vector<size_t> cut, off;
-  shard_cuts(lens, n_shards, skip, density_words, n_scalars, cut, off);
-  memcpy(cuts_out, cut.data(), (n_shards + 1) * sizeof(size_t));
-  return BH_OK;
-}
-size_t bh_test_pool_size_class(size_t bytes) { return DevicePool::size_class(bytes); }
 int bh_msm_sharded_async(bh_ctx *const *ctxs, const bh_bases *const *shards, size_t n_shards, size_t skip,
                          const void *scalars_host, size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
                          size_t density_len, bh_msm_sharded_job **out) {
   if (!ctxs || !shards || !n_shards || !out || (n_scalars && !scalars_host)) return BH_ERR_INVALID_ARG;
   if (density_words && density_len != n_scalars) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329
-  const int group = shards[0]->group;
   for (size_t k = 0; k < n_shards; k++)
-    if (!ctxs[k] || !shards[k] || shards[k]->group != group) return BH_ERR_INVALID_ARG;
+    if (!ctxs[k] || !shards[k] || shards[k]->group != shards[0]->group) return BH_ERR_INVALID_ARG;
+  const int group = shards[0]->group;
   std::vector<size_t> lens(n_shards);
   for (size_t k = 0; k < n_shards; k++) lens[k] = shards[k]->n;
   std::vector<size_t> cut, off;
@@ -1133,6 +1138,29 @@ int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;
   float ms[4] = {0, 0, 0, 0};
   int rc = msm_job_finish(*job->impl, out_affine, ms);
+  if (job->second) {   // the upper half of a multiexp over host scalars (msm_split_host)
+    MsmJobImpl *lo = job->impl, *hi = job->second;
+    alignas(16) unsigned char part[192];
+    const int rc_hi = msm_job_finish(*hi, part, nullptr);
+    const size_t rec = lo->group == BH_G1 ? 96 : 192;
+    if (rc < 0 && rc != BH_ERR_UNEXPECTED_EOF && rc != BH_ERR_UNEXPECTED_IDENTITY) {
+      // a HIP failure of the lower half stands
+    } else if (rc_hi < 0 && rc_hi != BH_ERR_UNEXPECTED_EOF && rc_hi != BH_ERR_UNEXPECTED_IDENTITY) {
+      rc = rc_hi;
+    } else if (lo->saw_eof) {
+      // every entry of the upper half comes after the lower half's first EOF entry: the lower half's verdict stands
+    } else {
+      const bool eof = hi->saw_eof, ident = lo->saw_ident || hi->saw_ident;
+      const bool ident_top = lo->saw_ident_top || hi->saw_ident_top;
+      // without an EOF of its own a half reports ident_top only if it resolved it (always_resolve_ident): msm_finish
+      if (eof && ident) rc = ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF;
+      else if (eof) rc = BH_ERR_UNEXPECTED_EOF;
+      else if (ident) rc = BH_ERR_UNEXPECTED_IDENTITY;
+      else { host_point_add(lo->group, out_affine, out_affine, part, 1); rc = BH_OK; }
+    }
+    if (rc != BH_OK) memset(out_affine, 0, rec);
+    msm_job_delete(hi);
+  }
   if (stage_ms4) memcpy(stage_ms4, ms, sizeof ms);
   msm_job_delete(job->impl);
   delete job;
@@ -1153,86 +1181,6 @@ int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host, 
   return fixed_base_mul(group, base_affine_host, scalars_dev, n, fmt, out_dev, pick_stream(ctx, stream));
 }
 
-// ---- test hooks ---------------------------------------------------------------------------------
-int bh_test_fr_mul_dev(bh_ctx *ctx, void *r, const void *a, const void *b, size_t n) {
-  int rc = test_fr_mul(r, a, b, n, ctx->c.stream);
-  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
-  return rc;
-}
-int bh_test_fp_mul_dev(bh_ctx *ctx, void *r, const void *a, const void *b, size_t n) {
-  int rc = test_fp_mul(r, a, b, n, ctx->c.stream);
-  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
-  return rc;
-}
-int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r, const void *a, const void *b, size_t n) {
-  int rc = test_point_add(group, r, a, b, n, ctx->c.stream);
-  if (rc == BH_OK) BH_HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
-  return rc;
-}
-int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
-                      const void *b_dev, size_t n) {
-  if (!ctx) return BH_ERR_INVALID_ARG;
-  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  return test_g2_k3(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
-}
-int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
-                         const void *b_dev, size_t n) {
-  if (!ctx) return BH_ERR_INVALID_ARG;
-  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
-  return test_g2_pairs(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
-}
-int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *zstart_out_host) {
-  return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, zstart_out_host);
-}
-void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
-  for (size_t i = 0; i < n; i++) fe_mul(((fr_t *)r)[i], ((const fr_t *)a)[i], ((const fr_t *)b)[i]);
-}
-void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n) {
-  // the FFT's multiplier: second operand pre-sliced into 30-bit limbs (ff.cuh fe_to_bform / fe_mul_b)
-  for (size_t i = 0; i < n; i++) {
-    u32 B[9];
-    fe_to_bform<FrParams>(B, ((const fr_t *)b)[i]);
-    fe_mul_b<FrParams>(((fr_t *)r)[i], ((const fr_t *)a)[i], B);
-  }
-}
-void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
-  for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
-}
-int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9) {
-  // host only: the plan make_plan picks - out9 = c, W, buckets per window, K, chunks per window, sort passes,
-  // lo_bits, hi_bits, pairs (W*n) low 32 bits
-  if (!out9 || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
-  const MsmPlan p = make_plan(n, forced_c, 0, group == BH_G2);
-  out9[0] = p.c; out9[1] = p.W; out9[2] = p.nb; out9[3] = p.chunk; out9[4] = p.chunks_per_window; out9[5] = p.sort_passes;
-  out9[6] = p.lo_bits; out9[7] = p.hi_bits; out9[8] = (unsigned)((u64)p.W * p.n);
-  return BH_OK;
-}
-int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b) {
-  // the lazily reduced Fp helpers of the curve code (ff.cuh), compiled for the host; operands in [0, 2p)
-  fp_t x, y, z;
-  memcpy(&x, a, sizeof x);
-  if (b) memcpy(&y, b, sizeof y); else fe_zero(y);
-  int flag = 0;
-  switch (op) {
-    case 0: fpl_add(z, x, y); break;
-    case 1: fpl_sub(z, x, y); break;
-    case 2: fpl_neg(z, x); break;
-    case 3: fpl_canon(z, x); break;
-    case 4: z = x; flag = fpl_is_zero(x) ? 1 : 0; break;
-    case 5: z = fp_mul_call(x, y); break;   // lazily reduced Montgomery product
-    case 6: z = fp_sqr_call(x); break;
-    case 7: z = x; flag = fpl_eq(x, y) ? 1 : 0; break;
-    default: return BH_ERR_INVALID_ARG;
-  }
-  memcpy(r, &z, sizeof z);
-  return flag;
-}
-void bh_test_fr_inv_host(void *r, const void *a, size_t n) {
-  for (size_t i = 0; i < n; i++) fe_inv(((fr_t *)r)[i], ((const fr_t *)a)[i]);
-}
-void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n) { devhdr_point_add(group, r, a, b, n); }
-void bh_test_point_mul_host(int group, void *r, const void *a, const void *k) { devhdr_point_mul(group, r, a, k); }
 void bh_point_mul(int group, void *r, const void *a, const void *k_canonical) { host_point_mul(group, r, a, k_canonical); }
 void bh_point_lincomb(int group, void *r, const void *points, const void *scalars_canonical, size_t n) {
   host_point_lincomb(group, r, points, scalars_canonical, n);

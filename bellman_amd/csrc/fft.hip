@@ -25,6 +25,16 @@
 //     about 2^(log_n/2) entries);
 //   * every table entry is stored PRE-SLICED for the multiplier ("B form": the nine 30-bit limbs of w << 14,
 //     ff.cuh), which removes the operand re-slicing of one side of every product.
+// [r4] * from 2^12 to 2^24 points the inter-pass twiddles, the coset factors 7^i and 7^-i are ONE-level tables laid out in
+//     the order the kernel consumes them (element order: the entry of element g sits at index g, read coalesced beside
+//     the data) - one product per element instead of the two of the hi x lo tables; the 1/n of the inverse transforms
+//     is folded into the inverse twiddle table, so ifft has no scaling product at all.  48 B per element and table
+//     (0.2 GB at 2^22) bought 1-2 of the 11-13 products per element; traffic per pass goes from 64 to 112 B per
+//     element where a table is read, still far from the bound.
+//   * butterflies compute LAZILY REDUCED in [0, 2q): every product is data x (canonical) table entry, whose Montgomery
+//     result is < 1.91 q without the final conditional subtraction; additions / subtractions correct by +-2q (the sum
+//     of two such values needs bit 256: the carry out of the eight words decides with the borrow).  The last pass
+//     makes its outputs canonical, so what the caller sees is bit-identical to the reference's field elements.
 // Non-last passes read and write the same positions (pass 0 moves the data into a scratch vector); the last
 // pass scatters the digit-reversed result to natural order back into the caller's vector.  Workgroup -> tile
 // assignment is XCD-aware: tiles that share 128-byte lines (the narrow tiles of the 2^21 / 2^22 plans) go to the
@@ -52,6 +62,9 @@ struct NttPass {
   const BTw *post_lo;  // last pass: multiply output element k likewise (null: none)
   const BTw *post_hi;
   const BTw *post_const;   // ... or by this single entry (1/n of ifft; null: none)
+  // one-level tables in element order (null: the two-level tables above): entry g belongs to the element at index g of
+  // the vector this pass reads (pre1) / writes (tw1: inter-pass twiddle of a non-last pass; post1: last pass)
+  const BTw *pre1, *tw1, *post1;
   u32 lb;             // low bits of the two-level tables
   u32 log_n;
   u32 s;              // bits consumed by earlier passes
@@ -76,6 +89,37 @@ __device__ __forceinline__ void st_fr(fr_t *p, const fr_t &v) {
   uint4 *q = reinterpret_cast<uint4 *>(p);
   q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// ---- lazily reduced Fr: values in [0, 2q) (2q < 2^256) -----------------------------------------------------------
+__device__ __forceinline__ constexpr u32 fr_mod2(int i) {   // limb i of 2q
+  return (FrParams::mod(i) << 1) | (i ? FrParams::mod(i - 1) >> 31 : 0u);
+}
+__device__ __forceinline__ void frl_add(fr_t &r, const fr_t &a, const fr_t &b) {   // a + b < 4q: bit 256 is the carry
+  u32 t[8], d[8];
+  u32 c = 0, br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = addc(a.l[i], b.l[i], c, c);
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = subb(t[i], fr_mod2(i), br, br);
+  const bool ge = c || !br;   // the 257-bit sum is >= 2q
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = ge ? d[i] : t[i];
+}
+__device__ __forceinline__ void frl_sub(fr_t &r, const fr_t &a, const fr_t &b) {
+  u32 t[8];
+  u32 br = 0, c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = subb(a.l[i], b.l[i], br, br);
+  const u32 mask = 0u - br;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = addc(t[i], fr_mod2(i) & mask, c, c);
+}
+__device__ __forceinline__ void frl_canon(fr_t &r) {   // [0, 2q) -> [0, q)
+  u32 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = r.l[i];
+  fe_reduce_once<FrParams>(r, t);
 }
 
 // ---- the multiplier with a pre-sliced second operand ---------------------------------------------------------
@@ -103,7 +147,7 @@ __device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1,
   a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
   a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
   const u32 B[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2};
-  fe_mul_b<FrParams>(r, a, B);
+  fe_mul_b<FrParams, false>(r, a, B);   // lazily reduced: < 1.91 q for a < 2q and a canonical entry
   u32x20 o;
   o[0] = r.l[0]; o[1] = r.l[1]; o[2] = r.l[2]; o[3] = r.l[3]; o[4] = r.l[4]; o[5] = r.l[5]; o[6] = r.l[6]; o[7] = r.l[7];
   o[8] = n.a.x; o[9] = n.a.y; o[10] = n.a.z; o[11] = n.a.w; o[12] = n.b.x; o[13] = n.b.y; o[14] = n.b.z; o[15] = n.b.w;
@@ -182,8 +226,8 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
           mul_tw(y, cur, nx >= 0 ? tw_at(nx >> 8, nx & 255) : master);
         }
         fr_t u, v;
-        fe_add(u, e[t], y);
-        fe_sub(v, e[t], y);
+        frl_add(u, e[t], y);
+        frl_sub(v, e[t], y);
         e[t] = u;
         e[t + (1 << j)] = v;
       }
@@ -193,7 +237,7 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
   }
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
+__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
   __shared__ uint4 plane0[NTT_PLANE];
   __shared__ uint4 plane1[NTT_PLANE];
   const u32 R = 1u << a.r, C = 1u << a.log_c;
@@ -262,7 +306,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
       slot[i] = (col << a.r) + rrow;
       if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
-    if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
+    if (a.pre1) {   // one product per element; the entries form the same chain of loads as the two-level products
+      TwReg cur = tw_load(a.pre1 + gi[0]);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        if (tid + (u32)i * NTT_THREADS < total)
+          mul_tw(v[i], cur, (i + 1 < PER && tid + (u32)(i + 1) * NTT_THREADS < total) ? a.pre1 + gi[i + 1] : a.pre1);
+      }
+    } else if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
       const BTw *ph[PER], *pl[PER];
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -321,7 +372,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
       ph[i] = hi_tab ? hi_tab + (ex >> a.lb) : nullptr;   // no table: plain fft / the 1/n of ifft below
       pl[i] = lo_tab ? lo_tab + (ex & lb_mask) : nullptr;
     }
-    if (hi_tab) {
+    const BTw *one_level = !a.is_last ? a.tw1 : a.post1;
+    if (one_level) {
+      TwReg cur = tw_load(one_level + gi[0]);
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        if (tid + (u32)i * NTT_THREADS < total)
+          mul_tw(v[i], cur, (i + 1 < PER && tid + (u32)(i + 1) * NTT_THREADS < total) ? one_level + gi[i + 1] : one_level);
+      }
+    } else if (hi_tab) {
       TwReg cur = tw_load(ph[0]);
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -340,7 +399,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPass a) {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const u32 e = tid + (u32)i * NTT_THREADS;
-      if (e < total) st_fr(vout + gi[i], v[i]);
+      if (e < total) {
+        if (a.is_last) frl_canon(v[i]);   // what leaves the transform is the canonical field element
+        st_fr(vout + gi[i], v[i]);
+      }
     }
   }
 }
@@ -381,6 +443,26 @@ __global__ void gen_btw_kernel(BTw *out, u64 n, PowTable tab) {
     q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
     fe_mul(acc, acc, tab.p2[0]);
   }
+}
+
+// one-level inter-pass twiddle table of a non-last pass (s bits consumed before it, r radix bits): the element at index g
+// of the pass' vector sits at row j = (g >> logM) & (R - 1), column c = g & (M - 1) of its block (M = n >> (s + r)) and is
+// multiplied by scale * w^((c * j) << s mod n) when the pass stores it (ntt_pass_kernel's `ex`)
+__global__ void gen_tw1_kernel(BTw *out, u64 n, PowTable tab, u32 log_n, u32 s, u32 r) {
+  const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const u32 logM = log_n - s - r;
+  const u64 c = g & (((u64)1 << logM) - 1), j = (g >> logM) & (((u64)1 << r) - 1);
+  const u32 e = (u32)(((c * j) << s) & (n - 1));
+  fr_t acc = tab.scale;
+  for (int k = 0; k < 32; k++)
+    if ((e >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
+  BTw w;
+  fe_to_bform<FrParams>(w.l, acc);
+  uint4 *q = reinterpret_cast<uint4 *>(out + g);
+  q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+  q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+  q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
 }
 
 // ---- element-wise domain ops -----------------------------------------------------------------
@@ -483,7 +565,7 @@ static int make_btw_table(BTw **out, u64 count, const fr_t &g, const fr_t &scale
 
 void fft_tables_free(FftTables &t) {
   BTw **all[] = {&t.tw_lo[0], &t.tw_lo[1], &t.tw_hi[0], &t.tw_hi[1], &t.coset_lo, &t.coset_hi, &t.icoset_lo, &t.icoset_hi,
-                 &t.minv_dev};
+                 &t.minv_dev, &t.tw1[0][0], &t.tw1[0][1], &t.tw1[1][0], &t.tw1[1][1], &t.coset1, &t.icoset1};
   for (BTw **p : all) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -545,6 +627,50 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     if (rc) return fail(rc);
     t.init = true;
   }
+  // One-level tables in element order where they fit comfortably (n x 48 B each: 0.2 GB at 2^22, 0.8 GB at 2^24).  A
+  // failed allocation falls back to the two-level tables for this size for good (the decision is part of the cached
+  // state: the inverse twiddle table carries the 1/n, so the two kinds are never mixed within a size).
+  static const bool one_level_on = [] { const char *e = getenv("BELLMAN_HIP_FFT_ONE_LEVEL"); return !(e && *e == '0'); }();
+  uint32_t pr[3] = {0, 0, 0}, pL = 1;
+  plan_passes(log_n, pr, &pL);
+  bool one_level = one_level_on && log_n >= 12 && log_n <= 24 && !t.one_level_failed &&
+                   !(t.tw_lo[0] || t.tw_lo[1] || t.coset_lo || t.icoset_lo);
+  if (one_level) {
+    const size_t mark = fresh.size();
+    auto one_level_fail = [&]() {
+      (void)hipStreamSynchronize(st);
+      (void)hipGetLastError();
+      for (size_t i = mark; i < fresh.size(); i++) (void)hipFree(fresh[i]);
+      fresh.resize(mark);
+      t.one_level_failed = true;
+      one_level = false;
+    };
+    FftTables t1 = t;
+    bool ok = true;
+    if (need_tw && !t1.tw1[dir][0]) {
+      fr_t w = fr_domain_omega_host(log_n);
+      if (inverse) fe_inv(w, w);
+      uint32_t s_bits = 0;
+      for (uint32_t p = 0; p + 1 < pL && ok; p++) {
+        BTw *tab_p = nullptr;
+        ok = hipMalloc((void **)&tab_p, n * sizeof(BTw)) == hipSuccess;
+        if (!ok) break;
+        fresh.push_back(tab_p);
+        const PowTable pt = make_pow_table(w, (inverse && p == 0) ? t.minv : one);   // the 1/n of ifft / icoset_fft rides here
+        hipLaunchKernelGGL(gen_tw1_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, tab_p, n, pt, log_n, s_bits, pr[p]);
+        ok = hipGetLastError() == hipSuccess;
+        t1.tw1[dir][p] = tab_p;
+        s_bits += pr[p];
+      }
+    }
+    if (ok && need_coset && !t1.coset1) ok = make(&t1.coset1, n, fr_from_u64_host(7), one) == BH_OK;
+    if (ok && need_icoset && !t1.icoset1) {
+      fr_t ginv;
+      fe_inv(ginv, fr_from_u64_host(7));
+      ok = make(&t1.icoset1, n, ginv, one) == BH_OK;
+    }
+    if (ok) { t = t1; t.one_level = true; } else one_level_fail();
+  }
   const u64 n_lo = (u64)1 << t.lb, n_hi = (u64)1 << (log_n - t.lb);
   auto two_level = [&](BTw **lo, BTw **hi, const fr_t &base, const fr_t &scale) -> int {
     BTw *l = nullptr, *h = nullptr;
@@ -556,17 +682,17 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     *lo = l; *hi = h;   // a pair is set together or not at all
     return BH_OK;
   };
-  if (need_tw && !t.tw_lo[dir]) {
+  if (!one_level && need_tw && !t.tw_lo[dir]) {
     fr_t w = fr_domain_omega_host(log_n);
     if (inverse) fe_inv(w, w);
     int rc = two_level(&t.tw_lo[dir], &t.tw_hi[dir], w, one);
     if (rc) return fail(rc);
   }
-  if (need_coset && !t.coset_lo) {
+  if (!one_level && need_coset && !t.coset_lo) {
     int rc = two_level(&t.coset_lo, &t.coset_hi, fr_from_u64_host(7), one);   // MULTIPLICATIVE_GENERATOR
     if (rc) return fail(rc);
   }
-  if (need_icoset && !t.icoset_lo) {
+  if (!one_level && need_icoset && !t.icoset_lo) {
     fr_t ginv;
     fe_inv(ginv, fr_from_u64_host(7));
     int rc = two_level(&t.icoset_lo, &t.icoset_hi, ginv, t.minv);   // 7^-i / n
@@ -615,7 +741,11 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
     a.pre_hi = pre ? tab.coset_hi : nullptr;
     a.post_lo = post ? tab.icoset_lo : nullptr;
     a.post_hi = post ? tab.icoset_hi : nullptr;
-    a.post_const = (last && mode == BH_IFFT) ? tab.minv_dev : nullptr;
+    // one-level tables (L >= 2): the inverse twiddle table of pass 0 carries the 1/n, so ifft has no scaling product
+    a.tw1 = (tab.one_level && !last) ? tab.tw1[inverse ? 1 : 0][p] : nullptr;
+    a.pre1 = (tab.one_level && pre) ? tab.coset1 : nullptr;
+    a.post1 = (tab.one_level && post) ? tab.icoset1 : nullptr;
+    a.post_const = (last && mode == BH_IFFT && !tab.one_level) ? tab.minv_dev : nullptr;
     a.lb = tab.lb;
     a.log_n = log_n;
     a.s = s;

@@ -185,7 +185,9 @@ class DensityTracker {
 // nothing is stored, the object that travels through `|lc| lc + a + b` is 56 bytes instead of 230, and there is no
 // second pass.  Same values, same densities, same term order (profiles/r3_host_synthesis.txt).
 struct LcSink {
-  const Fr *inputs, *aux;                         // input_assignment / aux_assignment
+  // input_assignment / aux_assignment: the VECTORS, read per term - a closure that allocates a variable while it builds
+  // its combination (the reference's borrow rules forbid it, C++ does not) may reallocate them
+  const std::vector<Fr> *inputs, *aux;
   DensityTracker *input_density, *aux_density;    // either may be null (prover.rs:119-141)
   // set instead of the four fields above: every term is handed to `hook` as it is added (a ConstraintSystem that
   // records the structure of the circuit - the R1CS capture - takes the terms straight into its matrices)
@@ -210,24 +212,28 @@ class LinearCombination {
     if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
   }
   LinearCombination &operator=(const LinearCombination &o) {
+    if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
     if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
     return *this;
   }
   LinearCombination &operator=(LinearCombination &&o) noexcept {
+    if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
     if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
     return *this;
   }
-  // lvalue operands are copied (value semantics); a temporary is extended in place and handed on by reference
+  // lvalue operands are copied (value semantics); a temporary is extended in place and MOVED out - returned by value,
+  // so that `lc = std::move(lc) + x` is not a self-move and `auto &&r = zero() + a` does not dangle (moving an
+  // evaluating combination is a 56-byte copy)
   LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one()); return r; }
-  LinearCombination &&operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
+  LinearCombination operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
   LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
-  LinearCombination &&operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
+  LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
   LinearCombination operator+(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
-  LinearCombination &&operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
+  LinearCombination operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
   LinearCombination operator-(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
-  LinearCombination &&operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  LinearCombination operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
   size_t size() const { return n_; }
   // stored combinations only
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
@@ -243,10 +249,10 @@ class LinearCombination {
       if (sink_->hook) { sink_->hook(sink_->self, v, c); return; }
       const Fr *value;
       if (v.kind == Index::Input) {
-        value = sink_->inputs + v.idx;
+        value = sink_->inputs->data() + v.idx;
         if (sink_->input_density) sink_->input_density->inc(v.idx);
       } else {
-        value = sink_->aux + v.idx;
+        value = sink_->aux->data() + v.idx;
         if (sink_->aux_density) sink_->aux_density->inc(v.idx);
       }
       const Fr one = Fr::one();
@@ -461,6 +467,14 @@ struct AsyncProof {
 // ProvingAssignment with the input constraints of prover.rs:208-215) and starts the device part
 std::unique_ptr<AsyncProof> create_proof_async(bellman::Circuit &circuit, const R1cs *r1cs, Parameters &params, const Fr &r,
                                                const Fr &s);
+// [r4] the same split for a host that synthesised by itself (a C or Rust caller holding bellman's ProvingAssignment, or
+// just the witness when the constraint matrices are resident): the device part of prove_assignment / prove_witness on
+// a helper thread.  prove_assignment_async READS THE CALLER'S ARRAYS IN PLACE until wait() returns (five 32 MiB vectors
+// at 2^20 constraints: not copied); prove_witness_async copies the two witness vectors (they may be unaligned) before
+// it returns, so the caller may reuse its buffers for the next witness at once.
+std::unique_ptr<AsyncProof> prove_assignment_async(const AssignmentView &v, Parameters &params, const Fr &r, const Fr &s);
+std::unique_ptr<AsyncProof> prove_witness_async(const R1cs &r1cs, Parameters &params, const void *input_assignment, size_t n_inputs,
+                                                const void *aux_assignment, size_t n_aux, const Fr &r, const Fr &s);
 class ProofPipeline {
  public:
   ProofPipeline(Parameters &params, const R1cs *r1cs, size_t depth = 2) : params_(params), r1cs_(r1cs), depth_(depth ? depth : 1) {}

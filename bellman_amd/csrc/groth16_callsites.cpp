@@ -182,10 +182,6 @@ static Proof prove_via_call_sites(Parameters &params, const CallSiteInputs &in, 
 }
 }  // namespace groth16
 
-struct bh_params {
-  groth16::Parameters *p;
-};
-
 extern "C" int bh_test_groth16_prove_via_call_sites(bh_params *params, int mode, const void *a_evals, const void *b_evals,
                                                     const void *c_evals, size_t n_constraints, const void *input_assignment,
                                                     size_t n_inputs, const void *aux_assignment, size_t n_aux,

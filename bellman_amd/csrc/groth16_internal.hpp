@@ -4,6 +4,8 @@
 #include <stdlib.h>
 
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <stdexcept>
 
 #include "groth16.hpp"
@@ -41,3 +43,43 @@ inline double now_ms() {
 void proof_slice_for_tests(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);   // groth16_prover.cpp
 double capture_check_for_tests(bellman::Circuit &shape_of, bellman::Circuit &proved, size_t out4[4]);   // groth16_prover.cpp
 }  // namespace groth16
+
+// ---- pieces shared by the C entry points of the product (groth16_capi.cpp) and of the test library (demo_circuits.cpp)
+struct bh_params {
+  groth16::Parameters *p;
+};
+
+inline int run_guarded_sums(const std::function<groth16::MsmSums()> &f, void *sums_out) {
+  try {
+    groth16::MsmSums m = f();
+    memcpy(sums_out, &m, sizeof m);
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
+  } catch (...) { return BH_ERR_HIP; }
+}
+
+// a non-owning groth16::R1cs over a handle that belongs to the C caller
+struct R1csView {
+  groth16::R1cs r;
+  explicit R1csView(const bh_r1cs *h) : r(const_cast<bh_r1cs *>(h)) {}
+  ~R1csView() { r.handle = nullptr; }
+};
+
+inline int run_guarded(const std::function<groth16::Proof()> &f, void *proof_out) {
+  try {
+    groth16::Proof p = f();
+    memcpy(proof_out, &p.a, 96);
+    memcpy((char *)proof_out + 96, &p.b, 192);
+    memcpy((char *)proof_out + 288, &p.c, 96);
+    return BH_OK;
+  } catch (const bellman::SynthesisError &e) { return e.code;
+  } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
+  } catch (...) { return BH_ERR_HIP; }
+}
+
+struct bh_proof_job {
+  std::unique_ptr<groth16::AsyncProof> job;
+  std::unique_ptr<R1csView> view;
+  int early_rc = BH_OK;
+};

@@ -111,8 +111,11 @@ Variable ProvingAssignment::alloc_input(ValueFn f) {
 void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
   // inputs have full density in the A query; there is no C query (prover.rs:119-141).  The closures get combinations
   // that evaluate each term as it is added (groth16.hpp); a closure that returns some other, stored combination is
-  // evaluated the classic way.
-  const Fr *in = input_assignment.data(), *ax = aux_assignment.data();
+  // evaluated the classic way.  CONTRACT of the evaluating form (the reference's `eval` walks only the RETURNED
+  // combination, prover.rs:19-55): a closure returns a combination derived linearly from its argument - terms added to a
+  // copy that is then discarded would still count in the density maps.  Every closure of the reference's own circuits
+  // and gadgets has that shape (`|lc| lc + a + (c, b)`).
+  const std::vector<Fr> *in = &input_assignment, *ax = &aux_assignment;
   const LcSink sa{in, ax, nullptr, &a_aux_density}, sb{in, ax, &b_input_density, &b_aux_density}, sc{in, ax, nullptr, nullptr};
   auto run = [&](LcFn &f, const LcSink &sink) -> Fr {
     const LinearCombination r = f(LinearCombination::evaluating(&sink));
@@ -744,6 +747,46 @@ std::unique_ptr<AsyncProof> create_proof_async(Circuit &circuit, const R1cs *r1c
       j->timings = local;
       j->timings.synthesis_ms = synth_ms;
       j->timings.total_ms = local.total_ms + synth_ms;
+    } catch (...) {
+      j->error = std::current_exception();
+    }
+  });
+  return job;
+}
+std::unique_ptr<AsyncProof> prove_assignment_async(const AssignmentView &v, Parameters &params, const Fr &r, const Fr &s) {
+  std::unique_ptr<AsyncProof> job(new AsyncProof());
+  AsyncProof *j = job.get();
+  Parameters *pp = &params;
+  job->worker = std::thread([j, v, pp, r, s] {
+    try {
+      ProveTimings local = {0, 0, 0, 0};
+      j->proof = prove_assignment(v, *pp, r, s, &local);
+      j->timings = local;
+    } catch (...) {
+      j->error = std::current_exception();
+    }
+  });
+  return job;
+}
+std::unique_ptr<AsyncProof> prove_witness_async(const R1cs &r1cs, Parameters &params, const void *input_assignment, size_t n_inputs,
+                                                const void *aux_assignment, size_t n_aux, const Fr &r, const Fr &s) {
+  std::unique_ptr<AsyncProof> job(new AsyncProof());
+  job->witness = g_witnesses.get();
+  WitnessAssignment &w = *job->witness;
+  w.input_assignment.resize(n_inputs);
+  w.aux_assignment.resize(n_aux);
+  if (n_inputs) memcpy((void *)w.input_assignment.data(), input_assignment, n_inputs * sizeof(Fr));
+  if (n_aux) memcpy((void *)w.aux_assignment.data(), aux_assignment, n_aux * sizeof(Fr));
+  AsyncProof *j = job.get();
+  const R1cs *rp = &r1cs;
+  Parameters *pp = &params;
+  job->worker = std::thread([j, rp, pp, r, s] {
+    try {
+      ProveTimings local = {0, 0, 0, 0};
+      const WitnessAssignment &w = *j->witness;
+      j->proof = prove_witness(*rp, *pp, w.input_assignment.data(), w.input_assignment.size(), w.aux_assignment.data(),
+                               w.aux_assignment.size(), r, s, &local);
+      j->timings = local;
     } catch (...) {
       j->error = std::current_exception();
     }

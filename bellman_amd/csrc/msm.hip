@@ -33,15 +33,6 @@
 
 namespace bh {
 
-template <class P>
-__global__ void fe_mul_kernel(Fe<P> *r, const Fe<P> *a, const Fe<P> *b, u64 n) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fe<P> x = a[i], y = b[i], z;
-  fe_mul(z, x, y);
-  r[i] = z;
-}
-
 // ---- job management / dispatch (used by api.hip) ------------------------------------------------
 constexpr size_t JOB_PINNED_BYTES = 256 * 1024;   // >= W*c*sizeof(XYZZ<Fp2>) + flags for every plan
 
@@ -116,6 +107,10 @@ int window_table(int group, void *table_dev, u64 n, u32 c, u32 W, hipStream_t st
 // runs the group's finish (stream synchronise, error resolution, host tail) once; caller holds job.mu
 static void msm_job_complete_locked(MsmJobImpl &job) {
   if (job.done) return;
+  // whoever completes the job - its waiter, the wait of a sharded multiexp (one job per GPU), or another issuing thread
+  // under back-pressure - may have another device current: the (rare) error-resolution launch and its copy go to the
+  // job's stream and have to be issued with the job's device current
+  (void)hipSetDevice(job.ctx->device);
   job.done_rc = job.group == BH_G1 ? msm_finish_g1(job, job.done_out, job.done_ms) : msm_finish_g2(job, job.done_out, job.done_ms);
   job.done = true;
 }
@@ -195,23 +190,6 @@ int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u6
 int points_check(int group, const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {
   return group == BH_G1 ? points_check_g1(pts_dev, n, status_dev, st) : points_check_g2(pts_dev, n, status_dev, st);
 }
-int test_point_add(int group, void *r, const void *a, const void *b, u64 n, hipStream_t st) {
-  return group == BH_G1 ? test_point_add_g1(r, a, b, n, st) : test_point_add_g2(r, a, b, n, st);
-}
-int test_fr_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st) {
-  if (!n) return BH_OK;
-  hipLaunchKernelGGL(fe_mul_kernel<FrParams>, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (fr_t *)r,
-                     (const fr_t *)a, (const fr_t *)b, n);
-  BH_HIP_CHECK(hipGetLastError());
-  return BH_OK;
-}
-int test_fp_mul(void *r, const void *a, const void *b, u64 n, hipStream_t st) {
-  if (!n) return BH_OK;
-  hipLaunchKernelGGL(fe_mul_kernel<FpParams>, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (fp_t *)r,
-                     (const fp_t *)a, (const fp_t *)b, n);
-  BH_HIP_CHECK(hipGetLastError());
-  return BH_OK;
-}
 void host_point_add(int group, void *r, const void *a, const void *b, u64 n) {
   if (group == BH_G1) host_point_add_g1(r, a, b, n); else host_point_add_g2(r, a, b, n);
 }
@@ -221,11 +199,4 @@ void host_point_mul(int group, void *r, const void *a, const void *k) {
 void host_point_lincomb(int group, void *r, const void *pts, const void *scalars, u64 n) {
   if (group == BH_G1) host_point_lincomb_g1(r, pts, scalars, n); else host_point_lincomb_g2(r, pts, scalars, n);
 }
-void devhdr_point_add(int group, void *r, const void *a, const void *b, u64 n) {
-  if (group == BH_G1) devhdr_point_add_g1(r, a, b, n); else devhdr_point_add_g2(r, a, b, n);
-}
-void devhdr_point_mul(int group, void *r, const void *a, const void *k) {
-  if (group == BH_G1) devhdr_point_mul_g1(r, a, k); else devhdr_point_mul_g2(r, a, k);
-}
-
 }  // namespace bh

@@ -1408,9 +1408,6 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
   int points_check_##SUFFIX(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {                    \
     return points_check_t<OPS>(pts_dev, n, status_dev, st);                                                   \
   }                                                                                                           \
-  int test_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n, hipStream_t st) {                 \
-    return test_point_add_t<OPS>(r, a, b, n, st);                                                             \
-  }                                                                                                           \
   void host_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n) {                                \
     host_point_add_t<OPS>(r, a, b, n);                                                                        \
   }                                                                                                           \
@@ -1419,12 +1416,6 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
   }                                                                                                           \
   void host_point_lincomb_##SUFFIX(void *r, const void *pts, const void *scalars, u64 n) {                    \
     host_point_lincomb_t<OPS>(r, pts, (const u32 *)scalars, n);                                               \
-  }                                                                                                           \
-  void devhdr_point_add_##SUFFIX(void *r, const void *a, const void *b, u64 n) {                              \
-    devhdr_point_add_t<OPS>(r, a, b, n);                                                                      \
-  }                                                                                                           \
-  void devhdr_point_mul_##SUFFIX(void *r, const void *a, const void *k) {                                     \
-    devhdr_point_mul_t<OPS>(r, a, (const u32 *)k);                                                            \
   }
 
 }  // namespace bh

@@ -30,63 +30,3 @@ int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
 }
 BH_INSTANTIATE_MSM_SUPPORT(g2, Fp2Ops)
 }
-
-// ---- test hook: the group law in the multi-lane forms on its own (tests/test_gpu_parity.py::test_g2_k3_group_law,
-// test_g2_lane_pair_group_law) --------------------------------------------------------------------------------
-namespace bh {
-template <class F>
-__global__ __launch_bounds__(128) void lanes_group_law_kernel(XYZZ<Fp2Ops> *r_add, XYZZ<Fp2Ops> *r_madd, XYZZ<Fp2Ops> *r_dbl,
-                                                              const Affine<Fp2Ops> *a, const Affine<Fp2Ops> *b, u32 n) {
-  u32 in_block, i;
-  if (!worker_index<F>(default_per_wave<F>(), in_block, i) || i >= n) return;
-  Affine<F> pa, pb;
-  load_affine<F>(pa, a + i);
-  load_affine<F>(pb, b + i);
-  XYZZ<F> x, y, z;
-  xyzz_from_affine(x, pa);
-  xyzz_from_affine(y, pb);
-  xyzz_add(z, x, y);
-  store_xyzz<F>(&r_add[i], z);
-  z = x;
-  if (!aff_is_identity(pb)) xyzz_madd(z, pb);
-  store_xyzz<F>(&r_madd[i], z);
-  xyzz_dbl(z, x);
-  store_xyzz<F>(&r_dbl[i], z);
-}
-// out_*: n affine records each on the HOST (XYZZ results converted with the host arithmetic)
-template <class F>
-static int test_g2_lanes(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n) {
-  typedef XYZZ<Fp2Ops> Pt;
-  if (!n) return BH_OK;
-  Pt *d = (Pt *)c.pool.acquire(3 * n * sizeof(Pt));
-  if (!d) return BH_ERR_HIP;
-  const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
-  hipLaunchKernelGGL(lanes_group_law_kernel<F>, dim3((u32)((n + wpb - 1) / wpb)), dim3(128), 0, c.stream, d, d + n, d + 2 * n,
-                     (const Affine<Fp2Ops> *)a_dev, (const Affine<Fp2Ops> *)b_dev, (u32)n);
-  int rc = hipGetLastError() == hipSuccess ? BH_OK : BH_ERR_HIP;
-  std::vector<Pt> h(3 * n);
-  if (rc == BH_OK && hipMemcpyAsync(h.data(), d, 3 * n * sizeof(Pt), hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = BH_ERR_HIP;
-  if (hipStreamSynchronize(c.stream) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
-  c.pool.release(d);
-  if (rc != BH_OK) return rc;
-  typedef HostFp2Ops H;
-  void *outs[3] = {out_add, out_madd, out_dbl};
-  for (int k = 0; k < 3; k++)
-    for (u64 i = 0; i < n; i++) {
-      Pt q = h[k * n + i];
-      Fp2Ops::canon(q.x); Fp2Ops::canon(q.y); Fp2Ops::canon(q.zz); Fp2Ops::canon(q.zzz);   // lazily reduced on the device
-      XYZZ<H> hq;
-      memcpy(&hq, &q, sizeof hq);
-      Affine<H> aff;
-      xyzz_to_affine(aff, hq);
-      memcpy((char *)outs[k] + i * sizeof aff, &aff, sizeof aff);
-    }
-  return BH_OK;
-}
-int test_g2_k3(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n) {
-  return test_g2_lanes<Fp2K3Ops>(c, out_add, out_madd, out_dbl, a_dev, b_dev, n);
-}
-int test_g2_pairs(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n) {
-  return test_g2_lanes<Fp2PairOps>(c, out_add, out_madd, out_dbl, a_dev, b_dev, n);
-}
-}  // namespace bh

@@ -364,35 +364,4 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
   return BH_OK;
 }
 
-
-// bring-up aid: stages 1-3 only, results copied to the host (tests/test_gpu_parity.py)
-int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
-                    u32 *zstart_out) {
-  const MsmPlan p = make_plan(n, cbits, 0, false);
-  hipStream_t st = c.stream;
-  const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
-  MsmBuffers b;
-  std::vector<void *> owned;
-  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); owned.push_back(q); return q; };
-  void *sc = alloc(n * 32);
-  b.pairs_a = (u64 *)alloc(npairs * 8);
-  b.pairs_b = (u64 *)alloc(npairs * 8);
-  b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
-  b.zstart = (u32 *)alloc((u64)p.W * 4);
-  b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
-  b.word_prefix = nullptr;
-  int rc = BH_OK;
-  for (void *q : owned) if (!q) rc = BH_ERR_HIP;
-  const u64 *sorted = nullptr;
-  if (rc == BH_OK && hipMemcpyAsync(sc, scalars_host, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemsetAsync(b.err, 0, sizeof(ErrFlags), st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK) rc = msm_run_stages(p, b, sc, fmt, nullptr, 0, n, st, &sorted);
-  if (rc == BH_OK && hipMemcpyAsync(pairs_out, sorted, npairs * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemcpyAsync(zstart_out, b.zstart, (u64)p.W * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
-  for (void *q : owned) c.pool.release(q);
-  return rc;
-}
-
 }  // namespace bh

@@ -122,10 +122,6 @@ int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);   // ms: float[
 int msm_finish_g2(MsmJobImpl &job, void *out_affine, float *ms);
 int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
 int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
-int test_point_add_g1(void *r, const void *a, const void *b, u64 n, hipStream_t st);
-int test_point_add_g2(void *r, const void *a, const void *b, u64 n, hipStream_t st);
-int test_g2_k3(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n);   // msm_g2.hip
-int test_g2_pairs(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n);
 // per-point status word of the uncompressed-point loader (api.hip decode kernel + point_check_kernel)
 enum PointStatus : u32 {
   PT_COMPRESSED = 1,        // compression flag set on an uncompressed point
@@ -151,9 +147,5 @@ void host_point_mul_g1(void *r, const void *a, const void *k);
 void host_point_mul_g2(void *r, const void *a, const void *k);
 void host_point_lincomb_g1(void *r, const void *pts, const void *scalars, u64 n);
 void host_point_lincomb_g2(void *r, const void *pts, const void *scalars, u64 n);
-void devhdr_point_add_g1(void *r, const void *a, const void *b, u64 n);
-void devhdr_point_add_g2(void *r, const void *a, const void *b, u64 n);
-void devhdr_point_mul_g1(void *r, const void *a, const void *k);
-void devhdr_point_mul_g2(void *r, const void *a, const void *k);
 
 }  // namespace bh

@@ -650,3 +650,47 @@ def create_proof_demo_async(params, r1cs, kind, size, seed, witness, constants, 
         return Proof(out)
 
     return wait
+
+
+def _proof_waiter(lib, job, keep):
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+
+    def wait(timings=None):
+        _alive = keep  # noqa: F841  (the arrays the device part reads in place stay referenced until the wait)
+        out = np.zeros(48, dtype=np.uint64)
+        tm = (ctypes.c_float * 4)()
+        check(lib.bh_groth16_proof_wait(job, p(out), tm), "create_proof (async wait)")
+        if timings is not None:
+            timings[:] = list(tm)
+        return Proof(out)
+
+    return wait
+
+
+def prove_assignment_arrays_async(params, asg, r, s):
+    """bh_groth16_prove_assignment_async on the arrays of demo_assignment: the device part of create_proof
+    (prover.rs:217-360) on a helper thread; the arrays are read in place until the returned wait() has been called."""
+    lib = _lib.load()
+    rs = fr_to_mont_array([r, s])
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    job = ctypes.c_void_p()
+    check(lib.bh_groth16_prove_assignment_async(params._h, p(asg["a"]), p(asg["b"]), p(asg["c"]), asg["a"].shape[0],
+                                                p(asg["input_assignment"]), asg["input_assignment"].shape[0],
+                                                p(asg["aux_assignment"]), asg["aux_assignment"].shape[0], p(asg["a_aux_density"]),
+                                                p(asg["b_input_density"]), p(asg["b_aux_density"]), p(rs[0:1]), p(rs[1:2]),
+                                                ctypes.byref(job)), "create_proof (async)")
+    return _proof_waiter(lib, job, (asg, rs))
+
+
+def prove_witness_async(r1cs, params, input_assignment, aux_assignment, r, s):
+    """bh_groth16_prove_witness_async: the witness vectors (Montgomery [n,4] uint64 arrays, or lists of ints) are copied
+    before this returns; the device part runs on a helper thread.  Returns wait(timings=None) -> Proof."""
+    lib = _lib.load()
+    ia = input_assignment if isinstance(input_assignment, np.ndarray) else fr_to_mont_array(list(input_assignment))
+    aa = aux_assignment if isinstance(aux_assignment, np.ndarray) else fr_to_mont_array(list(aux_assignment))
+    rs = fr_to_mont_array([r, s])
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    job = ctypes.c_void_p()
+    check(lib.bh_groth16_prove_witness_async(params._h, r1cs._h, p(ia), ia.shape[0], p(aa), aa.shape[0], p(rs[0:1]), p(rs[1:2]),
+                                             ctypes.byref(job)), "create_proof (async)")
+    return _proof_waiter(lib, job, (r1cs,))

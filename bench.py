@@ -43,7 +43,10 @@ HBM_PEAK_GBPS = 8000.0
 BYTES_PER_TERM_G1 = 128  # 96 B affine base + 32 B scalar, each read once
 
 
-MADS_PER_MIXED_ADD = 8 * 351 + 2 * 273   # XYZZ madd: 8M + 2S; 13-limb radix-2^30 product/reduction, symmetric squaring
+# XYZZ madd: 8M + 2S; 13-limb radix-2^30 product (169 mads) + reduction (169 + 13 quotient products); symmetric squaring
+# (91 + 182).  Since round 4 the last line Y3 = R*(Q - X3) - Y1*PPP is two products under ONE reduction (ff.cuh fe_mul2):
+# one reduction (169 + 13) fewer per addition - the numerator of roofline.alu shrinks with it.
+MADS_PER_MIXED_ADD = 8 * 351 + 2 * 273 - 182
 
 
 def splitmix_scalars(n, seed):
@@ -513,6 +516,51 @@ def check_sharded_fold(worker, lib, world, rank, coll_dev, log_n_check=12):
     return "fold of %d shards of 2^%d terms == one multiexp of 2^%d x %d terms (checked on every rank)" % (world, log_n_check, log_n_check, world)
 
 
+def bench_one_process_sharded(lib, n_ctx, n_devices, log_n):
+    """ONE multiexp over n_ctx contexts of THIS process, context k on device k % n_devices (bh_msm_sharded_async): host
+    scalars in, one result out; checked against the fold of per-shard multiexps."""
+    import bellman_amd
+
+    n = 1 << log_n
+    workers = [bellman_amd.Worker(k % n_devices) for k in range(n_ctx)]
+    per = n // n_ctx
+    shards, t_all = [], splitmix_scalars(n, 0x0E9C)
+    for k, w in enumerate(workers):
+        lo, hi = k * per, (n if k == n_ctx - 1 else (k + 1) * per)
+        dt, dout = w.alloc((hi - lo) * 32), w.alloc((hi - lo) * 96)
+        w.upload(dt, t_all[lo:hi])
+        assert lib.bh_fixed_base_mul_dev(w.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), dt, hi - lo, 0, dout, None) == 0
+        w.synchronize()
+        w.free(dt)
+        shards.append(bellman_amd.Bases.copy_device(w, 1, dout, hi - lo))
+        w.free(dout)
+    sc = splitmix_scalars(n, 0x5CA1A)
+    got = bellman_amd.multiexp_sharded(workers, shards, bellman_amd.FullDensity(), sc).wait()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        again = bellman_amd.multiexp_sharded(workers, shards, bellman_amd.FullDensity(), sc).wait()
+    dt_s = (time.perf_counter() - t0) / reps
+    assert np.array_equal(got, again)
+    # the same sum from one multiexp per shard, folded with bh_point_add
+    acc = np.zeros(12, dtype=np.uint64)
+    for k, w in enumerate(workers):
+        lo, hi = k * per, (n if k == n_ctx - 1 else (k + 1) * per)
+        part = bellman_amd.multiexp(w, shards[k], bellman_amd.FullDensity(), sc[lo:hi]).wait()
+        r = np.zeros(12, dtype=np.uint64)
+        lib.bh_point_add(1, r.ctypes.data_as(ctypes.c_void_p), acc.ctypes.data_as(ctypes.c_void_p), part.ctypes.data_as(ctypes.c_void_p), 1)
+        acc = r
+    assert np.array_equal(got, acc), "one-process sharded multiexp != fold of the per-shard multiexps"
+    for h in shards:
+        h.release()
+    for w in workers:
+        w.close()
+    return {"workload": "ONE G1 multiexp of 2^%d terms (host scalars) over %d contexts of one process on %d device(s), "
+                        "== fold of the per-shard multiexps" % (log_n, n_ctx, min(n_ctx, n_devices)),
+            "value": round(n / dt_s / 1e6, 3), "unit": "Mscalar-mul/s", "ms": round(dt_s * 1e3, 2),
+            "contexts": n_ctx, "devices": min(n_ctx, n_devices), "scaling": "strong"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -564,6 +612,20 @@ def main():
     worker = bellman_amd.Worker(device_index)
     n = 1 << args.log_n
 
+    # ---- who is running: every rank reports its device, rank 0 prints the census (the N > 1 line proves by itself
+    # that N ranks ran on N distinct devices; src/multicore.rs:21-92 is "all the cores of one box") ----------------
+    props = torch.cuda.get_device_properties(device_index)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": device_index, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "pci_device_id": getattr(props, "pci_device_id", None), "host": os.uname().nodename, "pid": os.getpid()}
+    census = [me]
+    if collective:
+        census = [None] * world
+        dist.all_gather_object(census, me)
+    distinct_devices = len({(c["host"], c["uuid"] or c["device_index"], c["pci_bus_id"]) for c in census})
+    if collective and backend == "nccl" and world > 1:
+        assert distinct_devices == world, "RCCL run with %d ranks on %d distinct devices: %r" % (world, distinct_devices, census)
+
     # ---- synthetic inputs, generated by the PRODUCT on the device (no oracle involved) --------
     # bases P_i = [t_i] G for SplitMix-derived t_i (distinct, prime-order, never the identity);
     # each rank owns a different shard of the (virtual) world*n-term problem.
@@ -608,7 +670,10 @@ def main():
         stage += np.array(ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed * 1e3 / max(args.steps, 1)]
     if collective:
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, elapsed * 1e3 / max(args.steps, 1))
         tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -685,6 +750,15 @@ def main():
               "scaling": "strong", "steps": steps5}
         del bases5, b5, t5, s5
         worker.trim()
+    # one PROCESS driving every GPU of the node (bh_msm_sharded_async: one context per device, the reference's single
+    # process with all cores of one box, src/multicore.rs:21-92): rank 0 runs it while the other ranks wait at the barrier
+    one_process = None
+    if distributed and args.c5_log_n:
+        barrier()
+        if rank == 0:
+            one_process = bench_one_process_sharded(lib, min(world, torch.cuda.device_count()) if backend == "nccl" else world,
+                                                    torch.cuda.device_count(), min(args.c5_log_n, 22))
+        barrier()
     out = None
     if rank == 0:
         acc_ms = float(stage[2])
@@ -694,6 +768,15 @@ def main():
             "value": round(value, 3),
             "unit": "Mscalar-mul/s",
             "n_gpus": world,
+            "ranks_seen": len(census),
+            "distinct_devices": distinct_devices,
+            "ms_per_step_per_rank": [round(float(x), 4) for x in per_rank_ms],
+            "ranks": [{k: c[k] for k in ("rank", "device_index", "uuid", "pci_bus_id", "host")} for c in census],
+            "backend": (backend + (" (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "")) if collective else None,
+            "library": _lib.library_identity(),
+            # SURVEY.md 8(d) words the metric "incl. scalar upload": the same multiexp with the 32 MiB of scalars handed over
+            # as a HOST buffer on every call (what an unpatched prover.rs issues); `value` is the resident-scalar figure
+            "value_incl_scalar_upload": round(world * pcie_value, 3) if pcie_value else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -732,7 +815,8 @@ def main():
                 "alu": {"unit": "Tmad/s", "peak": 26.2,
                         "achieved": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
                         "frac": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
-                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273) v_mad_u64_u32",
+                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273 - 182: the last two "
+                                "products share one reduction) = %d v_mad_u64_u32 / v_mul_lo_u32 per addition" % MADS_PER_MIXED_ADD,
                         "peak_provenance": "v_mad_u64_u32 microbenchmark on this chip (tools/microbench_int.hip, "
                                            "profiles/r1_microbench_int.txt) at its sustained clock; under the accumulate kernel the "
                                            "SQ counters put the clock near 2.0 GHz (profiles/r1_pmc_valu.json), so the fraction is "
@@ -768,6 +852,8 @@ def main():
             out["create_proof_sharded"] = sharded_proof
         if c5 is not None:
             out["msm_c5_sharded"] = c5
+        if one_process is not None:
+            out["msm_one_process_sharded"] = one_process
         if not args.no_proof and not distributed:
             out["msm_other_shapes"] = [bench_msm_shape(worker, lib, 2, 19), bench_msm_shape(worker, lib, 2, 20),
                                        bench_msm_shape(worker, lib, 1, 16)]
@@ -780,7 +866,7 @@ def main():
         # (tools/gpu_r3_final.sh -> profiles/r3_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
         # read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte
         # pieces, so `traffic` carries the read-corrected (doubled FETCH_SIZE) figure and the note the raw one.
-        for name in ("r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
+        for name in ("r4_final_pmc_accumulate.json", "r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             except Exception:

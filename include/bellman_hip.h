@@ -244,6 +244,8 @@ typedef struct {
 #define BH_MSM_HOLD 128u        /* enqueue only the digit / sort stage; bh_msm_start (or the job's wait) enqueues the rest */
 #define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default: merge + reduction above 2^17 buckets) */
 #define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^18 terms) */
+#define BH_MSM_NO_SPLIT 512u /* host scalars: do not issue a large multiexp as two halves (the second half's upload then does
+                             * not run beside the first half's kernels) */
 #define BH_MSM_G2_LANE_PAIRS 256u /* G2: force the lane-pair kernel for the bucket accumulation (default from 2^18 terms) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
                       size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
@@ -362,13 +364,6 @@ int bh_groth16_prove_assignment(bh_params *params, const void *a_evals, const vo
                                 const uint64_t *a_aux_density, const uint64_t *b_input_density,
                                 const uint64_t *b_aux_density, const void *r, const void *s,
                                 void *proof_out, float *timings4);
-/* create_proof on a circuit written in C++ against the mirror (like bellman user code):
- * kind 0 = MiMCDemo (groth16/tests/common/mod.rs; witness = xl|xr, constants = `size` Fr),
- * kind 1 = synthetic multiplicative chain of `size` rounds (witness = x0). */
-int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed,
-                          const void *witness, const void *constants, const void *r, const void *s,
-                          void *proof_out, float *timings4);
-
 /* ---- R1CS resident in HBM: constraint evaluation as sparse matrix x witness --------
  * The reference evaluates the A/B/C linear combinations of every constraint on one host thread
  * during synthesis (groth16/src/prover.rs:19-55 `eval`, :105-145 `enforce`).  The matrices are a
@@ -414,16 +409,25 @@ int bh_groth16_prove_witness(bh_params *params, const bh_r1cs *r1cs, const void 
                              size_t n_inputs, const void *aux_assignment, size_t n_aux, const void *r,
                              const void *s, void *proof_out, float *timings4);
 /* ---- one caller, proofs back to back: create_proof split at the synthesis / device boundary -----------------
- * bh_groth16_prove_demo_async synthesises the circuit on the CALLING thread (prover.rs:182-215; with `r1cs` only the
- * witness closures run, constraints are evaluated on the device) and returns while the device part (prover.rs:217-360)
- * runs on a helper thread; bh_groth16_proof_wait blocks for it (the Waiter of the whole proof), writes the proof and
- * frees the job.  Submitting proof k+1 before waiting for proof k overlaps its synthesis with proof k's GPU work - what
- * groth16::ProofPipeline (csrc/groth16.hpp) does for C++ callers.  Proofs are identical to the synchronous calls'.
- * r1cs == NULL: host synthesis as in the reference (bh_groth16_prove_demo). */
+ * The reference's create_proof is synthesis on the host (groth16/src/prover.rs:182-215) followed by the device part
+ * (:217-360); a single caller that proves in a loop leaves the GPU idle during every synthesis and the host idle during
+ * every device part.  The _async calls return once the device part has been handed to a helper thread;
+ * bh_groth16_proof_wait blocks for it (the Waiter of the whole proof), writes the proof and frees the job.  Issuing
+ * proof k+1 before waiting for proof k overlaps its synthesis with proof k's GPU work - what groth16::ProofPipeline
+ * (csrc/groth16.hpp) does for C++ callers.  Proofs are identical to the synchronous calls'.
+ *   bh_groth16_prove_assignment_async  arguments as bh_groth16_prove_assignment; the arrays are READ IN PLACE until
+ *                                      bh_groth16_proof_wait returns (a Rust host keeps its ProvingAssignment alive);
+ *   bh_groth16_prove_witness_async     arguments as bh_groth16_prove_witness; the two witness vectors are copied before
+ *                                      the call returns, the r1cs handle must outlive the wait. */
 typedef struct bh_proof_job bh_proof_job;
-int bh_groth16_prove_demo_async(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
-                                const void *witness, const void *constants, const void *r, const void *s,
-                                bh_proof_job **job);
+int bh_groth16_prove_assignment_async(bh_params *params, const void *a_evals, const void *b_evals,
+                                      const void *c_evals, size_t n_constraints, const void *input_assignment,
+                                      size_t n_inputs, const void *aux_assignment, size_t n_aux,
+                                      const uint64_t *a_aux_density, const uint64_t *b_input_density,
+                                      const uint64_t *b_aux_density, const void *r, const void *s, bh_proof_job **job);
+int bh_groth16_prove_witness_async(bh_params *params, const bh_r1cs *r1cs, const void *input_assignment,
+                                   size_t n_inputs, const void *aux_assignment, size_t n_aux, const void *r,
+                                   const void *s, bh_proof_job **job);
 int bh_groth16_proof_wait(bh_proof_job *job, void *proof_out, float *timings4);
 
 /* ---- one proof over several GPUs: every rank holds the CRS and the matrices, builds the
@@ -439,17 +443,6 @@ int bh_groth16_prove_witness_part(bh_params *params, const bh_r1cs *r1cs, const 
                                   size_t parts, void *sums_out, float *timings4);
 void bh_groth16_sums_add(void *acc, const void *other);
 int bh_groth16_assemble(bh_params *params, const void *sums, const void *r, const void *s, void *proof_out);
-int bh_groth16_prove_demo_r1cs_part(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
-                                    uint64_t seed, const void *witness, const void *constants, size_t part,
-                                    size_t parts, void *sums_out, float *timings4);
-/* The demo circuits of bh_groth16_prove_demo through that path: capture the matrices once ... */
-int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants,
-                         bh_r1cs **out);
-/* ... then per proof run only the circuit's witness closures on the host (enforce is a no-op). */
-int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
-                               uint64_t seed, const void *witness, const void *constants, const void *r,
-                               const void *s, void *proof_out, float *timings4);
-
 #ifdef __cplusplus
 }
 #endif

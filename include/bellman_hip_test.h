@@ -1,6 +1,8 @@
-/* libbellman_hip - self-test hooks used by tests/ and tools/ only.  NOT part of the product boundary
- * (include/bellman_hip.h): nothing here is needed by a caller of multiexp / EvaluationDomain /
- * create_proof.  The symbols live in the same shared library so the tests exercise the shipped code. */
+/* libbellman_hip_test.so - self-test hooks and built-in demo circuits used by tests/, tools/ and bench.py only.  NOT part
+ * of the product boundary (include/bellman_hip.h): nothing here is needed by a caller of multiexp / EvaluationDomain /
+ * create_proof, and none of it is in libbellman_hip.so.  The test library links against the shipped one, so everything
+ * below still runs the shipped kernels and the shipped prover (csrc/test_hooks.hip, demo_circuits.cpp,
+ * groth16_callsites.cpp). */
 #ifndef BELLMAN_HIP_TEST_H
 #define BELLMAN_HIP_TEST_H
 #include "bellman_hip.h"
@@ -8,6 +10,30 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* ---- built-in demo circuits: create_proof on a circuit written in C++ against the mirror (like bellman user code;
+ * Python cannot define one, so bench.py and the tests reach these through ctypes):
+ * kind 0 = MiMCDemo (groth16/tests/common/mod.rs; witness = xl|xr, constants = `size` Fr),
+ * kind 1 = synthetic multiplicative chain of `size` rounds (witness = x0). */
+int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed,
+                          const void *witness, const void *constants, const void *r, const void *s,
+                          void *proof_out, float *timings4);
+/* the same split at the synthesis / device boundary (bh_groth16_prove_*_async of the product): synthesises the circuit
+ * on the CALLING thread (prover.rs:182-215; with `r1cs` only the witness closures run, constraints are evaluated on the
+ * device) and returns while the device part runs on a helper thread; bh_groth16_proof_wait collects it */
+int bh_groth16_prove_demo_async(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size, uint64_t seed,
+                                const void *witness, const void *constants, const void *r, const void *s,
+                                bh_proof_job **job);
+int bh_groth16_prove_demo_r1cs_part(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
+                                    uint64_t seed, const void *witness, const void *constants, size_t part,
+                                    size_t parts, void *sums_out, float *timings4);
+/* The demo circuits of bh_groth16_prove_demo through that path: capture the matrices once ... */
+int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants,
+                         bh_r1cs **out);
+/* ... then per proof run only the circuit's witness closures on the host (enforce is a no-op). */
+int bh_groth16_prove_demo_r1cs(bh_params *params, const bh_r1cs *r1cs, int circuit_kind, size_t size,
+                               uint64_t seed, const void *witness, const void *constants, const void *r,
+                               const void *s, void *proof_out, float *timings4);
 
 /* element-wise field / group ops on the device */
 int bh_test_fr_mul_dev(bh_ctx *ctx, void *r_dev, const void *a_dev, const void *b_dev, size_t n);

@@ -172,7 +172,6 @@ extern "C" {
     pub fn bh_proof_write(proof_affine: *const c_void, out192: *mut c_void);
     pub fn bh_groth16_params_release(p: *mut BhParams);
     pub fn bh_groth16_prove_assignment(params: *mut BhParams, a_evals: *const c_void, b_evals: *const c_void, c_evals: *const c_void, n_constraints: usize, input_assignment: *const c_void, n_inputs: usize, aux_assignment: *const c_void, n_aux: usize, a_aux_density: *const u64, b_input_density: *const u64, b_aux_density: *const u64, r: *const c_void, s: *const c_void, proof_out: *mut c_void, timings4: *mut f32) -> c_int;
-    pub fn bh_groth16_prove_demo(params: *mut BhParams, circuit_kind: c_int, size: usize, seed: u64, witness: *const c_void, constants: *const c_void, r: *const c_void, s: *const c_void, proof_out: *mut c_void, timings4: *mut f32) -> c_int;
     pub fn bh_r1cs_create(ctx: *mut BhCtx, n_inputs: usize, n_aux: usize, n_constraints: usize, abc: *const BhCsr, coeffs: *const c_void, n_coeffs: usize, out: *mut *mut BhR1cs) -> c_int;
     pub fn bh_r1cs_release(r: *mut BhR1cs);
     pub fn bh_r1cs_shape(r: *const BhR1cs, n_inputs: *mut usize, n_aux: *mut usize, n_constraints: *mut usize) -> c_int;
@@ -182,12 +181,10 @@ extern "C" {
     pub fn bh_r1cs_eval_transposed_dev(ctx: *mut BhCtx, r: *mut BhR1cs, lagrange_dev: *const c_void, at_dev: *mut c_void, bt_dev: *mut c_void, ct_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn bh_fr_qap_ext_dev(ctx: *mut BhCtx, e_dev: *mut c_void, at_dev: *const c_void, bt_dev: *const c_void, ct_dev: *const c_void, n_inputs: usize, n_vars: usize, alpha: *const c_void, beta: *const c_void, gamma_inv: *const c_void, delta_inv: *const c_void, stream: *mut c_void) -> c_int;
     pub fn bh_groth16_prove_witness(params: *mut BhParams, r1cs: *const BhR1cs, input_assignment: *const c_void, n_inputs: usize, aux_assignment: *const c_void, n_aux: usize, r: *const c_void, s: *const c_void, proof_out: *mut c_void, timings4: *mut f32) -> c_int;
-    pub fn bh_groth16_prove_demo_async(params: *mut BhParams, r1cs: *const BhR1cs, circuit_kind: c_int, size: usize, seed: u64, witness: *const c_void, constants: *const c_void, r: *const c_void, s: *const c_void, job: *mut *mut BhProofJob) -> c_int;
+    pub fn bh_groth16_prove_assignment_async(params: *mut BhParams, a_evals: *const c_void, b_evals: *const c_void, c_evals: *const c_void, n_constraints: usize, input_assignment: *const c_void, n_inputs: usize, aux_assignment: *const c_void, n_aux: usize, a_aux_density: *const u64, b_input_density: *const u64, b_aux_density: *const u64, r: *const c_void, s: *const c_void, job: *mut *mut BhProofJob) -> c_int;
+    pub fn bh_groth16_prove_witness_async(params: *mut BhParams, r1cs: *const BhR1cs, input_assignment: *const c_void, n_inputs: usize, aux_assignment: *const c_void, n_aux: usize, r: *const c_void, s: *const c_void, job: *mut *mut BhProofJob) -> c_int;
     pub fn bh_groth16_proof_wait(job: *mut BhProofJob, proof_out: *mut c_void, timings4: *mut f32) -> c_int;
     pub fn bh_groth16_prove_witness_part(params: *mut BhParams, r1cs: *const BhR1cs, input_assignment: *const c_void, n_inputs: usize, aux_assignment: *const c_void, n_aux: usize, part: usize, parts: usize, sums_out: *mut c_void, timings4: *mut f32) -> c_int;
     pub fn bh_groth16_sums_add(acc: *mut c_void, other: *const c_void);
     pub fn bh_groth16_assemble(params: *mut BhParams, sums: *const c_void, r: *const c_void, s: *const c_void, proof_out: *mut c_void) -> c_int;
-    pub fn bh_groth16_prove_demo_r1cs_part(params: *mut BhParams, r1cs: *const BhR1cs, circuit_kind: c_int, size: usize, seed: u64, witness: *const c_void, constants: *const c_void, part: usize, parts: usize, sums_out: *mut c_void, timings4: *mut f32) -> c_int;
-    pub fn bh_groth16_demo_r1cs(ctx: *mut BhCtx, circuit_kind: c_int, size: usize, seed: u64, constants: *const c_void, out: *mut *mut BhR1cs) -> c_int;
-    pub fn bh_groth16_prove_demo_r1cs(params: *mut BhParams, r1cs: *const BhR1cs, circuit_kind: c_int, size: usize, seed: u64, witness: *const c_void, constants: *const c_void, r: *const c_void, s: *const c_void, proof_out: *mut c_void, timings4: *mut f32) -> c_int;
 }

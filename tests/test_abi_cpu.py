@@ -28,20 +28,48 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _exported_c_symbols(path):
+    """unmangled function symbols a shared library defines and exports"""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and not ln.split()[2].startswith("_")}
+
+
 def test_header_symbols_all_exported(lib):
+    """[r4] libbellman_hip.so exports EXACTLY the C symbols include/bellman_hip.h declares; the test hooks and the
+    built-in demo circuits (include/bellman_hip_test.h) live in libbellman_hip_test.so, which links against it."""
     hdr = open(os.path.join(ROOT, "include", "bellman_hip.h")).read()
     declared = set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
-    # the product boundary carries no test hooks: they live in their own header
-    assert not [d for d in declared if d.startswith("bh_test_")]
+    # the product boundary carries no test hooks and no demo circuits: they live in their own header and library
+    assert not [d for d in declared if d.startswith("bh_test_") or "demo" in d]
     test_hdr = open(os.path.join(ROOT, "include", "bellman_hip_test.h")).read()
     hooks = set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", test_hdr))
-    assert hooks and all(h.startswith("bh_test_") for h in hooks)
-    declared |= hooks
-    assert declared == set(_lib.EXPORTS)
+    assert hooks and all(h.startswith("bh_test_") or "demo" in h for h in hooks)
+    assert declared == set(_lib.EXPORTS) and hooks == set(_lib.TEST_EXPORTS)
+    assert _exported_c_symbols(_lib.LIB_PATH) == declared
+    assert _exported_c_symbols(_lib.TEST_LIB_PATH) == hooks
     for sym in declared:
-        assert hasattr(lib, sym), sym
+        assert hasattr(lib.product, sym), sym
+    for sym in hooks:
+        assert hasattr(lib.test, sym) and not hasattr(lib.product, sym), sym
     assert b"gfx950" in lib.bh_version()
+
+
+def test_library_override_needs_two_variables():
+    """BELLMAN_HIP_LIB alone does not swap the library under the tests or the bench (bellman_amd/_lib.py)."""
+    import subprocess
+    import sys
+
+    code = "from bellman_amd import _lib; print(_lib.LIB_PATH)"
+    env = dict(os.environ, BELLMAN_HIP_LIB="/nonexistent/libbellman_hip.so")
+    env.pop("BELLMAN_HIP_ALLOW_LIB_OVERRIDE", None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == os.path.join(ROOT, "bellman_amd", "lib", "libbellman_hip.so")
+    env["BELLMAN_HIP_ALLOW_LIB_OVERRIDE"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "/nonexistent/libbellman_hip.so"
 
 
 def test_no_cpu_fallback_without_gpu(lib):

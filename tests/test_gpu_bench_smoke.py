@@ -56,3 +56,9 @@ def test_bench_ranks_on_one_gpu_gloo(ranks):
     assert out["create_proof_sharded"]["scaling"] == "strong" and "identical to the single-GPU proof" in out["create_proof_sharded"]["workload"]
     assert out["msm_c5_sharded"]["scaling"] == "strong" and out["msm_c5_sharded"]["value"] > 0
     assert "cpu_baseline" not in out          # rank 0 at N = 1 only
+    # [r4] the line proves who ran: every rank reported in, here all of them on the one GPU of the box (under RCCL
+    # bench.py asserts distinct_devices == world itself)
+    assert out["ranks_seen"] == ranks and out["distinct_devices"] == 1 and len(out["ms_per_step_per_rank"]) == ranks
+    assert [r["rank"] for r in out["ranks"]] == list(range(ranks)) and out["backend"].startswith("gloo")
+    assert out["library"]["version"].startswith("bellman_hip") and not out["library"]["override"]
+    assert out["msm_one_process_sharded"]["contexts"] == ranks and out["msm_one_process_sharded"]["value"] > 0

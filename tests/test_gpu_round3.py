@@ -430,6 +430,47 @@ def test_async_proofs_two_deep_equal_the_synchronous_ones(worker):
     r1cs.release()
 
 
+def test_async_proofs_from_an_assignment_and_from_a_witness(worker):
+    """[r4] bh_groth16_prove_assignment_async / bh_groth16_prove_witness_async + bh_groth16_proof_wait: what a C or Rust
+    host that synthesised by itself calls to keep two proofs in flight (prover.rs:182-215 on its side, :217-360 here).
+    Every proof equals the synchronous entry point's and create_proof's for the same circuit, r, s; the witness call has
+    copied its inputs when it returns (the buffers are overwritten right away); an error surfaces at the wait."""
+    from bellman_amd import UnexpectedEof
+    from bellman_amd import groth16 as pg
+
+    rounds, seed = 4093, 23
+    pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
+    r1cs = pg.R1CS.from_demo(worker, 1, rounds, seed)
+    want = [pg.create_proof_demo(pp, 1, rounds, seed, [2000 + i], None, 70 + i, 80 + i) for i in range(4)]
+    asgs = [pg.demo_assignment(1, rounds, seed, [2000 + i]) for i in range(4)]
+    # the assignment path, two deep
+    waits, got = [], []
+    for i in range(4):
+        waits.append(pg.prove_assignment_arrays_async(pp, asgs[i], 70 + i, 80 + i))
+        if len(waits) == 2:
+            got.append(waits.pop(0)())
+    got += [w() for w in waits]
+    for g, w, asg, i in zip(got, want, asgs, range(4)):
+        assert _same(g, w.a, w.b, w.c)
+        sync = pg.prove_assignment_arrays(pp, asg, 70 + i, 80 + i)
+        assert _same(sync, w.a, w.b, w.c)
+    # the witness path (constraints evaluated on the device), inputs overwritten as soon as the call returns
+    waits = []
+    for i in range(4):
+        ia, aa = asgs[i]["input_assignment"].copy(), asgs[i]["aux_assignment"].copy()
+        waits.append(pg.prove_witness_async(r1cs, pp, ia, aa, 70 + i, 80 + i))
+        ia[:] = 0
+        aa[:] = 0
+    for wt, w in zip(waits, want):
+        assert _same(wt(), w.a, w.b, w.c)
+    short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h[:-2], l, a, b1, b2)
+    wait = pg.prove_assignment_arrays_async(short, asgs[0], 2, 3)
+    with pytest.raises(UnexpectedEof):
+        wait()
+    assert worker.info()["jobs_in_flight"] == 0
+    r1cs.release()
+
+
 def test_held_jobs_two_phase_issue(worker):
     """BH_MSM_HOLD / bh_msm_start: jobs issued held (digit + sort stage only), started in another order or not at all
     (the wait starts them) - the results are those of the plain call, whatever the plan (classic, window table, G2)."""

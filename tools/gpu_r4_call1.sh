@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ALL=$GRAFT_REPO_ROOT/bellman_amd/lib_exp_all/libbellman_hip.so
 [ -f $ALL ] || { echo "build lib_exp_all first"; exit 1; }
-BELLMAN_HIP_LIB=$ALL timeout 420 python -m pytest tests/test_gpu_parity.py tests/test_gpu_groth16.py -m gpu -x -q \
+BELLMAN_HIP_ALLOW_LIB_OVERRIDE=1 BELLMAN_HIP_LIB=$ALL timeout 420 python -m pytest tests/test_gpu_parity.py tests/test_gpu_groth16.py -m gpu -x -q \
    --deselect tests/test_gpu_groth16.py::test_chain_2_20_config_c4 > $OUT/parity_all.txt 2>&1
 echo "parity (both switches): $(tail -1 $OUT/parity_all.txt)"
 for rep in 1 2; do
@@ -29,7 +29,7 @@ python tools/profile_suite.py msm 1 20 8 16 0 >> $OUT/c15.txt 2>&1
 cat $OUT/c15.txt
 BENCH="python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-proof --timed-steps-only"
 $BENCH > $OUT/bench_base.json 2>/dev/null
-BELLMAN_HIP_LIB=$ALL $BENCH > $OUT/bench_all.json 2>/dev/null
+BELLMAN_HIP_ALLOW_LIB_OVERRIDE=1 BELLMAN_HIP_LIB=$ALL $BENCH > $OUT/bench_all.json 2>/dev/null
 python - <<'PY'
 import glob, json, os
 o = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r4_call1")
