@@ -141,7 +141,6 @@ struct bh_scalars {
 };
 struct bh_msm_job {
   MsmJobImpl *impl;
-  MsmJobImpl *second = nullptr;   // a multiexp over host scalars issued as two halves (msm_split_host): the upper half
 };
 
 // hipMalloc'ed block freed on scope exit unless released: the BH_HIP_CHECK early returns of the register /
@@ -872,47 +871,7 @@ static bool tiny_msm_on_host(const bh_bases *bases, size_t skip, const void *sca
 
 static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
                       size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0, void *after_stream = nullptr);
-// [r4] A large multiexp over HOST scalars (what a Rust host with only multiexp.rs patched issues, 32 MiB per call at
-// 2^20 terms) spent 0.7 ms of PCIe time before its first kernel could start - the copy from pageable memory blocks the
-// issuing thread, and nothing of the pipeline before the sort can use partial data.  It is therefore issued as TWO
-// multiexps over the lower and the upper half of the exponents (the same bases handle, the second one skipping the
-// bases the first half consumes): the second half's copy runs while the first half sorts and accumulates, and the first
-// half's latency-bound reduction runs beside the second half's accumulation.  The two results are added on the host at
-// the wait, with the error precedence of ONE multiexp (src/multiexp.rs:295-300): a half reports whether an identity
-// base was consumed in the reference's top window (window size of the whole length) before its first EOF entry; if
-// the lower half ran out of bases its verdict stands (everything in the upper half comes later), otherwise an identity
-// in the top window of either half wins over the upper half's EOF.
-constexpr size_t MSM_SPLIT_MIN = (size_t)1 << 19;
-static int msm_split_host(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, size_t n, int fmt,
-                          const uint64_t *density, const bh_msm_opts *o, bh_msm_job **out) {
-  const size_t m = ((n / 2) + 63) & ~(size_t)63;   // density words stay aligned
-  size_t dense_before = m;
-  if (density) {
-    dense_before = 0;
-    for (size_t w = 0; w < m / 64; w++) dense_before += (size_t)__builtin_popcountll(density[w]);
-  }
-  bh_msm_opts oo = {0, 0, 0};
-  if (o) oo = *o;
-  oo.flags |= BH_MSM_NO_SPLIT;
-  bh_msm_job *lo = nullptr, *hi = nullptr;
-  int rc = msm_common(ctx, bases, skip, scalars, true, m, fmt, density, true, density ? m : 0, &oo, &lo, n);
-  if (rc != BH_OK) return rc;
-  rc = msm_common(ctx, bases, skip + dense_before, (const char *)scalars + m * 32, true, n - m, fmt,
-                  density ? density + m / 64 : nullptr, true, density ? n - m : 0, &oo, &hi, n);
-  if (rc != BH_OK) {
-    unsigned char sink[192];
-    (void)bh_msm_wait(lo, sink);
-    return rc;
-  }
-  lo->second = hi->impl;
-  delete hi;
-  *out = lo;
-  return BH_OK;
-}
-static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars, bool scalars_on_host,
-                      size_t n, int fmt, const uint64_t *density, bool density_on_host, size_t density_len,
-                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n, void *after_stream) {
+                      const bh_msm_opts *o, bh_msm_job **out, u64 shard_ref_n = 0, void *after_stream = nullptr) {
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
@@ -922,10 +881,6 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   }
   if (fmt != BH_SCALARS_CANONICAL && fmt != BH_SCALARS_MONT) return BH_ERR_INVALID_ARG;
   if (density && density_len != n) return BH_ERR_INVALID_ARG;   // multiexp.rs:324-329 (assert)
-  static const bool split_on = [] { const char *e = getenv("BELLMAN_HIP_SPLIT_HOST_SCALARS"); return !(e && *e == '0'); }();
-  if (split_on && scalars_on_host && n >= MSM_SPLIT_MIN && !shard_ref_n && !after_stream && (!density || density_on_host) &&
-      !(opts.flags & (BH_MSM_NO_SPLIT | BH_MSM_HOLD | BH_MSM_STAGE_TIMES)))
-    return msm_split_host(ctx, bases, skip, scalars, n, fmt, density, o, out);
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   // back-pressure (src/multicore.rs:47-73): at the cap the issuing thread completes the oldest job itself
   while (!msm_slot_try_reserve(ctx->c))
@@ -1138,29 +1093,6 @@ int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   if (!job) return BH_ERR_INVALID_ARG;
   float ms[4] = {0, 0, 0, 0};
   int rc = msm_job_finish(*job->impl, out_affine, ms);
-  if (job->second) {   // the upper half of a multiexp over host scalars (msm_split_host)
-    MsmJobImpl *lo = job->impl, *hi = job->second;
-    alignas(16) unsigned char part[192];
-    const int rc_hi = msm_job_finish(*hi, part, nullptr);
-    const size_t rec = lo->group == BH_G1 ? 96 : 192;
-    if (rc < 0 && rc != BH_ERR_UNEXPECTED_EOF && rc != BH_ERR_UNEXPECTED_IDENTITY) {
-      // a HIP failure of the lower half stands
-    } else if (rc_hi < 0 && rc_hi != BH_ERR_UNEXPECTED_EOF && rc_hi != BH_ERR_UNEXPECTED_IDENTITY) {
-      rc = rc_hi;
-    } else if (lo->saw_eof) {
-      // every entry of the upper half comes after the lower half's first EOF entry: the lower half's verdict stands
-    } else {
-      const bool eof = hi->saw_eof, ident = lo->saw_ident || hi->saw_ident;
-      const bool ident_top = lo->saw_ident_top || hi->saw_ident_top;
-      // without an EOF of its own a half reports ident_top only if it resolved it (always_resolve_ident): msm_finish
-      if (eof && ident) rc = ident_top ? BH_ERR_UNEXPECTED_IDENTITY : BH_ERR_UNEXPECTED_EOF;
-      else if (eof) rc = BH_ERR_UNEXPECTED_EOF;
-      else if (ident) rc = BH_ERR_UNEXPECTED_IDENTITY;
-      else { host_point_add(lo->group, out_affine, out_affine, part, 1); rc = BH_OK; }
-    }
-    if (rc != BH_OK) memset(out_affine, 0, rec);
-    msm_job_delete(hi);
-  }
   if (stage_ms4) memcpy(stage_ms4, ms, sizeof ms);
   msm_job_delete(job->impl);
   delete job;

@@ -62,8 +62,10 @@ struct NttPass {
   const BTw *post_lo;  // last pass: multiply output element k likewise (null: none)
   const BTw *post_hi;
   const BTw *post_const;   // ... or by this single entry (1/n of ifft; null: none)
-  // one-level tables in element order (null: the two-level tables above): entry g belongs to the element at index g of
-  // the vector this pass reads (pre1) / writes (tw1: inter-pass twiddle of a non-last pass; post1: last pass)
+  // one-level tables in TILE order (null: the two-level tables above; only for full tiles, log_n >= 12): entry
+  // t * 2048 + e belongs to element e of tile t in the order the load phase (pre1) / the store phase (tw1: inter-pass
+  // twiddle of a non-last pass; post1: last pass) walks the tile, so that consecutive lanes read consecutive entries
+  // whatever the tile's shape in memory is (the 2^21 / 2^22 plans have tiles one or two elements wide)
   const BTw *pre1, *tw1, *post1;
   u32 lb;             // low bits of the two-level tables
   u32 log_n;
@@ -237,27 +239,18 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
   }
 }
 
-__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
-  __shared__ uint4 plane0[NTT_PLANE];
-  __shared__ uint4 plane1[NTT_PLANE];
-  const u32 R = 1u << a.r, C = 1u << a.log_c;
-  const u32 tid = threadIdx.x;
-  const fr_t *vin = blockIdx.y == 0 ? a.in : a.in_y[blockIdx.y - 1];
-  fr_t *vout = blockIdx.y == 0 ? a.out : a.out_y[blockIdx.y - 1];
-  const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
-  const u64 n = (u64)1 << a.log_n;
-
-  // ---- which tile (XCD-aware: blocks b, b+8, b+16, ... run on one XCD and get consecutive tiles) ------------
-  u64 t = blockIdx.x;
-  if (a.xcd_swizzle) {
-    const u32 per_xcd = gridDim.x >> 3;
-    t = (u64)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  }
-  // ---- where is this tile? ---------------------------------------------------------------
-  // non-last: element(row j, col c) at base + j*M + c            (M = n >> (s + r))
-  // last:     element(row j, col c) at base + c*colstride + j    (rows contiguous)
+// ---- where is tile t of a pass? ----------------------------------------------------------------------------------
+// non-last: element(row j, col c) at base + j*M + c            (M = n >> (s + r))
+// last:     element(row j, col c) at base + c*colstride + j    (rows contiguous)
+struct TileGeo {
   u64 base, in_row_stride, in_col_stride;
-  u32 jp0 = 0;        // first column's j' (non-last passes)
+  u64 out_base, out_row_stride, out_col_stride;
+  u32 jp0;   // first column's j' (non-last passes)
+};
+__device__ __forceinline__ TileGeo tile_geo(const NttPass &a, u64 t) {
+  const u64 n = (u64)1 << a.log_n;
+  u64 base, in_row_stride, in_col_stride;
+  u32 jp0 = 0;
   u64 out_base = 0, out_row_stride = 1, out_col_stride = 1;
   if (!a.is_last) {
     const u32 logM = a.log_n - a.s - a.r;
@@ -285,6 +278,33 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
     out_col_stride = 1;
   }
 
+  TileGeo g;
+  g.base = base; g.in_row_stride = in_row_stride; g.in_col_stride = in_col_stride;
+  g.out_base = out_base; g.out_row_stride = out_row_stride; g.out_col_stride = out_col_stride; g.jp0 = jp0;
+  return g;
+}
+
+__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
+  __shared__ uint4 plane0[NTT_PLANE];
+  __shared__ uint4 plane1[NTT_PLANE];
+  const u32 R = 1u << a.r, C = 1u << a.log_c;
+  const u32 tid = threadIdx.x;
+  const fr_t *vin = blockIdx.y == 0 ? a.in : a.in_y[blockIdx.y - 1];
+  fr_t *vout = blockIdx.y == 0 ? a.out : a.out_y[blockIdx.y - 1];
+  const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
+
+  // ---- which tile (XCD-aware: blocks b, b+8, b+16, ... run on one XCD and get consecutive tiles) ------------
+  u64 t = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const u32 per_xcd = gridDim.x >> 3;
+    t = (u64)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  }
+  const TileGeo tg = tile_geo(a, t);
+  const u64 base = tg.base, in_row_stride = tg.in_row_stride, in_col_stride = tg.in_col_stride;
+  const u32 jp0 = tg.jp0;
+  const u64 out_base = tg.out_base, out_row_stride = tg.out_row_stride, out_col_stride = tg.out_col_stride;
+  const u64 tile_first = t << NTT_LOG_TILE;   // one-level tables are in TILE order: entry t * 2048 + e belongs to element e of tile t
+
   // ---- load (bit-reversed rows), optional pre-multiplication ------------------------------
   const u32 total = R << a.log_c;
   const u32 lb_mask = (1u << a.lb) - 1;
@@ -307,12 +327,10 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
       if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
     if (a.pre1) {   // one product per element; the entries form the same chain of loads as the two-level products
-      TwReg cur = tw_load(a.pre1 + gi[0]);
+      const BTw *tab = a.pre1 + tile_first + tid;   // element e = tid + i * 256 of this tile: lanes read consecutive entries
+      TwReg cur = tw_load(tab);
 #pragma unroll
-      for (int i = 0; i < PER; i++) {
-        if (tid + (u32)i * NTT_THREADS < total)
-          mul_tw(v[i], cur, (i + 1 < PER && tid + (u32)(i + 1) * NTT_THREADS < total) ? a.pre1 + gi[i + 1] : a.pre1);
-      }
+      for (int i = 0; i < PER; i++) mul_tw(v[i], cur, i + 1 < PER ? tab + (i + 1) * NTT_THREADS : tab);
     } else if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
       const BTw *ph[PER], *pl[PER];
 #pragma unroll
@@ -374,12 +392,10 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
     }
     const BTw *one_level = !a.is_last ? a.tw1 : a.post1;
     if (one_level) {
-      TwReg cur = tw_load(one_level + gi[0]);
+      const BTw *tab = one_level + tile_first + tid;
+      TwReg cur = tw_load(tab);
 #pragma unroll
-      for (int i = 0; i < PER; i++) {
-        if (tid + (u32)i * NTT_THREADS < total)
-          mul_tw(v[i], cur, (i + 1 < PER && tid + (u32)(i + 1) * NTT_THREADS < total) ? one_level + gi[i + 1] : one_level);
-      }
+      for (int i = 0; i < PER; i++) mul_tw(v[i], cur, i + 1 < PER ? tab + (i + 1) * NTT_THREADS : tab);
     } else if (hi_tab) {
       TwReg cur = tw_load(ph[0]);
 #pragma unroll
@@ -445,24 +461,36 @@ __global__ void gen_btw_kernel(BTw *out, u64 n, PowTable tab) {
   }
 }
 
-// one-level inter-pass twiddle table of a non-last pass (s bits consumed before it, r radix bits): the element at index g
-// of the pass' vector sits at row j = (g >> logM) & (R - 1), column c = g & (M - 1) of its block (M = n >> (s + r)) and is
-// multiplied by scale * w^((c * j) << s mod n) when the pass stores it (ntt_pass_kernel's `ex`)
-__global__ void gen_tw1_kernel(BTw *out, u64 n, PowTable tab, u32 log_n, u32 s, u32 r) {
-  const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  const u32 logM = log_n - s - r;
-  const u64 c = g & (((u64)1 << logM) - 1), j = (g >> logM) & (((u64)1 << r) - 1);
-  const u32 e = (u32)(((c * j) << s) & (n - 1));
-  fr_t acc = tab.scale;
-  for (int k = 0; k < 32; k++)
-    if ((e >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
-  BTw w;
-  fe_to_bform<FrParams>(w.l, acc);
-  uint4 *q = reinterpret_cast<uint4 *>(out + g);
-  q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
-  q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
-  q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
+// one-level table of a pass in tile order (ntt_pass_kernel): entry t * 2048 + e = scale * g^x with
+//   kind 0  x = the inter-pass twiddle exponent of element e in the STORE phase of a non-last pass (`ex`),
+//   kind 1  x = the index of the element the LOAD phase reads as its element e (coset factors g^i of the first pass),
+//   kind 2  x = the index the STORE phase of the last pass writes its element e to (7^-i of icoset_fft)
+__global__ __launch_bounds__(NTT_THREADS) void gen_tile_table_kernel(BTw *out, NttPass a, PowTable tab, int kind) {
+  const u64 t = blockIdx.x;
+  const TileGeo tg = tile_geo(a, t);
+  const u32 R = 1u << a.r, C = 1u << a.log_c;
+  const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
+  for (u32 e = threadIdx.x; e < (u32)NTT_TILE; e += NTT_THREADS) {
+    u32 x;
+    if (kind == 1) {
+      u32 row, col;
+      if (!a.is_last) { row = e >> a.log_c; col = e & (C - 1); } else { col = e >> a.r; row = e & (R - 1); }
+      x = (u32)(tg.base + row * tg.in_row_stride + col * tg.in_col_stride);
+    } else {
+      const u32 row = e >> a.log_c, col = e & (C - 1);
+      x = kind == 0 ? (u32)((((u64)(tg.jp0 + col) * row) << a.s) & n_mask)
+                    : (u32)(tg.out_base + row * tg.out_row_stride + col * tg.out_col_stride);
+    }
+    fr_t acc = tab.scale;
+    for (int k = 0; k < 32; k++)
+      if ((x >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
+    BTw w;
+    fe_to_bform<FrParams>(w.l, acc);
+    uint4 *q = reinterpret_cast<uint4 *>(out + (t << NTT_LOG_TILE) + e);
+    q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+    q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+    q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
+  }
 }
 
 // ---- element-wise domain ops -----------------------------------------------------------------
@@ -586,6 +614,29 @@ static void plan_passes(uint32_t log_n, uint32_t *r, uint32_t *L) {
   for (uint32_t i = 0; i < l; i++) r[i] = q + (i < rem ? 1 : 0);
 }
 
+// the geometry fields of pass p (what tile_geo and the index arithmetic of ntt_pass_kernel read); s = bits consumed by
+// the passes before it
+static NttPass pass_geometry(uint32_t log_n, const uint32_t *r, uint32_t L, uint32_t p, uint32_t s) {
+  NttPass a = NttPass();   // (value-initialised: every pointer null)
+  const bool last = (p == L - 1);
+  a.log_n = log_n;
+  a.s = s;
+  a.r = r[p];
+  a.is_last = last ? 1 : 0;
+  a.r0 = r[0];
+  a.L = L;
+  a.r1 = r[1];
+  // tile columns: as many as fit 2048 elements, bounded by the extent of the column dimension
+  uint32_t log_c = NTT_LOG_TILE - r[p];
+  if (L == 1) log_c = 0;
+  else if (last) { if (log_c > r[0]) log_c = r[0]; }
+  else { uint32_t logM = log_n - s - r[p]; if (log_c > logM) log_c = logM; }
+  a.log_c = log_c;
+  const u64 tiles = ((u64)1 << log_n) >> (r[p] + log_c);
+  a.xcd_swizzle = (tiles >= 64 && (tiles & 7) == 0) ? 1 : 0;
+  return a;
+}
+
 static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bool need_coset, bool need_icoset,
                       hipStream_t st, FftTables *out, const BTw **master) {
   std::lock_guard<std::mutex> g(c.fft_mu);
@@ -647,27 +698,34 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     };
     FftTables t1 = t;
     bool ok = true;
+    // entry t * 2048 + e of a table belongs to element e of tile t of its pass (gen_tile_table_kernel)
+    auto tile_table = [&](BTw **dst, uint32_t p, uint32_t s_bits, int kind, const fr_t &base, const fr_t &scale) {
+      BTw *tab_p = nullptr;
+      if (hipMalloc((void **)&tab_p, n * sizeof(BTw)) != hipSuccess) return false;
+      fresh.push_back(tab_p);
+      const NttPass geo = pass_geometry(log_n, pr, pL, p, s_bits);
+      hipLaunchKernelGGL(gen_tile_table_kernel, dim3((u32)(n >> NTT_LOG_TILE)), dim3(NTT_THREADS), 0, st, tab_p, geo,
+                         make_pow_table(base, scale), kind);
+      if (hipGetLastError() != hipSuccess) return false;
+      *dst = tab_p;
+      return true;
+    };
     if (need_tw && !t1.tw1[dir][0]) {
       fr_t w = fr_domain_omega_host(log_n);
       if (inverse) fe_inv(w, w);
       uint32_t s_bits = 0;
       for (uint32_t p = 0; p + 1 < pL && ok; p++) {
-        BTw *tab_p = nullptr;
-        ok = hipMalloc((void **)&tab_p, n * sizeof(BTw)) == hipSuccess;
-        if (!ok) break;
-        fresh.push_back(tab_p);
-        const PowTable pt = make_pow_table(w, (inverse && p == 0) ? t.minv : one);   // the 1/n of ifft / icoset_fft rides here
-        hipLaunchKernelGGL(gen_tw1_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, tab_p, n, pt, log_n, s_bits, pr[p]);
-        ok = hipGetLastError() == hipSuccess;
-        t1.tw1[dir][p] = tab_p;
+        ok = tile_table(&t1.tw1[dir][p], p, s_bits, 0, w, (inverse && p == 0) ? t.minv : one);   // the 1/n of ifft / icoset_fft rides here
         s_bits += pr[p];
       }
     }
-    if (ok && need_coset && !t1.coset1) ok = make(&t1.coset1, n, fr_from_u64_host(7), one) == BH_OK;
+    if (ok && need_coset && !t1.coset1) ok = tile_table(&t1.coset1, 0, 0, 1, fr_from_u64_host(7), one);
     if (ok && need_icoset && !t1.icoset1) {
       fr_t ginv;
       fe_inv(ginv, fr_from_u64_host(7));
-      ok = make(&t1.icoset1, n, ginv, one) == BH_OK;
+      uint32_t s_last = 0;
+      for (uint32_t p = 0; p + 1 < pL; p++) s_last += pr[p];
+      ok = tile_table(&t1.icoset1, pL - 1, s_last, 2, ginv, one);
     }
     if (ok) { t = t1; t.one_level = true; } else one_level_fail();
   }
@@ -726,7 +784,7 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
   if (rc) return rc;
   uint32_t s = 0;
   for (uint32_t p = 0; p < L; p++) {
-    NttPass a;
+    NttPass a = pass_geometry(log_n, r, L, p, s);
     const bool last = (p == L - 1);
     // ping-pong without a copy: pass 0 data -> scratch, middle passes in place in scratch,
     // last pass scratch -> data (digit-reversing scatter)
@@ -747,21 +805,7 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
     a.post1 = (tab.one_level && post) ? tab.icoset1 : nullptr;
     a.post_const = (last && mode == BH_IFFT && !tab.one_level) ? tab.minv_dev : nullptr;
     a.lb = tab.lb;
-    a.log_n = log_n;
-    a.s = s;
-    a.r = r[p];
-    a.is_last = last ? 1 : 0;
-    a.r0 = r[0];
-    a.L = L;
-    a.r1 = r[1];
-    // tile columns: as many as fit 2048 elements, bounded by the extent of the column dimension
-    uint32_t log_c = NTT_LOG_TILE - r[p];
-    if (L == 1) log_c = 0;
-    else if (last) { if (log_c > r[0]) log_c = r[0]; }
-    else { uint32_t logM = log_n - s - r[p]; if (log_c > logM) log_c = logM; }
-    a.log_c = log_c;
-    const u64 tiles = ((u64)1 << log_n) >> (r[p] + log_c);
-    a.xcd_swizzle = (tiles >= 64 && (tiles & 7) == 0) ? 1 : 0;
+    const u64 tiles = ((u64)1 << log_n) >> (r[p] + a.log_c);
     if (n_more && L != 1) return BH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
     BH_HIP_CHECK(hipGetLastError());

@@ -344,8 +344,13 @@ __device__ __forceinline__ u32 run_last_chunk(const u64 *src, u32 n, u32 z, u32 
 // entry owns it: it finds the run's last chunk, folds tail[l0] + head[l0+1 .. l1] itself when that is at most
 // `walk` additions, and queues longer runs for msm_merge_runs_kernel so that no lane ever executes a long serial
 // chain of point additions (~20 us per link).
+// wavefronts per SIMD the register allocation aims at (hipcc reads the second launch bound that way): two for every
+// bundle whose lane state allows it - the lane-triple instantiation sat at 256 VGPRs + 2 AGPRs, one wavefront per SIMD
+// for two registers (profiles/r4_call8.txt: G2 reduce 1.0 -> 0.91-0.94 ms)
 template <class F>
-__global__ __launch_bounds__(128) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart,
+constexpr int merge_waves_per_simd() { return (F::LANES == 1 && F::WORDS == 24) ? 1 : 2; }
+template <class F>
+__global__ __launch_bounds__(128, merge_waves_per_simd<F>()) void msm_merge_chunks_kernel(const u64 *pairs, const u32 *zstart,
                                                                XYZZ<typename F::Mem> *pts,
                                                                const XYZZ<typename F::Mem> *head,
                                                                const XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
@@ -408,7 +413,7 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
 // heavy witnesses put half the scalars of window 0 into ONE bucket.
 constexpr u32 BIG_RUN_CHUNKS = 128;
 template <class F>
-__global__ __launch_bounds__(64) void msm_merge_runs_kernel(XYZZ<typename F::Mem> *pts, const XYZZ<typename F::Mem> *head,
+__global__ __launch_bounds__(64, merge_waves_per_simd<F>()) void msm_merge_runs_kernel(XYZZ<typename F::Mem> *pts, const XYZZ<typename F::Mem> *head,
                                                             const XYZZ<typename F::Mem> *tail, u32 c, u32 chunks_per_window,
                                                             const LongRun *runs, u32 max_runs, LongRun *big_runs,
                                                             u32 max_big, ErrFlags *err, u32 G) {

@@ -1,6 +1,6 @@
 // G2 (Fp2) instantiation of the MSM pipeline.  Three kernel bundles over the same records in memory:
 //   lane triples (fp2k3.cuh)  - a G2 addition with the latency and the register footprint of a G1 addition: the
-//                               latency-bound jobs (accumulation below 2^18 terms; merge + reduction of up to 2^17
+//                               latency-bound jobs (accumulation below 2^15 terms; merge + reduction of up to 2^17
 //                               buckets, i.e. every window-table plan);
 //   lane pairs (fp2pair.cuh)  - schoolbook Fp2 products with one reduction per lane, two wavefronts per SIMD: the
 //                               throughput-bound accumulation of large jobs [round 4];
@@ -15,7 +15,8 @@ int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
   // 0 = lane triples, 1 = lane pairs, 2 = one lane per point
   const bool f_single = opts.flags & BH_MSM_G2_SINGLE_LANE, f_triples = !f_single && (opts.flags & BH_MSM_G2_LANE_TRIPLES);
   const bool f_pairs = opts.flags & BH_MSM_G2_LANE_PAIRS;   // accumulation only; combines with the two above
-  const int acc = f_pairs ? 1 : f_single ? 2 : f_triples ? 0 : (n >= ((u64)1 << 18) ? 1 : 0);
+  // (profiles/r4_call8.txt: pairs from 2^15 terms - 2^15 1.57 vs 1.73 ms, 2^16 1.67 vs 1.96, 2^17 2.20 vs 2.88; equal at 2^14)
+  const int acc = f_pairs ? 1 : f_single ? 2 : f_triples ? 0 : (n >= ((u64)1 << 15) ? 1 : 0);
   const bool red_single = f_single ? true : f_triples ? false : (u64)pl.NB > ((u64)1 << 17);
 #define BH_G2_CASE(F, FR) return msm_enqueue<F, FR>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table)
   if (red_single) {

@@ -243,10 +243,8 @@ typedef struct {
 #define BH_MSM_STAGE_TIMES 64u  /* record the per-stage HIP events bh_msm_wait_profile reports (4 extra API calls) */
 #define BH_MSM_HOLD 128u        /* enqueue only the digit / sort stage; bh_msm_start (or the job's wait) enqueues the rest */
 #define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default: merge + reduction above 2^17 buckets) */
-#define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^18 terms) */
-#define BH_MSM_NO_SPLIT 512u /* host scalars: do not issue a large multiexp as two halves (the second half's upload then does
-                             * not run beside the first half's kernels) */
-#define BH_MSM_G2_LANE_PAIRS 256u /* G2: force the lane-pair kernel for the bucket accumulation (default from 2^18 terms) */
+#define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^15 terms) */
+#define BH_MSM_G2_LANE_PAIRS 256u /* G2: force the lane-pair kernel for the bucket accumulation (default from 2^15 terms) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
                       size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
                       size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);

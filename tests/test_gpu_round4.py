@@ -50,18 +50,18 @@ def test_fft_with_two_level_and_one_level_tables(one_level):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def test_host_scalar_multiexp_issued_as_two_halves(worker):
-    """[r4] bh_msm_async with >= 2^19 HOST scalars is issued as two multiexps over the halves of the exponents, so that
-    the upper half's upload runs beside the lower half's kernels (csrc/api.hip msm_split_host).  Result and error
-    semantics are those of ONE multiexp (src/multiexp.rs:210-332): == the oracle and == the unsplit call
-    (BH_MSM_NO_SPLIT) with a density map and skip; running out of bases in the upper half, in the lower half; an identity
-    base in either half with a full-size scalar (top window: wins over a later EOF) or a small one (the EOF wins), or
-    under a zero scalar (never seen)."""
+def test_large_host_scalar_multiexp_error_semantics(worker):
+    """bh_msm_async with 2^19 + 777 HOST scalars (what a Rust host with only multiexp.rs patched issues per multiexp):
+    result and error semantics of src/multiexp.rs:210-332 at a size where the full pipeline runs - == the oracle with a
+    density map and skip; running out of bases near the end, or a quarter of the way in; an identity base early or late
+    with a full-size scalar (top window: wins over a later EOF) or a small one (the EOF wins), or under a zero scalar
+    (never seen).  (Written for the round-4 experiment that issued such a multiexp as two halves so that the second
+    half's upload would overlap the first half's kernels: no gain - each half pays the latency-bound stages and a host
+    tail of its own, profiles/r4_call8.txt - removed; the cases stay.)"""
     import bellman_amd
     from bellman_amd import UnexpectedEof, UnexpectedIdentity
     from oracle import cref
 
-    NO_SPLIT = 512
     n = (1 << 19) + 777
     rnd = np.random.default_rng(41)
     bases = cref.gen_bases(1, n + 100, a=3, b=5)
@@ -74,17 +74,15 @@ def test_host_scalar_multiexp_issued_as_two_halves(worker):
         rc, want = cref.multiexp(1, host_bases, skip, None if density is None else cref.density_bitmap(density), scalars,
                                  threads=cref.lib().orc_max_threads())
         d = bellman_amd.FullDensity() if density is None else bellman_amd.DensityTracker(density)
-        outs = []
-        for flags in (0, NO_SPLIT):
-            try:
-                got = bellman_amd.multiexp(worker, hbases, d, scalars, skip=skip, flags=flags).wait()
-                assert rc == 0 and np.array_equal(got, want), flags
-                outs.append(0)
-            except UnexpectedIdentity:
-                outs.append(1)
-            except UnexpectedEof:
-                outs.append(2)
-        assert outs == [rc, rc], (outs, rc)
+        try:
+            got = bellman_amd.multiexp(worker, hbases, d, scalars, skip=skip).wait()
+            assert rc == 0 and np.array_equal(got, want)
+            out = 0
+        except UnexpectedIdentity:
+            out = 1
+        except UnexpectedEof:
+            out = 2
+        assert out == rc, (out, rc)
         return rc
 
     assert run(hb, sc, None, 0, bases) == 0
