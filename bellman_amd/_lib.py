@@ -26,7 +26,7 @@ EXPORTS = [
     "bh_dev_zero_on", "bh_ctx_synchronize", "bh_ctx_accumulations_after", "bh_ctx_trim",
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
-    "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
+    "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_write_uncompressed", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
     "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
     "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after", "bh_msm_start",
     "bh_msm_sharded_async", "bh_msm_sharded_wait",
@@ -195,6 +195,7 @@ def load():
     lib.bh_proof_write.restype = None
     lib.bh_bases_read_uncompressed.argtypes = [vp, i32, vp, sz, c.c_uint, c.POINTER(vp), c.POINTER(sz)]
     lib.bh_bases_download.argtypes = [vp, vp, sz, sz, vp]
+    lib.bh_bases_write_uncompressed.argtypes = [vp, vp, sz, sz, vp]
     lib.bh_groth16_params_release.restype = None
     lib.bh_groth16_prove_assignment.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     lib.bh_groth16_prove_demo.argtypes = [vp, i32, sz, c.c_uint64, vp, vp, vp, vp, vp, vp]

@@ -103,6 +103,30 @@ __global__ void decode_uncompressed_kernel(const unsigned char *raw, u32 coords_
   out[pt * coords_per_point + co] = v;
 }
 
+// the inverse: Montgomery records -> the uncompressed encoding (Parameters::write, groth16/src/lib.rs:258-287 through
+// bls12_381's to_uncompressed): one thread per coordinate; an all-zero record is the identity (flag 0x40, zeros)
+__global__ void encode_uncompressed_kernel(const fp_t *pts, u32 coords_per_point, unsigned char *raw, u64 n) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * coords_per_point) return;
+  const u64 pt = t / coords_per_point;
+  const u32 ci = (u32)(t % coords_per_point);          // position on the wire
+  const fp_t *rec = pts + pt * coords_per_point;
+  u32 any = 0;
+  for (u32 k = 0; k < coords_per_point; k++)
+#pragma unroll
+    for (int w = 0; w < 12; w++) any |= rec[k].l[w];
+  const u32 co = (coords_per_point == 4) ? (ci ^ 1u) : ci;   // G2 stores c1 before c0 on the wire
+  fp_t v = rec[co], c;
+  fe_from_mont(c, v);
+  u32 *dst = reinterpret_cast<u32 *>(raw + pt * coords_per_point * 48 + (size_t)ci * 48);
+#pragma unroll
+  for (int w = 0; w < 12; w++) {
+    u32 x = any ? __builtin_bswap32(c.l[11 - w]) : 0u;
+    if (!any && ci == 0 && w == 0) x = 0x40u;   // first byte of the record: the infinity flag
+    dst[w] = x;
+  }
+}
+
 // smallest index whose status makes Parameters::read fail (lib.rs:300-315)
 __global__ void first_bad_point_kernel(const u32 *status, u64 n, u32 forbid_identity, unsigned long long *min_idx) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -130,6 +154,13 @@ struct bh_bases {
   WindowTable tab = {0, 0, 0};
   bool auto_table = false;   // built at registration under the context's table budget; bh_ctx_trim may drop it
   bh_ctx *ctx = nullptr;
+  // [r4] G1 vectors that run the classic plan (>= 2^17 points, owned by the handle): a second copy of the records at a
+  // 128-byte stride, which is what the bucket accumulation gathers from - every gather is exactly one cache line (a
+  // 96-byte record at a 96-byte stride straddles two lines half of the time).  profiles/r4_call11_padded_bases.txt:
+  // FETCH_SIZE of the accumulate launch 2.20 -> 1.58 GB at 2^20; accumulate -1 % at 2^20 (the table sits in the
+  // Infinity Cache either way), -3 % at 2^22 (it does not).  Dense `dev` stays what every other path and the API see.
+  // BELLMAN_HIP_BASE_PAD=0 switches it off; vectors whose copy would exceed 1/16 of the device memory are not padded.
+  void *padded = nullptr;
 };
 // a scalar vector resident in HBM (bh_scalars_*): create_proof hands the same assignment to up to four multiexps
 struct bh_scalars {
@@ -201,6 +232,20 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
   // automatic window table: only while all automatic tables of the context stay within its budget (default a
   // quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB / bh_ctx_set_limits): a table is 13-32 x its base
   // vector (2^22 G2 points: 12.9 GB) and must not starve the per-proof workspaces
+  static const bool pad_on = [] { const char *e = getenv("BELLMAN_HIP_BASE_PAD"); return !(e && *e == '0'); }();
+  if (pad_on && group == BH_G1 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
+      (ctx->c.hbm_total == 0 || n * 128 <= ctx->c.hbm_total / 16)) {
+    if (hipMalloc(&b->padded, n * 128) == hipSuccess) {
+      if (hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+        (void)hipFree(b->padded);
+        b->padded = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      b->padded = nullptr;
+    }
+  }
   const unsigned lg = auto_table_max_log2(group);
   if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) {
     const size_t need = table_bytes_for(b, table_window_bits(n, group == BH_G2));
@@ -730,6 +775,23 @@ int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count
   }
   return BH_OK;
 }
+int bh_bases_write_uncompressed(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host_bytes) {
+  if (!ctx || !b || first + count > b->n || (count && !out_host_bytes)) return BH_ERR_INVALID_ARG;
+  const size_t rec = b->group == BH_G1 ? 96 : 192;
+  const u32 cpp = b->group == BH_G1 ? 2 : 4;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  if (!count) return BH_OK;
+  void *raw = ctx->c.pool.acquire(count * rec);
+  if (!raw) return BH_ERR_HIP;
+  const u64 threads = (u64)count * cpp;
+  hipLaunchKernelGGL(encode_uncompressed_kernel, dim3((u32)((threads + 255) / 256)), dim3(256), 0, ctx->c.stream,
+                     (const fp_t *)((const char *)b->dev + first * rec), cpp, (unsigned char *)raw, (u64)count);
+  int rc = hipGetLastError() == hipSuccess ? BH_OK : BH_ERR_HIP;
+  if (rc == BH_OK && hipMemcpyAsync(out_host_bytes, raw, count * rec, hipMemcpyDeviceToHost, ctx->c.stream) != hipSuccess) rc = BH_ERR_HIP;
+  if (hipStreamSynchronize(ctx->c.stream) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  ctx->c.pool.release(raw);
+  return rc;
+}
 int bh_bases_copy_dev(bh_ctx *ctx, int group, const void *dev_points, size_t n, bh_bases **out) {
   if (!ctx || !out || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
   const size_t rec = group == BH_G1 ? 96 : 192;
@@ -800,6 +862,7 @@ void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
     b->ctx->c.table_bytes = b->ctx->c.table_bytes > bytes ? b->ctx->c.table_bytes - bytes : 0;
   }
   if (b->table) (void)hipFree(b->table);
+  if (b->padded) (void)hipFree(b->padded);
   if (b->owned && b->dev) (void)hipFree(b->dev);
   delete b;
 }
@@ -875,6 +938,7 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
+  opts.padded_bases = bases->table ? nullptr : bases->padded;
   if (o) {
     if (o->window_bits && (o->window_bits < 2 || o->window_bits > 24)) return BH_ERR_INVALID_ARG;
     opts.c = o->window_bits; opts.chunk = o->chunk; opts.flags = o->flags;

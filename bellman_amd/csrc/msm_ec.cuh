@@ -123,7 +123,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
                                                              const Affine<typename F::Mem> *bases,
                                                              XYZZ<typename F::Mem> *pts, XYZZ<typename F::Mem> *head,
                                                              XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
-                                                             u32 chunks_per_window, ErrFlags *err) {
+                                                             u32 chunks_per_window, ErrFlags *err, u32 base_stride) {
   static_assert(!LDS_ACC || F::LANES == 1, "the LDS accumulator belongs to the single-lane kernels");
   static_assert(F::LANES == 1 || F::LANES == 2 || F::LANES == 3, "one lane, a lane pair or a lane triple per group element");
   const u32 w = blockIdx.y;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
         cur = d;
       }
       Affine<F> q;
-      load_affine<F>(q, bases + ((u32)e & 0x7fffffffu));
+      load_affine<F>(q, reinterpret_cast<const Affine<typename F::Mem> *>(reinterpret_cast<const char *>(bases) +
+                                                                          (size_t)((u32)e & 0x7fffffffu) * base_stride));
       if (aff_is_identity(q)) { saw_identity = true; continue; }
       if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
       xyzz_madd(acc, q);
@@ -971,6 +972,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     const u32 wpb = workers_per_block<F>(128, default_per_wave<F>());
     const dim3 grid((p.chunks_per_window + wpb - 1) / wpb, p.W);
     const Affine<M> *bases = (const Affine<M> *)bases_dev;
+    // G1 records at a 128-byte stride for the gathers of the classic plan (api.hip bh_bases::padded)
+    const bool padded = opts.padded_bases && !use_table && !G2 && F::LANES == 1 && !lds_acc;
     // launches that fill the chip join the context's accumulation chain (common.hpp)
     static const bool chain_on = [] { const char *e = getenv("BELLMAN_HIP_ACC_CHAIN"); return !(e && *e == '0'); }();
     const bool chained = chain_on && (u64)grid.x * grid.y * 128 >= (u64)c.num_cus * 4 * 64;
@@ -985,13 +988,14 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     if constexpr (F::LANES == 1) {
       if (lds_acc)
         hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
-                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, (u32)sizeof(Affine<M>));
       else
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
-                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart,
+                           padded ? (const Affine<M> *)opts.padded_bases : bases, pts, head, tail, p.n, p.c, p.chunk,
+                           p.chunks_per_window, err, padded ? 128u : (u32)sizeof(Affine<M>));
     } else {
       hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
-                         tail, p.n, p.c, p.chunk, p.chunks_per_window, err);
+                         tail, p.n, p.c, p.chunk, p.chunks_per_window, err, (u32)sizeof(Affine<M>));
     }
     BH_HIP_CHECK(hipGetLastError());
     if (chained) {

@@ -39,6 +39,7 @@ struct MsmOpts {
   // top window even when it saw no EOF itself - the fold needs it for the error precedence
   u64 ref_n = 0;
   bool always_resolve_ident = false;
+  const void *padded_bases = nullptr;   // the same G1 records at a 128-byte stride (api.hip bh_bases::padded); null: none
 };
 
 struct MsmPlan {

@@ -260,6 +260,11 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
                "encoding); Parameters::read(checked) %.0f ms / (unchecked) %.0f ms incl. the host-to-device copy - decoding, "
                "on-curve and subgroup tests on the device; untimed set-up"
                % (generate_ms, 4 * (1 << log_n), 1 << log_n, write_ms, crs_bytes / 1e6, read_checked_ms, read_unchecked_ms),
+        # what a user waits for before the first proof (none of it is in any per-proof figure); structured so that
+        # regressions there are visible (groth16/src/lib.rs:258-398, generator.rs:163-510)
+        "setup": {"constraints_log2": log_n, "r1cs_capture_ms": round(capture_ms, 1), "generate_parameters_ms": round(generate_ms, 1),
+                  "params_write_ms": round(write_ms, 1), "params_bytes": crs_bytes, "params_read_checked_ms": round(read_checked_ms, 1),
+                  "params_read_unchecked_ms": round(read_unchecked_ms, 1), "window_table_bytes": int(worker.info().get("table_bytes", 0))},
         "with_r1cs_resident_in_hbm": {
             "note": "constraint matrices captured once per circuit (%.0f ms, untimed, like the CRS upload); per proof: "
                     "witness closures on the host, A.w/B.w/C.w + everything else on the device; identical proofs" % capture_ms,
@@ -636,7 +641,9 @@ def main():
                                    ctypes.c_void_p(t_dev.data_ptr()), n, 0, ctypes.c_void_p(bases_dev.data_ptr()), None)
     assert rc == 0
     worker.synchronize()
-    bases = bellman_amd.Bases.wrap_device(worker, 1, ctypes.c_void_p(bases_dev.data_ptr()), n)
+    # registered like a CRS query (bh_bases_copy_dev: the handle owns its device copy - and, for a G1 vector of this
+    # size, the 128-byte-stride copy the accumulation gathers from); no window table at this size
+    bases = bellman_amd.Bases.copy_device(worker, 1, ctypes.c_void_p(bases_dev.data_ptr()), n)
     s_host = splitmix_scalars(n, 0x5CA1A25 + rank * 4 * n)
     s_dev = torch.from_numpy(s_host.view(np.int64)).cuda()
     torch.cuda.synchronize()
@@ -860,6 +867,7 @@ def main():
             out["create_proof_mimc"] = bench_mimc(worker, cpu_baseline=not args.no_cpu_baseline)
             out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
+            out["setup"] = out["create_proof"]["setup"]   # (also at the top level: the set-up path of the config C4 proof)
             if args.c5_proof_log_n:
                 out["create_proof_c5"] = bench_create_proof_c5(worker, args.c5_proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of this same command

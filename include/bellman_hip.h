@@ -174,6 +174,10 @@ int bh_bases_read_uncompressed(bh_ctx *ctx, int group, const void *host_bytes, s
                                bh_bases **out, size_t *bad_index);
 /* copies `count` device-resident affine records (Montgomery) starting at `first` back to the host */
 int bh_bases_download(bh_ctx *ctx, const bh_bases *b, size_t first, size_t count, void *out_host);
+/* the same range in the uncompressed encoding Parameters::write emits (groth16/src/lib.rs:258-287; 96 / 192 bytes per
+ * point, big-endian coordinates, G2 c1 before c0, identity = flag byte 0x40): encoded on the device, count * 96|192 bytes
+ * to out_host_bytes - the inverse of bh_bases_read_uncompressed */
+int bh_bases_write_uncompressed(bh_ctx *ctx, const bh_bases *bases, size_t first, size_t count, void *out_host_bytes);
 /* Window table for a registered base vector (optional; the CRS is fixed across proofs, groth16/src/lib.rs
  * :443-473 hands out the same Arc<Vec<Affine>> every time): stores 2^(c*j) P_i for every window j next to
  * the bases (W = ceil(256/c) rows, W x the memory).  Multiexps over such bases send every digit of a

@@ -134,6 +134,7 @@ extern "C" {
     pub fn bh_bases_register_uncompressed(ctx: *mut BhCtx, group: c_int, host_bytes: *const c_void, n: usize, out: *mut *mut BhBases) -> c_int;
     pub fn bh_bases_read_uncompressed(ctx: *mut BhCtx, group: c_int, host_bytes: *const c_void, n: usize, flags: c_uint, out: *mut *mut BhBases, bad_index: *mut usize) -> c_int;
     pub fn bh_bases_download(ctx: *mut BhCtx, b: *const BhBases, first: usize, count: usize, out_host: *mut c_void) -> c_int;
+    pub fn bh_bases_write_uncompressed(ctx: *mut BhCtx, bases: *const BhBases, first: usize, count: usize, out_host_bytes: *mut c_void) -> c_int;
     pub fn bh_bases_precompute(ctx: *mut BhCtx, b: *mut BhBases, window_bits: c_uint) -> c_int;
     pub fn bh_bases_table_info(b: *const BhBases, window_bits: *mut c_uint, rows: *mut c_uint, bytes: *mut usize) -> c_int;
     pub fn bh_bases_copy_dev(ctx: *mut BhCtx, group: c_int, dev_points: *const c_void, n: usize, out: *mut *mut BhBases) -> c_int;

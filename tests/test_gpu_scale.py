@@ -274,7 +274,9 @@ def test_fft_above_2_25(worker, log_n):
         three-pass digit reversal) cannot survive this;
       * coset_fft of the same polynomial at sampled points (a_j 7^(i_j) w^(i_j k));
       * random data: ifft(fft(x)) == x and icoset_fft(coset_fft(x)) == x on every element.
-    2^29 ... 2^31 (16 - 64 GiB vectors + as much scratch) are not run anywhere in this repository."""
+    2^29 ... 2^31 (16 - 64 GiB vectors + as much scratch + a copy): the same method with everything generated and
+    compared on the device side, tools/fft_huge.py - test_fft_2_29_device_side below runs 2^29, the output of all three
+    sizes is profiles/r4_fft_2p29_2p31.txt."""
     import bellman_amd
 
     n = 1 << log_n
@@ -306,3 +308,17 @@ def test_fft_above_2_25(worker, log_n):
     d.icoset_fft()
     assert np.array_equal(d.into_coeffs(), x)
     worker.trim()
+
+
+def test_fft_2_29_device_side():
+    """[r4] 2^29 points (16 GiB vector; three passes 10 + 10 + 9) by tools/fft_huge.py: sparse polynomial against Python
+    integers at sampled outputs (fft, coset_fft), dense round trips compared on the device - the method of
+    test_fft_above_2_25 without host-sized arrays.  2^30 and 2^31 (192 GiB of device memory in total) were run with the
+    same tool: profiles/r4_fft_2p29_2p31.txt (src/domain.rs:57-59 allows exp <= 31)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fft_huge.py"), "29"], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "2^29 done" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
