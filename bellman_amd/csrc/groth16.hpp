@@ -72,11 +72,33 @@ __attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t 
     c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                             \
   }
   BH_FR_ROW(b[0]) BH_FR_ROW(b[1]) BH_FR_ROW(b[2]) BH_FR_ROW(b[3])
-#undef BH_FR_ROW
   uint64_t t[4] = {t0, t1, t2, t3};
   if (t4 || geq_mod(t)) sub_mod(t);
   r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
 }
+// a * v for a ONE-limb second operand: the product rows of its three zero limbs vanish and only their reduction steps
+// remain - 24 limb products instead of 36.  Fr::from_u64 (bls12_381's `From<u64> for Scalar` is a full product with R^2)
+// is what a circuit calls for every constant it writes down; the synthetic chain circuit of BASELINE config C4 spends
+// two of its three products per constraint there.
+__attribute__((always_inline)) inline void mont_mul_u64(uint64_t *r, const uint64_t *a, uint64_t v) {
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  BH_FR_ROW(v)
+#define BH_FR_REDUCE_ROW                                                                  \
+  {                                                                                       \
+    const uint64_t m = t0 * INV;                                                          \
+    u128 c = ((u128)m * MOD[0] + t0) >> 64;                                               \
+    c += (u128)m * MOD[1] + t1; t0 = (uint64_t)c; c >>= 64;                               \
+    c += (u128)m * MOD[2] + t2; t1 = (uint64_t)c; c >>= 64;                               \
+    c += (u128)m * MOD[3] + t3; t2 = (uint64_t)c; c >>= 64;                               \
+    c += t4; t3 = (uint64_t)c; t4 = (uint64_t)(c >> 64);                                  \
+  }
+  BH_FR_REDUCE_ROW BH_FR_REDUCE_ROW BH_FR_REDUCE_ROW
+#undef BH_FR_REDUCE_ROW
+  uint64_t t[4] = {t0, t1, t2, t3};
+  if (t4 || geq_mod(t)) sub_mod(t);
+  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+}
+#undef BH_FR_ROW
 }  // namespace fr_detail
 
 struct Fr {
@@ -84,9 +106,8 @@ struct Fr {
   static Fr zero() { return Fr{{0, 0, 0, 0}}; }
   static Fr one() { return Fr{{fr_detail::R[0], fr_detail::R[1], fr_detail::R[2], fr_detail::R[3]}}; }
   static Fr from_u64(uint64_t v) {
-    const uint64_t c[4] = {v, 0, 0, 0};
     Fr r;
-    fr_detail::mont_mul(r.l, c, fr_detail::R2);
+    fr_detail::mont_mul_u64(r.l, fr_detail::R2, v);
     return r;
   }
   static Fr from_u512(const uint64_t limbs_le[8]);   // wide reduction, as ff's Field::random does
