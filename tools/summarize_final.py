@@ -30,6 +30,8 @@ def main():
     cp("gputests.txt", "gputests.txt")
     cp("fft.txt", "fft.txt")
     cp("mimc.txt", "mimc.txt")
+    cp("pmc_extra.json", "pmc_g2_pairs_and_fft.json")
+    cp("proof.txt", "proof_2p20.txt")
     with open(os.path.join(prof, tag + "_sizes.txt"), "w") as f:
         for name in ("sizes_g1.txt", "sizes_g1_large.txt", "sizes_g2.txt"):
             if os.path.exists(os.path.join(src, name)):
@@ -82,7 +84,7 @@ def write_summary(tag):
     tests = [ln for ln in open(os.path.join(prof, tag + "_gputests.txt")) if " passed" in ln]
     L = []
     A = L.append
-    A("# Round 2, final run on one MI355X (tools/gpu_final.sh, summarised by tools/summarize_final.py)\n")
+    A("# Final run of %s on one MI355X (tools/gpu_%s.sh, summarised by tools/summarize_final.py)\n" % (tag, tag.replace("_final", "_final") if tag.startswith("r") else "final"))
     A("`pytest tests -m gpu`: %s (`%s_gputests.txt`); `__graft_entry__.smoke()`: ok.\n" % (tests[-1].strip() if tests else "?", tag))
     A("## bench.py (default flags; `%s_bench.json`)\n" % tag)
     A("| item | value |\n|---|---|")
