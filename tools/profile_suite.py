@@ -124,6 +124,39 @@ def run_sweep(args):
                   (group, log_n, c, k, fl, wall, *best), flush=True)
 
 
+def run_tsweep(args):
+    """tsweep <group> <lo> <hi> <table c list, 0 = no table (classic plan)>: per-stage device ms of 2^lo..2^hi with the
+    window table rebuilt for each c (bh_bases_precompute), to re-check the plan boundaries of msm_stages.hip."""
+    group, lo, hi = int(args[0]), int(args[1]), int(args[2])
+    cs = [int(x) for x in args[3].split(",")]
+    from bellman_amd.multiexp import NO_TABLE
+    lib = _lib.load()
+    w = bellman_amd.Worker(0)
+    nmax = 1 << hi
+    dout = make_bases(w, lib, group, nmax)
+    s = splitmix_scalars(nmax, 2)
+    ds = w.alloc(nmax * 32)
+    w.upload(ds, s)
+    for log_n in range(lo, hi + 1):
+        n = 1 << log_n
+        for c in cs:
+            bases = bellman_amd.Bases.copy_device(w, group, dout, n)
+            flags = NO_TABLE if c == 0 else 0
+            if c:
+                bases.precompute(c)
+            best, walls = None, []
+            for it in range(7):
+                t0 = time.perf_counter()
+                r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True, flags=flags).wait()
+                walls.append((time.perf_counter() - t0) * 1e3)
+                if it and (best is None or ms[0] < best[0]):
+                    best = ms
+            walls = sorted(walls[1:])
+            print("G%d log_n=%d table c=%2d  wall median %.3f ms  device total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" %
+                  (group, log_n, c, walls[len(walls) // 2], *best), flush=True)
+            bases.release()
+
+
 def run_fft(args):
     log_n = int(args[0])
     iters = int(args[1]) if len(args) > 1 else 10
@@ -215,4 +248,4 @@ def run_proof(args):
 
 
 if __name__ == "__main__":
-    {"msm": run_msm, "sweep": run_sweep, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes, "proof": run_proof}[sys.argv[1]](sys.argv[2:])
+    {"msm": run_msm, "sweep": run_sweep, "tsweep": run_tsweep, "fft": run_fft, "mimc": run_mimc, "sizes": run_sizes, "proof": run_proof}[sys.argv[1]](sys.argv[2:])
