@@ -197,7 +197,8 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
   }
   return BH_OK;
 }
-// Base vectors of up to 2^16 (G1) / 2^22 (G2) points get their window table at registration
+// Base vectors of up to 2^18 (G1; 2^16 until round 4 - profiles/r4_call13_fft_batched_loads_and_plan_sweeps.txt: with a
+// table 2^17 1.04 vs 1.31 ms, 2^18 1.47 vs 1.72) / 2^22 (G2) points get their window table at registration
 // (BELLMAN_HIP_TABLE_MAX_LOG2 overrides both limits; 0 = never): a multiexp over a few thousand terms is a chain of
 // latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the windows and all but
 // one of its bucket reductions (the CRS is registered once per circuit).  Above those sizes the single bucket set's
@@ -209,7 +210,7 @@ static unsigned auto_table_max_log2(int group) {
     const long x = strtol(e, nullptr, 10);
     return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();
-  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 16u : 22u);
+  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 18u : 22u);
 }
 static size_t table_bytes_for(const bh_bases *b, unsigned c) {
   const u32 W = (256 + c - 1) / c;
@@ -233,7 +234,9 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
   // quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB / bh_ctx_set_limits): a table is 13-32 x its base
   // vector (2^22 G2 points: 12.9 GB) and must not starve the per-proof workspaces
   static const bool pad_on = [] { const char *e = getenv("BELLMAN_HIP_BASE_PAD"); return !(e && *e == '0'); }();
-  if (pad_on && group == BH_G1 && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
+  const unsigned lg_table = auto_table_max_log2(group);
+  const bool table_size = lg_table && n > TINY_MSM_MAX && n <= (size_t(1) << lg_table);   // (takes a window table instead)
+  if (pad_on && group == BH_G1 && !table_size && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
       (ctx->c.hbm_total == 0 || n * 128 <= ctx->c.hbm_total / 16)) {
     if (hipMalloc(&b->padded, n * 128) == hipSuccess) {
       if (hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) != hipSuccess ||
@@ -246,8 +249,7 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
       b->padded = nullptr;
     }
   }
-  const unsigned lg = auto_table_max_log2(group);
-  if (lg && n > TINY_MSM_MAX && n <= (size_t(1) << lg)) {
+  if (table_size) {
     const size_t need = table_bytes_for(b, table_window_bits(n, group == BH_G2));
     bool fits;
     {

@@ -156,6 +156,21 @@ __device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1,
   o[16] = n.c; o[17] = 0; o[18] = 0; o[19] = 0;
   return o;
 }
+// the same without the chained load: the entry is already in registers (one-level tables, loaded beside the data)
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+__device__ __attribute__((noinline)) static u32x8 fr_mul_w(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1, u32 w2) {
+  fr_t a, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
+  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  const u32 B[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2};
+  fe_mul_b<FrParams, false>(r, a, B);
+  return u32x8{r.l[0], r.l[1], r.l[2], r.l[3], r.l[4], r.l[5], r.l[6], r.l[7]};
+}
+__device__ __forceinline__ void mul_w(fr_t &a, const TwReg &w) {
+  const u32x8 o = fr_mul_w(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w.a, w.b, w.c);
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.l[i] = o[i];
+}
 // a <- a * cur, cur <- *next
 __device__ __forceinline__ void mul_tw(fr_t &a, TwReg &cur, const BTw *next) {
   const u32x20 o = fr_mul_tw(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, cur.a, cur.b, cur.c, next);
@@ -284,6 +299,11 @@ __device__ __forceinline__ TileGeo tile_geo(const NttPass &a, u64 t) {
   return g;
 }
 
+// ONE: the instantiation for sizes with one-level tables (tw1 / pre1 / post1).  Their entries stream from HBM (0.2 GB per
+// table and pass), so the chain "multiply while the next entry loads" of the two-level path - whose entries sit in L2 -
+// left a third of the wave cycles waiting (profiles/r4_final_pmc_g2_pairs_and_fft.json: SQ_WAIT_ANY 32 %): all eight
+// entries of a thread are loaded at once, beside the data, before the first product.
+template <bool ONE>
 __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
   __shared__ uint4 plane0[NTT_PLANE];
   __shared__ uint4 plane1[NTT_PLANE];
@@ -326,12 +346,14 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
       slot[i] = (col << a.r) + rrow;
       if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
-    if (a.pre1) {   // one product per element; the entries form the same chain of loads as the two-level products
-      const BTw *tab = a.pre1 + tile_first + tid;   // element e = tid + i * 256 of this tile: lanes read consecutive entries
-      TwReg cur = tw_load(tab);
+    if (ONE && a.pre1) {   // one product per element; entry of element e = tid + i * 256: lanes read consecutive entries
+      const BTw *tab = a.pre1 + tile_first + tid;
+      TwReg w[PER];
 #pragma unroll
-      for (int i = 0; i < PER; i++) mul_tw(v[i], cur, i + 1 < PER ? tab + (i + 1) * NTT_THREADS : tab);
-    } else if (a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
+      for (int i = 0; i < PER; i++) w[i] = tw_load(tab + i * NTT_THREADS);
+#pragma unroll
+      for (int i = 0; i < PER; i++) mul_w(v[i], w[i]);
+    } else if (!ONE && a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
       const BTw *ph[PER], *pl[PER];
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -373,6 +395,25 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
   {
     fr_t v[PER];
     u64 gi[PER];
+    if constexpr (ONE) {
+      const BTw *one_level = !a.is_last ? a.tw1 : a.post1;
+      TwReg w[PER];
+      if (one_level) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) w[i] = tw_load(one_level + tile_first + tid + i * NTT_THREADS);
+      }
+#pragma unroll
+      for (int i = 0; i < PER; i++) {
+        const u32 e = tid + (u32)i * NTT_THREADS;
+        const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
+        v[i] = tile_ld(plane0, plane1, (col << a.r) + row);
+        gi[i] = out_base + row * out_row_stride + col * out_col_stride;
+      }
+      if (one_level) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) mul_w(v[i], w[i]);
+      }
+    } else {
     const BTw *ph[PER], *pl[PER];
     // the two-level table a pass multiplies its outputs with: inter-pass twiddles w_n^ex (not the last pass; ex = 0
     // gives hi[0] * lo[0] = 1 * 1, exact in Montgomery form), or the coset / 1/n scaling of the last pass
@@ -390,13 +431,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
       ph[i] = hi_tab ? hi_tab + (ex >> a.lb) : nullptr;   // no table: plain fft / the 1/n of ifft below
       pl[i] = lo_tab ? lo_tab + (ex & lb_mask) : nullptr;
     }
-    const BTw *one_level = !a.is_last ? a.tw1 : a.post1;
-    if (one_level) {
-      const BTw *tab = one_level + tile_first + tid;
-      TwReg cur = tw_load(tab);
-#pragma unroll
-      for (int i = 0; i < PER; i++) mul_tw(v[i], cur, i + 1 < PER ? tab + (i + 1) * NTT_THREADS : tab);
-    } else if (hi_tab) {
+    if (hi_tab) {
       TwReg cur = tw_load(ph[0]);
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -412,6 +447,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
         if (tid + (u32)i * NTT_THREADS < total) mul_tw(v[i], cur, a.post_const);
       }
     }
+    }   // two-level tables
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const u32 e = tid + (u32)i * NTT_THREADS;
@@ -807,7 +843,8 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
     a.lb = tab.lb;
     const u64 tiles = ((u64)1 << log_n) >> (r[p] + a.log_c);
     if (n_more && L != 1) return BH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
+    if (tab.one_level) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
     BH_HIP_CHECK(hipGetLastError());
     s += r[p];
   }

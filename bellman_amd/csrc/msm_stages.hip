@@ -285,9 +285,11 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // fills the chip (profiles/r2_call15_table_bits.txt: G1 2^15 0.79 vs 0.90 ms, 2^16 0.96 vs 1.03; G2 2^15 1.64 vs 1.74)
   // tiny G2 vectors: 32 rows of 8 bits - 128 buckets instead of 4096 mostly empty ones, a shorter reduction chain
   // (profiles/r2_call19_table_bits_tiny.txt: 2^9 0.65 vs 0.80 ms, 2^10 0.72 vs 0.81, 2^11 0.85 vs 0.91; G1: no difference)
+  // [r4] re-swept with the lane-pair G2 accumulation and the fused G1 formula (profiles/r4_call13_*): G2 2^15 takes the
+  // 8-bit table (1.43 vs 1.53-1.54 ms with 13 / 16 bits); G1 tables now reach 2^18 (16 bits: 1.06 / 1.47 ms at 2^17 / 2^18)
   if (lg <= 11) return g2 ? 8 : 13;
-  if (g2) return lg == 15 ? 13 : 16;
-  return (lg == 15 || lg == 16) ? 13 : lg <= 17 ? 16 : 20;
+  if (g2) return lg == 15 ? 8 : 16;
+  return (lg == 15 || lg == 16) ? 13 : lg <= 18 ? 16 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
