@@ -38,7 +38,7 @@ int msm_job_after(MsmJobImpl &job, hipStream_t after);
 void msm_job_set_result(MsmJobImpl &job, int rc, const void *affine_record);
 void msm_job_own(MsmJobImpl &job, void *dev_ptr);
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
-                   hipStream_t st);
+                   hipStream_t st, void *table_dev);
 void host_point_add(int group, void *r, const void *a, const void *b, u64 n);
 void host_point_mul(int group, void *r, const void *a, const void *k);
 void host_point_lincomb(int group, void *r, const void *pts, const void *scalars, u64 n);
@@ -1175,8 +1175,20 @@ int bh_msm_wait(bh_msm_job *job, void *out_affine) { return bh_msm_wait_timed(jo
 
 int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host, const void *scalars_dev, size_t n,
                           int fmt, void *out_dev, void *stream) {
-  if (group != BH_G1 && group != BH_G2) return BH_ERR_INVALID_ARG;
-  return fixed_base_mul(group, base_affine_host, scalars_dev, n, fmt, out_dev, pick_stream(ctx, stream));
+  if (!ctx || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
+  if (!n) return BH_OK;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  // the window table of the base (32 x 255 affine records, built on the stream in front of the multiplications): a
+  // plain allocation freed with hipFreeAsync-like semantics is not available for pool blocks, so it is a pool block
+  // returned once the stream has drained - the call stays asynchronous for a caller-supplied stream only up to here
+  hipStream_t st = pick_stream(ctx, stream);
+  const size_t rec = group == BH_G1 ? 96 : 192;
+  void *table = ctx->c.pool.acquire(FIXED_BASE_TABLE_RECORDS * rec);
+  if (!table) return BH_ERR_HIP;
+  int rc = fixed_base_mul(group, base_affine_host, scalars_dev, n, fmt, out_dev, st, table);
+  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  ctx->c.pool.release(table);
+  return rc;
 }
 
 void bh_point_mul(int group, void *r, const void *a, const void *k_canonical) { host_point_mul(group, r, a, k_canonical); }

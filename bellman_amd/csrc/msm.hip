@@ -183,9 +183,9 @@ int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   return job.done_rc;
 }
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
-                   hipStream_t st) {
-  return group == BH_G1 ? fixed_base_mul_g1(base_host, scalars_dev, n, fmt, out_dev, st)
-                        : fixed_base_mul_g2(base_host, scalars_dev, n, fmt, out_dev, st);
+                   hipStream_t st, void *table_dev) {
+  return group == BH_G1 ? fixed_base_mul_g1(base_host, scalars_dev, n, fmt, out_dev, st, table_dev)
+                        : fixed_base_mul_g2(base_host, scalars_dev, n, fmt, out_dev, st, table_dev);
 }
 int points_check(int group, const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {
   return group == BH_G1 ? points_check_g1(pts_dev, n, status_dev, st) : points_check_g2(pts_dev, n, status_dev, st);

@@ -751,19 +751,60 @@ inline double sum_slot_factor(int kind) {
 // ============================================================================================
 // fixed-base scalar multiplication (fixture generation) and test hooks
 // ============================================================================================
+// out[i] = [s_i] base (generator.rs:271-296,398-421 use a windowed fixed-base table on the CPU; so does this).
+// [r4] Table T[j][d - 1] = d * 2^(8j) * base, j < 32, d = 1 .. 255 (affine; 0.8 MB for G1, 1.6 MB for G2, L2 resident): a
+// scalar is its 32 bytes, a multiplication is at most 32 mixed additions and no doubling at all - 320 field products
+// and one inversion instead of the 255 doublings + ~127 additions (3 600 products) of the double-and-add ladder this
+// replaces.  generate_parameters for a 2^20-constraint circuit is 4 x 2^20 G1 + 2^20 G2 such multiplications.
+constexpr u32 FB_ROWS = 32, FB_COLS = 255;
+// step 1: the row bases 2^(8j) * base (one lane per row: 8j doublings, one inversion)
 template <class F>
-__global__ void __launch_bounds__(128) fixed_base_mul_kernel(Affine<F> base, const void *scalars, int fmt, u64 n, Affine<F> *out) {
+__global__ void __launch_bounds__(64) fixed_base_rows_kernel(Affine<F> base, Affine<F> *table) {
+  const u32 j = threadIdx.x;
+  if (j >= FB_ROWS) return;
+  Affine<F> p = base;
+  if (j && !aff_is_identity(base)) {
+    XYZZ<F> acc, t;
+    xyzz_dbl_affine(acc, base);
+    for (u32 k = 1; k < 8 * j; k++) { xyzz_dbl(t, acc); acc = t; }
+    xyzz_to_affine(p, acc);
+  }
+  table[(size_t)j * FB_COLS] = p;
+}
+// step 2: d * (row base) for d = 2 .. 255 by double-and-add over the 8 bits of d (one lane per entry)
+template <class F>
+__global__ void __launch_bounds__(128) fixed_base_table_kernel(Affine<F> *table) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= FB_ROWS * FB_COLS) return;
+  const u32 j = e / FB_COLS, d = e % FB_COLS + 1;
+  if (d == 1) return;
+  const Affine<F> p = table[(size_t)j * FB_COLS];
+  Affine<F> r = p;
+  if (!aff_is_identity(p)) {
+    XYZZ<F> acc, t;
+    xyzz_set_identity(acc);
+    for (int b = 7; b >= 0; b--) {
+      xyzz_dbl(t, acc);
+      acc = t;
+      if ((d >> b) & 1) xyzz_madd(acc, p);
+    }
+    xyzz_to_affine(r, acc);
+  }
+  table[e] = r;
+}
+template <class F>
+__global__ void __launch_bounds__(128) fixed_base_mul_kernel(const Affine<F> *table, const void *scalars, int fmt, u64 n, Affine<F> *out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fr_t s;
   load_scalar(scalars, i, fmt, s);
   XYZZ<F> acc;
   xyzz_set_identity(acc);
-  for (int b = 254; b >= 0; b--) {
-    XYZZ<F> t;
-    xyzz_dbl(t, acc);
-    acc = t;
-    if ((s.l[b >> 5] >> (b & 31)) & 1) xyzz_madd(acc, base);
+  for (u32 j = 0; j < FB_ROWS; j++) {
+    const u32 d = (s.l[j >> 2] >> ((j & 3) * 8)) & 255u;
+    if (!d) continue;
+    const Affine<F> q = table[(size_t)j * FB_COLS + d - 1];
+    if (!aff_is_identity(q)) xyzz_madd(acc, q);   // (an identity base gives an all-identity table)
   }
   Affine<F> r;
   xyzz_to_affine(r, acc);
@@ -1231,12 +1272,17 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
 
 template <class F>
 static int fixed_base_mul_t(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
-                            hipStream_t st) {
+                            hipStream_t st, void *table_dev) {
   const u32 blocks = (u32)((n + 127) / 128);
   if (!blocks) return BH_OK;
   Affine<F> b;
   memcpy(&b, base_host, sizeof b);
-  hipLaunchKernelGGL(fixed_base_mul_kernel<F>, dim3(blocks), dim3(128), 0, st, b, scalars_dev, fmt, n,
+  Affine<F> *table = (Affine<F> *)table_dev;   // FB_ROWS * FB_COLS records, owned by the caller until `st` has drained
+  hipLaunchKernelGGL(fixed_base_rows_kernel<F>, dim3(1), dim3(64), 0, st, b, table);
+  BH_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(fixed_base_table_kernel<F>, dim3((FB_ROWS * FB_COLS + 127) / 128), dim3(128), 0, st, table);
+  BH_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(fixed_base_mul_kernel<F>, dim3(blocks), dim3(128), 0, st, (const Affine<F> *)table, scalars_dev, fmt, n,
                      (Affine<F> *)out_dev);
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
@@ -1411,8 +1457,8 @@ template <class F> static void devhdr_point_mul_t(void *r, const void *a, const 
     return msm_finish<OPS>(job, out_affine, ms);                                                              \
   }                                                                                                           \
   int fixed_base_mul_##SUFFIX(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,  \
-                              hipStream_t st) {                                                               \
-    return fixed_base_mul_t<OPS>(base_host, scalars_dev, n, fmt, out_dev, st);                                \
+                              hipStream_t st, void *table_dev) {                                              \
+    return fixed_base_mul_t<OPS>(base_host, scalars_dev, n, fmt, out_dev, st, table_dev);                     \
   }                                                                                                           \
   int points_check_##SUFFIX(const void *pts_dev, u64 n, u32 *status_dev, hipStream_t st) {                    \
     return points_check_t<OPS>(pts_dev, n, status_dev, st);                                                   \

@@ -121,8 +121,9 @@ int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
                    int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
 int msm_finish_g1(MsmJobImpl &job, void *out_affine, float *ms);   // ms: float[4] or null
 int msm_finish_g2(MsmJobImpl &job, void *out_affine, float *ms);
-int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
-int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st);
+int fixed_base_mul_g1(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st, void *table_dev);
+int fixed_base_mul_g2(const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev, hipStream_t st, void *table_dev);
+constexpr size_t FIXED_BASE_TABLE_RECORDS = 32 * 255;   // msm_ec.cuh FB_ROWS x FB_COLS
 // per-point status word of the uncompressed-point loader (api.hip decode kernel + point_check_kernel)
 enum PointStatus : u32 {
   PT_COMPRESSED = 1,        // compression flag set on an uncompressed point

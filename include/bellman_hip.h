@@ -311,7 +311,9 @@ int bh_msm_sharded_async(bh_ctx *const *ctxs, const bh_bases *const *shards, siz
 int bh_msm_sharded_wait(bh_msm_sharded_job *job, void *out_affine);
 
 /* ---- fixed-base scalar multiplication (fixture / CRS generation; SURVEY §8 f4,
- * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device */
+ * groth16/src/generator.rs:271-296,398-421): out[i] = [s_i] base, affine records on device.  Windowed like the
+ * reference's (a table of d * 2^(8j) * base is built on the device in front of the multiplications: at most 32 mixed
+ * additions per scalar, no doublings); the call returns when the results are in out_dev (it waits for the stream). */
 int bh_fixed_base_mul_dev(bh_ctx *ctx, int group, const void *base_affine_host,
                           const void *scalars_dev, size_t n, int scalar_fmt, void *out_dev,
                           void *stream);
