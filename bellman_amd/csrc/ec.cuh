@@ -46,9 +46,12 @@ BH_HD void store_xyzz(XYZZ<typename F::Mem> *p, const XYZZ<F> &q) {
   F::store(&p->zzz, q.zzz);
 }
 
+// affine records are CANONICAL wherever they come from (memory, xyzz_to_affine): the identity is the all-zero record, and
+// testing for it needs none of the "0 or p" comparisons of the lazily reduced is_zero (48 instructions fewer per base of
+// the bucket accumulation)
 template <class F>
 BH_HD bool aff_is_identity(const Affine<F> &p) {
-  return F::is_zero(p.x) && F::is_zero(p.y);
+  return F::is_zero_canonical(p.x, p.y);
 }
 template <class F>
 BH_HD void xyzz_set_identity(XYZZ<F> &p) {

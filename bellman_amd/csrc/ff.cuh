@@ -650,6 +650,12 @@ struct FpOps {
   BH_HD static void zero(T &r) { fe_zero(r); }
   BH_HD static void one(T &r) { fe_one(r); }
   BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a); }
+  BH_HD static bool is_zero_canonical(const T &a, const T &b) {   // both of two CANONICAL values are zero
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o |= a.l[i] | b.l[i];
+    return o == 0;
+  }
   BH_HD static bool eq(const T &a, const T &b) { return fpl_eq(a, b); }
   BH_HD static void add(T &r, const T &a, const T &b) { fpl_add(r, a, b); }
   BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub(r, a, b); }
@@ -703,6 +709,9 @@ struct Fp2Ops {
   BH_HD static void zero(T &r) { fe_zero(r.c0); fe_zero(r.c1); }
   BH_HD static void one(T &r) { fe_one(r.c0); fe_zero(r.c1); }
   BH_HD static bool is_zero(const T &a) { return fpl_is_zero(a.c0) && fpl_is_zero(a.c1); }
+  BH_HD static bool is_zero_canonical(const T &a, const T &b) {
+    return FpOps::is_zero_canonical(a.c0, a.c1) && FpOps::is_zero_canonical(b.c0, b.c1);
+  }
   BH_HD static bool eq(const T &a, const T &b) { return fpl_eq(a.c0, b.c0) && fpl_eq(a.c1, b.c1); }
   BH_HD static void add(T &r, const T &a, const T &b) { fpl_add2(r.c0, a.c0, b.c0, r.c1, a.c1, b.c1); }
   BH_HD static void sub(T &r, const T &a, const T &b) { fpl_sub2(r.c0, a.c0, b.c0, r.c1, a.c1, b.c1); }

@@ -101,6 +101,7 @@ struct Fp2K3Ops {
     for (int i = 0; i < 12; i++) r.l[i] = c1 ? 0u : FpParams::one(i);
   }
   __device__ __forceinline__ static bool is_zero(const T &a) { return k3_all(fpl_is_zero(a)); }
+  __device__ __forceinline__ static bool is_zero_canonical(const T &a, const T &b) { return k3_all(FpOps::is_zero_canonical(a, b)); }
   __device__ __forceinline__ static bool eq(const T &a, const T &b) {
     fp_t d;
     fpl_sub(d, a, b);

@@ -120,6 +120,7 @@ struct HostFpOps {
   static void zero(T &r) { memset(&r, 0, sizeof r); }
   static void one(T &r) { memcpy(r.l, hostfp::ONE, sizeof hostfp::ONE); }
   static bool is_zero(const T &a) { return hostfp::is_zero(a); }
+  static bool is_zero_canonical(const T &a, const T &b) { return hostfp::is_zero(a) && hostfp::is_zero(b); }
   static bool eq(const T &a, const T &b) { return hostfp::eq(a, b); }
   static void add(T &r, const T &a, const T &b) { hostfp::add(r, a, b); }
   static void sub(T &r, const T &a, const T &b) { hostfp::sub(r, a, b); }
@@ -138,6 +139,7 @@ struct HostFp2Ops {
   static void zero(T &r) { memset(&r, 0, sizeof r); }
   static void one(T &r) { B::one(r.c0); B::zero(r.c1); }
   static bool is_zero(const T &a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }
+  static bool is_zero_canonical(const T &a, const T &b) { return is_zero(a) && is_zero(b); }
   static bool eq(const T &a, const T &b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
   static void add(T &r, const T &a, const T &b) { B::add(r.c0, a.c0, b.c0); B::add(r.c1, a.c1, b.c1); }
   static void sub(T &r, const T &a, const T &b) { B::sub(r.c0, a.c0, b.c0); B::sub(r.c1, a.c1, b.c1); }
