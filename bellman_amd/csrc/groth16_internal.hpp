@@ -79,7 +79,9 @@ inline int run_guarded(const std::function<groth16::Proof()> &f, void *proof_out
 }
 
 struct bh_proof_job {
-  std::unique_ptr<groth16::AsyncProof> job;
+  // members are destroyed in reverse order: the job (whose destructor joins the helper thread) before the view of the
+  // constraint matrices that thread reads
   std::unique_ptr<R1csView> view;
+  std::unique_ptr<groth16::AsyncProof> job;
   int early_rc = BH_OK;
 };
