@@ -161,7 +161,12 @@ struct bh_bases {
   // Infinity Cache either way), -3 % at 2^22 (it does not).  Dense `dev` stays what every other path and the API see.
   // BELLMAN_HIP_BASE_PAD=0 switches it off; vectors whose copy would exceed 1/16 of the device memory are not padded.
   void *padded = nullptr;
+  // [r4] ... and the window table of a G1 vector too large for the Infinity Cache (>= 2^19 points: 16 rows of 2^19
+  // records are 0.8 GB) is KEPT at that stride only: `table` then holds W * n records of 128 bytes, read by the bucket
+  // accumulation alone (MsmOpts::padded_table); everything else of such a job reads the dense `dev`.
+  bool table_padded = false;
 };
+static inline size_t table_rec_bytes(const bh_bases *b) { return b->group == BH_G1 ? (b->table_padded ? 128 : 96) : 192; }
 // a scalar vector resident in HBM (bh_scalars_*): create_proof hands the same assignment to up to four multiexps
 struct bh_scalars {
   bh_ctx *ctx;
@@ -197,12 +202,20 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
   }
   return BH_OK;
 }
-// Base vectors of up to 2^18 (G1; 2^16 until round 4 - profiles/r4_call13_fft_batched_loads_and_plan_sweeps.txt: with a
-// table 2^17 1.04 vs 1.31 ms, 2^18 1.47 vs 1.72) / 2^22 (G2) points get their window table at registration
-// (BELLMAN_HIP_TABLE_MAX_LOG2 overrides both limits; 0 = never): a multiexp over a few thousand terms is a chain of
-// latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the windows and all but
-// one of its bucket reductions (the CRS is registered once per circuit).  Above those sizes the single bucket set's
-// deeper reduction tree and the table's cache footprint cost what the table saves (profiles/r2_call4_*).
+// Base vectors of up to 2^18 (G1) / 2^22 (G2) points get their window table at registration (BELLMAN_HIP_TABLE_MAX_LOG2
+// overrides both limits, BELLMAN_HIP_TABLE_MAX_LOG2_G1 the G1 limit alone; 0 = never): a multiexp over a few thousand
+// terms is a chain of latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the
+// windows and all but one of its bucket reductions (the CRS is registered once per circuit).
+// G1 history: 2^16 until round 4; 2^18 after profiles/r4_call13_fft_batched_loads_and_plan_sweeps.txt (2^17 1.04 vs
+// 1.31 ms, 2^18 1.47 vs 1.72).  2^19 ... 2^22 were measured and NOT adopted (profiles/r4_call16_g1_tables_2p19_2p22.txt,
+// r4_call17_g1_tables_in_proofs.txt): a multiexp called alone gets faster - the classic plan ends in a HOST tail of 256
+// doublings + 256 additions (16 windows x 16 bit sums, 0.27-0.44 ms by box), the table plan in 19 + 20: wall 2.21 vs
+// 2.67 ms at 2^19, 3.92-3.95 vs 4.09-4.28 at 2^20, 6.95 vs 7.42 at 2^21, 12.3 vs 13.5 at 2^22 - but its bucket
+// accumulation is slower per addition (2.89-2.94 vs 2.54-2.57 ms at 2^20: the same 16 n gathers come from a 2 GB table
+// in HBM instead of a 128 MB vector in the Infinity Cache), and wherever the host tail is hidden behind the next job
+// that is all that counts: two multiexps in flight 265 vs 282 M terms/s, a 2^20 proof 77.8 vs 74.9 ms (GPU part 23.6 vs
+// 20.7), twelve proof threads 37-40 vs 43-45 proofs/s.  A caller whose multiexps run one at a time can opt in with
+// BELLMAN_HIP_TABLE_MAX_LOG2_G1=22 (or bh_bases_precompute).
 static unsigned auto_table_max_log2(int group) {
   static const int v = [] {
     const char *e = getenv("BELLMAN_HIP_TABLE_MAX_LOG2");
@@ -210,11 +223,24 @@ static unsigned auto_table_max_log2(int group) {
     const long x = strtol(e, nullptr, 10);
     return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();
+  static const int v1 = [] {
+    const char *e = getenv("BELLMAN_HIP_TABLE_MAX_LOG2_G1");
+    if (!e || !*e) return -1;
+    const long x = strtol(e, nullptr, 10);
+    return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
+  }();
+  if (group == BH_G1 && v1 >= 0) return (unsigned)v1;
   return v >= 0 ? (unsigned)v : (group == BH_G1 ? 18u : 22u);
+}
+// G1 tables of 2^19 points and more are stored at a 128-byte record stride (bh_bases::table_padded);
+// BELLMAN_HIP_TABLE_PAD=0 keeps them dense
+static bool table_will_pad(const bh_bases *b) {
+  static const bool on = [] { const char *e = getenv("BELLMAN_HIP_TABLE_PAD"); return !(e && *e == '0'); }();
+  return on && b->group == BH_G1 && b->n >= ((size_t)1 << 19);
 }
 static size_t table_bytes_for(const bh_bases *b, unsigned c) {
   const u32 W = (256 + c - 1) / c;
-  return (size_t)W * b->n * (b->group == BH_G1 ? 96 : 192);
+  return (size_t)W * b->n * (b->group == BH_G1 ? (table_will_pad(b) ? 128 : 96) : 192);
 }
 static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
   bh_bases *b = new bh_bases{group, dev, n, owned};
@@ -262,6 +288,8 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
         b->auto_table = true;
         std::lock_guard<std::mutex> g(ctx->c.job_mu);
         ctx->c.tables.push_back(b);
+        const size_t actual = (size_t)b->tab.W * b->n * table_rec_bytes(b);   // (dense after all, if the padded copy did not fit)
+        if (actual < need) ctx->c.table_bytes -= need - actual;
       } else {
         std::lock_guard<std::mutex> g(ctx->c.job_mu);
         ctx->c.table_bytes -= need;
@@ -376,6 +404,7 @@ int bh_ctx_trim(bh_ctx *ctx) {
     for (bh_bases *b : ctx->c.tables) {
       if (b->table) (void)hipFree(b->table);
       b->table = nullptr;
+      b->table_padded = false;
       b->auto_table = false;
     }
     if (ctx->c.inflight.empty() && ctx->c.issuing == 0) {
@@ -818,11 +847,11 @@ int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits) {
     auto &v = ctx->c.tables;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i] == b) { v.erase(v.begin() + i); break; }
-    const size_t bytes = (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192);
+    const size_t bytes = (size_t)b->tab.W * b->n * table_rec_bytes(b);
     ctx->c.table_bytes = ctx->c.table_bytes > bytes ? ctx->c.table_bytes - bytes : 0;
     b->auto_table = false;
   }
-  if (b->table) { (void)hipFree(b->table); b->table = nullptr; }
+  if (b->table) { (void)hipFree(b->table); b->table = nullptr; b->table_padded = false; }
   if (b->n == 0) return BH_OK;
   const u32 c = window_bits ? window_bits : table_window_bits(b->n, b->group == BH_G2);
   if (c < 2 || c > 24) return BH_ERR_INVALID_ARG;
@@ -841,7 +870,27 @@ int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits) {
   if (rc == BH_OK) rc = window_table(b->group, t, b->n, c, W, st);
   if (rc == BH_OK && hipStreamSynchronize(st) != hipSuccess) rc = BH_ERR_HIP;
   if (rc != BH_OK) { (void)hipFree(t); return rc; }
+  bool padded = false;
+  if (table_will_pad(b)) {
+    // re-laid at a 128-byte stride (one cache line per gathered record); the dense build buffer is dropped.  If the
+    // second allocation fails the dense table is kept - it is the same table
+    void *tp = nullptr;
+    if (hipMalloc(&tp, (size_t)W * b->n * 128) == hipSuccess) {
+      if (hipMemcpy2DAsync(tp, 128, t, rec, rec, (size_t)W * b->n, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+          hipStreamSynchronize(st) == hipSuccess) {
+        (void)hipFree(t);
+        t = tp;
+        padded = true;
+      } else {
+        (void)hipGetLastError();
+        (void)hipFree(tp);
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   b->table = t;
+  b->table_padded = padded;
   b->tab = WindowTable{c, W, (u64)b->n};
   return BH_OK;
 }
@@ -849,7 +898,7 @@ int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows
   if (!b) return BH_ERR_INVALID_ARG;
   if (window_bits) *window_bits = b->table ? b->tab.c : 0;
   if (rows) *rows = b->table ? b->tab.W : 0;
-  if (bytes) *bytes = b->table ? (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192) : 0;
+  if (bytes) *bytes = b->table ? (size_t)b->tab.W * b->n * table_rec_bytes(b) : 0;
   return BH_OK;
 }
 void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
@@ -860,7 +909,7 @@ void bh_bases_release(bh_ctx *ctx, bh_bases *b) {
     auto &v = b->ctx->c.tables;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i] == b) { v.erase(v.begin() + i); break; }
-    const size_t bytes = (size_t)b->tab.W * b->n * (b->group == BH_G1 ? 96 : 192);
+    const size_t bytes = (size_t)b->tab.W * b->n * table_rec_bytes(b);
     b->ctx->c.table_bytes = b->ctx->c.table_bytes > bytes ? b->ctx->c.table_bytes - bytes : 0;
   }
   if (b->table) (void)hipFree(b->table);
@@ -940,7 +989,9 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
-  opts.padded_bases = bases->table ? nullptr : bases->padded;
+  opts.padded_bases = bases->padded;   // (read by the classic plan only)
+  const bool ptab = bases->table && bases->table_padded;
+  opts.padded_table = ptab ? bases->table : nullptr;
   if (o) {
     if (o->window_bits && (o->window_bits < 2 || o->window_bits > 24)) return BH_ERR_INVALID_ARG;
     opts.c = o->window_bits; opts.chunk = o->chunk; opts.flags = o->flags;
@@ -989,7 +1040,7 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     }
   }
   if (rc == BH_OK)
-    rc = msm_job_enqueue(*impl, bases->table ? bases->table : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
+    rc = msm_job_enqueue(*impl, (bases->table && !ptab) ? bases->table : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
                          opts, bases->table ? &bases->tab : nullptr);
   if (rc != BH_OK) {
     float ms[4];

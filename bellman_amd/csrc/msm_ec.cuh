@@ -904,6 +904,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // fit the 31-bit base field of a pair
   const bool use_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c) &&
                          (u64)table->W * table->stride < ((u64)1 << 31) && (u64)table->W * n < ((u64)1 << 32);
+  if (opts.padded_table && G2) return BH_ERR_INVALID_ARG;   // only G1 tables are laid out at a 128-byte stride
   const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, G2, c.num_cus)
                               : make_plan(n, opts.c, opts.chunk, G2);
   // running bucket sum in LDS: only meaningful for the single-lane G2 kernel (its default), or when forced
@@ -975,7 +976,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 *sorted = nullptr;
   // small multiexps over a window table: one launch for everything up to the filled buckets (msm_small_fill_kernel)
   static const bool small_on = [] { const char *e = getenv("BELLMAN_HIP_SMALL_FUSED"); return !(e && *e == '0'); }();
-  const bool small_fused = small_on && use_table && p.W == 1 && p.nd <= SMALL_MAX_SCALARS && p.n <= SMALL_MAX_ENTRIES &&
+  const bool small_fused = small_on && use_table && !opts.padded_table && p.W == 1 && p.nd <= SMALL_MAX_SCALARS && p.n <= SMALL_MAX_ENTRIES &&
                            (u64)p.n <= (u64)SMALL_MAX_PER_BUCKET * p.nb && p.c <= 15 && small_fill_lds_bytes(p.nd, p.n) <= 64 * 1024 &&
                            !(opts.flags & BH_MSM_NO_SMALL_PATH);
   if (small_fused) {
@@ -1015,6 +1016,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     const Affine<M> *bases = (const Affine<M> *)bases_dev;
     // G1 records at a 128-byte stride for the gathers of the classic plan (api.hip bh_bases::padded)
     const bool padded = opts.padded_bases && !use_table && !G2 && F::LANES == 1 && !lds_acc;
+    // ... and of the table plan, when the table is one that was laid out that way (bh_bases::table_padded)
+    const bool padded_tab = opts.padded_table && use_table;
     // launches that fill the chip join the context's accumulation chain (common.hpp)
     static const bool chain_on = [] { const char *e = getenv("BELLMAN_HIP_ACC_CHAIN"); return !(e && *e == '0'); }();
     const bool chained = chain_on && (u64)grid.x * grid.y * 128 >= (u64)c.num_cus * 4 * 64;
@@ -1026,17 +1029,19 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       for (hipEvent_t ev : c.pending_barriers) BH_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));   // bh_ctx_accumulations_after
       c.pending_barriers.clear();
     }
+    // (every variant of the kernel takes the record stride, so a padded table is read correctly by all of them)
+    const Affine<M> *acc_bases = padded_tab ? (const Affine<M> *)opts.padded_table : padded ? (const Affine<M> *)opts.padded_bases : bases;
+    const u32 acc_stride = (padded || padded_tab) ? 128u : (u32)sizeof(Affine<M>);
     if constexpr (F::LANES == 1) {
       if (lds_acc)
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
-                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, (u32)sizeof(Affine<M>));
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
       else
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart,
-                           padded ? (const Affine<M> *)opts.padded_bases : bases, pts, head, tail, p.n, p.c, p.chunk,
-                           p.chunks_per_window, err, padded ? 128u : (u32)sizeof(Affine<M>));
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
     } else {
-      hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, bases, pts, head,
-                         tail, p.n, p.c, p.chunk, p.chunks_per_window, err, (u32)sizeof(Affine<M>));
+      hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
+                         tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
     }
     BH_HIP_CHECK(hipGetLastError());
     if (chained) {

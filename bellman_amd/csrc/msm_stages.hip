@@ -287,9 +287,13 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // (profiles/r2_call19_table_bits_tiny.txt: 2^9 0.65 vs 0.80 ms, 2^10 0.72 vs 0.81, 2^11 0.85 vs 0.91; G1: no difference)
   // [r4] re-swept with the lane-pair G2 accumulation and the fused G1 formula (profiles/r4_call13_*): G2 2^15 takes the
   // 8-bit table (1.43 vs 1.53-1.54 ms with 13 / 16 bits); G1 tables now reach 2^18 (16 bits: 1.06 / 1.47 ms at 2^17 / 2^18)
+  // [r4, call 16] G1 2^19-2^22 (not built automatically - api.hip auto_table_max_log2 - but on request; the tables of
+  // 2^19 points and more are kept at a 128-byte record stride): 16 bits up to 2^20 (wall 2.21 / 3.95 ms against 2.72 / 4.15
+  // with 20 bits), 20 bits above (2^21 6.95 vs 7.47 ms with 16 bits; 2^22 12.3 vs 14.2) -
+  // profiles/r4_call16_g1_tables_2p19_2p22.txt
   if (lg <= 11) return g2 ? 8 : 13;
   if (g2) return lg == 15 ? 8 : 16;
-  return (lg == 15 || lg == 16) ? 13 : lg <= 18 ? 16 : 20;
+  return (lg == 15 || lg == 16) ? 13 : lg <= 20 ? 16 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {

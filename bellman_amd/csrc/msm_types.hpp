@@ -40,6 +40,9 @@ struct MsmOpts {
   u64 ref_n = 0;
   bool always_resolve_ident = false;
   const void *padded_bases = nullptr;   // the same G1 records at a 128-byte stride (api.hip bh_bases::padded); null: none
+  // a G1 window table whose records sit at a 128-byte stride (api.hip bh_bases::table_padded): only the bucket
+  // accumulation of the table plan reads it; `bases_dev` of such a job is the dense base vector itself
+  const void *padded_table = nullptr;
 };
 
 struct MsmPlan {

@@ -3,7 +3,9 @@
 tables) sit under every multiexp / FFT test of the suite; here are the cases that need a special set-up:
 
   * the FFT's two-level tables (what sizes above 2^24 and a failed table allocation use) at sizes that take the
-    one-level tables by default (src/domain.rs:81-125).
+    one-level tables by default (src/domain.rs:81-125);
+  * the G1 window table at a 128-byte record stride (vectors of 2^19 ... 2^22 points) under every variant of the bucket
+    accumulation and against the classic plan over the same vector (src/multiexp.rs:210-332).
 Integer work: every limb equal, no tolerances."""
 
 import os
@@ -111,3 +113,80 @@ def test_large_host_scalar_multiexp_error_semantics(worker):
         h2s.release()
     for h in (hb, hs, ht):
         h.release()
+
+
+def test_g1_window_table_at_128_byte_stride(worker):
+    """A G1 vector of 2^19 points with its window table re-laid at a 128-byte record stride (api.hip
+    bh_bases::table_padded; 16-bit and 20-bit rows): the multiexp over it == the classic 16-window plan over the dense
+    vector == [sum s_i t_i]G, with full density, with a density map + skip, with a forced chunk length and with the
+    LDS-accumulator variant of the kernel (every variant takes the record stride).  Then the error semantics of
+    src/multiexp.rs:55-80,295-300 on that path - the error-resolution kernel reads the dense vector, not the table: an
+    identity base under a full-size / small / zero scalar, running out of bases, and both at once == what the classic plan
+    reports for the same inputs (itself == the oracle in test_large_host_scalar_multiexp_error_semantics).  (Such tables
+    are built on request - bh_bases_precompute, BELLMAN_HIP_TABLE_MAX_LOG2_G1 - not automatically:
+    profiles/r4_call17_g1_tables_in_proofs.txt.)"""
+    import bellman_amd
+    import importlib
+    from oracle import cref
+    from tests.test_gpu_scale import _device_bases, _splitmix
+
+    mx = importlib.import_module("bellman_amd.multiexp")
+    n = 1 << 19
+    t = _splitmix(n, 4190)
+    bases, _host, gen = _device_bases(worker, 1, t, table=False)   # a wrapped device vector: no table yet
+    sc = _splitmix(n, 4191)
+    rnd = np.random.default_rng(419)
+    m, skip = n - 4321, 5
+    bits = rnd.random(m) < 0.5
+    dt = bellman_amd.DensityTracker()
+    dt.bv = bits
+    cases = [("full", dict(density_map=bellman_amd.FullDensity(), exponents=sc)),
+             ("short + skip", dict(density_map=bellman_amd.FullDensity(), exponents=sc[: n - 12345], skip=777)),
+             ("density + skip", dict(density_map=dt, exponents=sc[:m], skip=skip))]
+    want = {name: bellman_amd.multiexp(worker, bases, flags=mx.NO_TABLE, **kw).wait() for name, kw in cases}
+    assert np.array_equal(want["full"], cref.point_mul(1, gen, cref.fr_dot(sc, t)))
+    assert np.array_equal(want["density + skip"], cref.point_mul(1, gen, cref.fr_dot(sc[:m][bits], t[skip:skip + int(bits.sum())])))
+    for c in (16, 20):
+        bases.precompute(c)
+        c_used, rows, nbytes = bases.table_info()
+        assert c_used == c and rows == (256 + c - 1) // c and nbytes == rows * n * 128   # one cache line per record
+        for name, kw in cases:
+            for flags, chunk in ((0, 0), (mx.ACC_LDS, 0), (0, 64), (mx.NO_SMALL_PATH, 0)):
+                got = bellman_amd.multiexp(worker, bases, flags=flags, chunk=chunk, **kw).wait()
+                assert np.array_equal(got, want[name]), (c, name, flags, chunk)
+    bases.release()
+
+    from bellman_amd import UnexpectedEof, UnexpectedIdentity
+
+    def outcome(hb, scalars, flags):
+        try:
+            return 0, bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), scalars, flags=flags).wait()
+        except UnexpectedIdentity:
+            return 1, None
+        except UnexpectedEof:
+            return 2, None
+
+    full = sc.copy()
+    full[:, 3] |= np.uint64(1 << 60)          # a non-zero top-window digit everywhere
+    small = full.copy()
+    small[17] = cref.ints_to_arr([5], 4)[0]   # the identity base is then met in window 0 only
+    zero = full.copy()
+    zero[17] = 0
+    b2 = _host.copy()
+    b2[17] = 0                                # identity record
+    expect = {}
+    for tag, bs in (("identity", b2), ("identity, one base short", b2[:-1]), ("one base short", _host[:-1])):
+        hb = bellman_amd.Bases(worker, 1, bs)
+        assert hb.table_info() == (0, 0, 0)
+        for sname, scal in (("full", full), ("small", small), ("zero", zero)):
+            expect[tag, sname] = outcome(hb, scal, mx.NO_TABLE)
+        hb.precompute(16)
+        assert hb.table_info()[2] == 16 * len(bs) * 128
+        for sname, scal in (("full", full), ("small", small), ("zero", zero)):
+            rc, val = outcome(hb, scal, 0)
+            assert rc == expect[tag, sname][0], (tag, sname, rc, expect[tag, sname][0])
+            if rc == 0:
+                assert np.array_equal(val, expect[tag, sname][1]), (tag, sname)
+        hb.release()
+    assert expect["identity", "full"][0] == 1 and expect["identity", "zero"][0] == 0 and expect["one base short", "full"][0] == 2
+    assert expect["identity, one base short", "full"][0] == 1 and expect["identity, one base short", "small"][0] == 2

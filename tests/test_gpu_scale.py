@@ -75,10 +75,12 @@ def _device_bases(worker, group, t, table=False):
     return bases, host, gen
 
 
-@pytest.mark.parametrize("group,log_n,table", [(1, 23, False), (1, 26, False), (2, 20, False), (2, 22, True)])
+@pytest.mark.parametrize("group,log_n,table", [(1, 19, True), (1, 21, True), (1, 23, False), (1, 26, False), (2, 20, False), (2, 22, True)])
 def test_msm_c5_scale_matches_oracle(worker, group, log_n, table):
     """multiexp over 2^log_n terms == restated multiexp_inner on all host cores, and == [sum s_i t_i]G.  G2 2^20 runs the
-    classic 16-window plan (one lane per point, 2^19 buckets), G2 2^22 the window-table plan a registered CRS query gets."""
+    classic 16-window plan (one lane per point, 2^19 buckets), G2 2^22 the window-table plan a registered CRS query gets;
+    G1 2^19 (16-bit rows) and 2^21 (20-bit rows) the window table kept at a 128-byte record stride (api.hip
+    bh_bases::table_padded) that G1 queries of 2^19 ... 2^22 points get since round 4."""
     import bellman_amd
 
     n = 1 << log_n
