@@ -427,6 +427,14 @@ void bh_ctx_destroy(bh_ctx *ctx) {
   for (auto &kv : ctx->c.fft_tables) fft_tables_free(kv.second);
   fft_master_free(ctx->c);
   ctx->c.pool.release_all();
+  {
+    // base handles that outlive the context (a host that releases them later - Python objects collected after the
+    // Worker was closed) keep their memory, tables included, and must not reach back into the context's bookkeeping
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    for (bh_bases *b : ctx->c.tables) { b->auto_table = false; b->ctx = nullptr; }
+    ctx->c.tables.clear();
+    ctx->c.table_bytes = 0;
+  }
   for (auto &r : ctx->c.job_pool) {
     for (int i = 0; i < 4; i++) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
     if (r.dep_event) (void)hipEventDestroy(r.dep_event);

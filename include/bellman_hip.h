@@ -53,6 +53,9 @@ typedef struct bh_msm_job bh_msm_job; /* an MSM in flight == bellman's Waiter<Re
 
 /* ---- context: replaces multicore::Worker::new() (src/multicore.rs:24-27) ------------- */
 int bh_ctx_create(int device, bh_ctx **out);
+/* Waits for the device, then frees the context's pools, streams and tables.  Jobs must have been waited on.  Base
+ * handles (bh_bases) may be released before or AFTER this call: a handle that outlives its context keeps its own
+ * device memory until bh_bases_release and can no longer be used for a multiexp. */
 void bh_ctx_destroy(bh_ctx *ctx);
 /* Worker::log_num_threads analogue (src/multicore.rs:29-31): log2 of the CU count. */
 uint32_t bh_ctx_log_num_cus(const bh_ctx *ctx);
