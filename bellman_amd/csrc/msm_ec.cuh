@@ -60,7 +60,7 @@ __device__ __forceinline__ bool worker_index(u32 per_wave, u32 &in_block, u32 &g
 template <class F>
 __global__ void msm_err_resolve_kernel(const void *scalars, int fmt, u32 n, const u64 *density,
                                        const u32 *word_prefix, u64 skip, u64 n_bases,
-                                       const Affine<F> *bases, u32 lo_ref, ErrFlags *err) {
+                                       const Affine<F> *bases, u32 base_stride, u32 lo_ref, ErrFlags *err) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 k = skip + i;
@@ -75,7 +75,9 @@ __global__ void msm_err_resolve_kernel(const void *scalars, int fmt, u32 n, cons
   bool top_nonzero = false;
   for (u32 b = lo_ref; b < 256; b += 16) top_nonzero |= extract_bits(s, b, (256 - b) < 16 ? (256 - b) : 16) != 0;
   if (!top_nonzero) return;
-  if (aff_is_identity(bases[k])) atomicOr(&err->ident_top, 1u);
+  // (the records the bucket accumulation of this job read: `base_stride` bytes apart)
+  if (aff_is_identity(*reinterpret_cast<const Affine<F> *>(reinterpret_cast<const char *>(bases) + (size_t)k * base_stride)))
+    atomicOr(&err->ident_top, 1u);
 }
 
 // ============================================================================================
@@ -967,7 +969,12 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   ErrFlags *err = b.err;
   job.err_dev = err;
   job.scalars_dev = scalars_dev; job.density_dev = density_dev; job.word_prefix = b.word_prefix;
-  job.bases_dev = bases_dev; job.skip = skip; job.n_bases = n_bases; job.fmt = fmt;
+  // what the error-resolution pass reads is what the accumulation reads: row 0 of a table at the 128-byte stride if
+  // that is this job's source (a snapshot, like every table), else the base vector / row 0 of a dense table
+  const bool from_padded_table = use_table && opts.padded_table;
+  job.bases_dev = from_padded_table ? opts.padded_table : bases_dev;
+  job.bases_stride = from_padded_table ? 128u : (u32)sizeof(Affine<M>);
+  job.skip = skip; job.n_bases = n_bases; job.fmt = fmt;
   job.ref_n = opts.ref_n; job.always_resolve_ident = opts.always_resolve_ident;
 
   job.timed = (opts.flags & BH_MSM_STAGE_TIMES) != 0;
@@ -1253,7 +1260,7 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
       const u32 c_ref = (u32)cref, w_ref = (255 + c_ref - 1) / c_ref, lo_ref = c_ref * (w_ref - 1);
       hipLaunchKernelGGL(msm_err_resolve_kernel<F>, dim3((p.nd + 255) / 256), dim3(256), 0, job.stream,
                          job.scalars_dev, job.fmt, p.nd, job.density_dev, job.word_prefix, job.skip, job.n_bases,
-                         (const Affine<F> *)job.bases_dev, lo_ref, job.err_dev);
+                         (const Affine<F> *)job.bases_dev, job.bases_stride, lo_ref, job.err_dev);
       if (hipMemcpyAsync(&ef, job.err_dev, sizeof ef, hipMemcpyDeviceToHost, job.stream) != hipSuccess ||
           hipStreamSynchronize(job.stream) != hipSuccess)
         rc = BH_ERR_HIP;

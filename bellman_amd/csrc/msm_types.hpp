@@ -86,6 +86,7 @@ struct MsmJobImpl {
   const u64 *density_dev = nullptr;
   const u32 *word_prefix = nullptr;
   const void *bases_dev = nullptr;
+  u32 bases_stride = 0;              // bytes between the records of `bases_dev`
   u64 skip = 0, n_bases = 0;
   int fmt = 0;
   ErrFlags *err_dev = nullptr;
