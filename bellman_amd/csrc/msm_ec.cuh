@@ -1256,8 +1256,8 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     if (ef.ident && (ef.eof || job.always_resolve_ident)) {
       // both kinds of failure exist (or the caller folds shards): the reference reports the top window's first failure
       const u64 nref = job.ref_n ? job.ref_n : p.nd;
-      const double cref = (nref < 32) ? 3.0 : std::ceil(std::log((double)nref));   // multiexp.rs:318-322
-      const u32 c_ref = (u32)cref, w_ref = (255 + c_ref - 1) / c_ref, lo_ref = c_ref * (w_ref - 1);
+      const double c_ln = (nref < 32) ? 3.0 : std::ceil(std::log((double)nref));   // multiexp.rs:318-322
+      const u32 c_ref = (u32)c_ln, w_ref = (255 + c_ref - 1) / c_ref, lo_ref = c_ref * (w_ref - 1);
       hipLaunchKernelGGL(msm_err_resolve_kernel<F>, dim3((p.nd + 255) / 256), dim3(256), 0, job.stream,
                          job.scalars_dev, job.fmt, p.nd, job.density_dev, job.word_prefix, job.skip, job.n_bases,
                          (const Affine<F> *)job.bases_dev, job.bases_stride, lo_ref, job.err_dev);
