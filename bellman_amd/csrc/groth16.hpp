@@ -371,6 +371,8 @@ class Parameters {
              const Fr &gamma, const Fr &delta, const Fr &tau);
   // Parameters::write (groth16/src/lib.rs:258-287)
   std::vector<unsigned char> write() const;
+  size_t serialized_size() const;                            // bytes `write` produces
+  void write_into(unsigned char *dst, size_t cap) const;     // the same bytes into the caller's buffer (no intermediate copy)
   ~Parameters();
   Parameters(const Parameters &) = delete;
   bh_ctx *ctx;

@@ -60,13 +60,10 @@ int bh_groth16_params_write(const bh_params *p, void *buf, size_t cap, size_t *l
   if (!p || !len) return BH_ERR_INVALID_ARG;
   try {
     const groth16::Parameters &P = *p->p;
-    size_t need = 864 + 4 + P.vk.ic.size() * 96 + 5 * 4;
-    const bh_bases *qs[5] = {P.h, P.l, P.a, P.b_g1, P.b_g2};
-    for (int q = 0; q < 5; q++) need += bh_bases_len(qs[q]) * (q < 4 ? 96 : 192);
+    const size_t need = P.serialized_size();
     *len = need;
     if (!buf || cap < need) return buf ? BH_ERR_INVALID_ARG : BH_OK;   // size query when buf == NULL
-    std::vector<unsigned char> o = P.write();
-    memcpy(buf, o.data(), o.size());
+    P.write_into((unsigned char *)buf, cap);
     return BH_OK;
   } catch (const bellman::SynthesisError &e) { return e.code;
   } catch (...) { return BH_ERR_HIP; }

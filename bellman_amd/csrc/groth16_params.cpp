@@ -198,22 +198,36 @@ void put_u32(std::vector<unsigned char> &o, size_t v) {
 }
 }  // namespace
 
-std::vector<unsigned char> Parameters::write() const {
-  std::vector<unsigned char> o;
-  put_g1(o, vk.alpha_g1); put_g1(o, vk.beta_g1); put_g2(o, vk.beta_g2); put_g2(o, vk.gamma_g2);
-  put_g1(o, vk.delta_g1); put_g2(o, vk.delta_g2);
-  put_u32(o, vk.ic.size());
-  for (const G1Affine &p : vk.ic) put_g1(o, p);
+size_t Parameters::serialized_size() const {
+  size_t need = 3 * 96 + 3 * 192 + 4 + vk.ic.size() * 96;   // alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2, |ic|, ic
+  const bh_bases *qs[5] = {h, l, a, b_g1, b_g2};
+  for (int q = 0; q < 5; q++) need += 4 + bh_bases_len(qs[q]) * (q < 4 ? 96 : 192);
+  return need;
+}
+// The five queries are encoded on the device and copied straight into `dst` (bh_bases_write_uncompressed): round 3's host
+// loop over 2.6 M points took 1.05 s of the 1.09 s this call needed for a 2^20-constraint CRS; the growing vector it
+// went through until late in round 4 (three reallocation copies, 450 MB of zero fill, one more copy into the C caller's
+// buffer) was most of the 0.36 s that were left.
+void Parameters::write_into(unsigned char *dst, size_t cap) const {
+  if (cap < serialized_size()) throw std::runtime_error("Parameters::write_into: buffer too small");
+  std::vector<unsigned char> head;   // the verifying key: a few hundred bytes, encoded on the host
+  put_g1(head, vk.alpha_g1); put_g1(head, vk.beta_g1); put_g2(head, vk.beta_g2); put_g2(head, vk.gamma_g2);
+  put_g1(head, vk.delta_g1); put_g2(head, vk.delta_g2);
+  put_u32(head, vk.ic.size());
+  for (const G1Affine &p : vk.ic) put_g1(head, p);
+  memcpy(dst, head.data(), head.size());
+  size_t at = head.size();
   const bh_bases *qs[5] = {h, l, a, b_g1, b_g2};
   for (int q = 0; q < 5; q++) {
-    const size_t n = bh_bases_len(qs[q]);
-    put_u32(o, n);
-    // [r4] encoded on the device (bh_bases_write_uncompressed): the host loop over 2.6 M points took 1.05 s of the
-    // 1.09 s this call needed for a 2^20-constraint CRS
-    const size_t rec = q < 4 ? 96 : 192, at = o.size();
-    o.resize(at + n * rec);
-    if (n) check(bh_bases_write_uncompressed(ctx, qs[q], 0, n, &o[at]));
+    const size_t n = bh_bases_len(qs[q]), rec = q < 4 ? 96 : 192;
+    for (int sft = 24; sft >= 0; sft -= 8) dst[at++] = (unsigned char)(n >> sft);
+    if (n) check(bh_bases_write_uncompressed(ctx, qs[q], 0, n, dst + at));
+    at += n * rec;
   }
+}
+std::vector<unsigned char> Parameters::write() const {
+  std::vector<unsigned char> o(serialized_size());
+  write_into(o.data(), o.size());
   return o;
 }
 

@@ -169,7 +169,7 @@ class Parameters:
         device-resident parameters; decoding and validation run on the GPU.  Raises UnexpectedEof,
         InvalidPoint or PointAtInfinity - whichever the reference's sequential reader hits first."""
         lib = _lib.load()
-        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        buf = np.frombuffer(data, dtype=np.uint8)   # bytes, bytearray or any buffer: no copy
         self = cls.__new__(cls)
         self.worker = worker
         h_ = ctypes.c_void_p()
@@ -203,9 +203,11 @@ class Parameters:
         lib = _lib.load()
         n = ctypes.c_size_t()
         check(lib.bh_groth16_params_write(self._h, None, 0, ctypes.byref(n)), "Parameters.write")
-        buf = np.zeros(n.value, dtype=np.uint8)
-        check(lib.bh_groth16_params_write(self._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n)), "Parameters.write")
-        return buf.tobytes()
+        out = bytearray(n.value)   # (a bytes-like Vec<u8>: compares equal to bytes; no second copy of half a gigabyte)
+        view = (ctypes.c_ubyte * n.value).from_buffer(out)
+        check(lib.bh_groth16_params_write(self._h, ctypes.cast(view, ctypes.c_void_p), n.value, ctypes.byref(n)), "Parameters.write")
+        del view
+        return out
 
     def vk_ext(self):
         """gamma_g2 ([24] uint64) and ic ([n,12] uint64): the verifier-side key elements"""
