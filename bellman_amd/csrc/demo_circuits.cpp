@@ -210,6 +210,24 @@ void bh_test_fr_from_u512_host(void *r, const void *limbs8) {
   const bellman::Fr f = bellman::Fr::from_u512(w);
   memcpy(r, &f, 32);
 }
+void bh_test_fr_ops_host(int op, void *r, const void *a, const void *b, size_t n) {
+  using bellman::Fr;
+  for (size_t i = 0; i < n; i++) {
+    Fr x, y = Fr::zero(), z;
+    memcpy(&x, (const char *)a + 32 * i, 32);
+    if (b) memcpy(&y, (const char *)b + 32 * i, 32);
+    switch (op) {
+      case 0: z = x + y; break;
+      case 1: z = x - y; break;
+      case 2: z = x * y; break;
+      case 3: z = x.neg(); break;
+      case 4: z = Fr::from_u64(x.l[0]); break;
+      case 5: x.to_canonical(z.l); break;
+      default: z = x.invert(); break;
+    }
+    memcpy((char *)r + 32 * i, &z, 32);
+  }
+}
 int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants, bh_r1cs **out) {
   if (!ctx || !out) return BH_ERR_INVALID_ARG;
   return with_demo_circuit(circuit_kind, size, seed, nullptr, constants, [&](bellman::Circuit &c) -> int {

@@ -14,6 +14,9 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <x86intrin.h>   // _addcarry_u64 / _subborrow_u64 (the host-side field arithmetic below)
+#endif
 
 #include <deque>
 #include <exception>
@@ -39,22 +42,101 @@ constexpr uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x333
 constexpr uint64_t INV = 0xfffffffeffffffffULL;
 constexpr uint64_t R[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
 constexpr uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
-inline bool geq_mod(const uint64_t *a) {
-  for (int i = 3; i >= 0; i--) {
-    if (a[i] > MOD[i]) return true;
-    if (a[i] < MOD[i]) return false;
-  }
-  return true;
+// add / subtract with carry as the instruction the CPU has for it (the 128-bit-integer spelling of a borrow chain compiles to
+// three or four instructions per limb with clang and g++ alike)
+#if defined(__x86_64__)
+typedef unsigned char carry_t;
+__attribute__((always_inline)) inline uint64_t adc(uint64_t a, uint64_t b, carry_t &c) {
+  unsigned long long r; c = _addcarry_u64(c, a, b, &r); return r;
 }
-inline void sub_mod(uint64_t *a) {
-  u128 br = 0;
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)a[i] - MOD[i] - (uint64_t)br;
-    a[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
+__attribute__((always_inline)) inline uint64_t sbb(uint64_t a, uint64_t b, carry_t &c) {
+  unsigned long long r; c = _subborrow_u64(c, a, b, &r); return r;
 }
-// 4x64 CIOS Montgomery product, fully unrolled (synthesis is the serial part of create_proof)
+#else
+typedef uint64_t carry_t;
+__attribute__((always_inline)) inline uint64_t adc(uint64_t a, uint64_t b, carry_t &c) {
+  const u128 x = (u128)a + b + c; c = (uint64_t)(x >> 64); return (uint64_t)x;
+}
+__attribute__((always_inline)) inline uint64_t sbb(uint64_t a, uint64_t b, carry_t &c) {
+  const u128 x = (u128)a - b - c; c = (uint64_t)(x >> 64) & 1; return (uint64_t)x;
+}
+#endif
+__attribute__((always_inline)) inline uint64_t sel(uint64_t mask, uint64_t if_set, uint64_t if_clear) {
+  return if_clear ^ ((if_clear ^ if_set) & mask);
+}
+// Whether a sum, a difference or a product needs its final correction is a coin flip for random field elements: the
+// corrections below are selections by mask, not branches (a mispredicted branch costs more than the addition itself).
+// t < 2q in four limbs -> [0, q)
+__attribute__((always_inline)) inline void final_sub(uint64_t *r, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3) {
+  carry_t b = 0;
+  const uint64_t d0 = sbb(t0, MOD[0], b), d1 = sbb(t1, MOD[1], b), d2 = sbb(t2, MOD[2], b), d3 = sbb(t3, MOD[3], b);
+  const uint64_t keep = 0 - (uint64_t)b;   // all ones: t < q
+  r[0] = sel(keep, t0, d0); r[1] = sel(keep, t1, d1); r[2] = sel(keep, t2, d2); r[3] = sel(keep, t3, d3);
+}
+__attribute__((always_inline)) inline void add_mod(uint64_t *r, const uint64_t *a, const uint64_t *b) {   // a, b < q
+  carry_t c = 0;
+  const uint64_t s0 = adc(a[0], b[0], c), s1 = adc(a[1], b[1], c), s2 = adc(a[2], b[2], c), s3 = adc(a[3], b[3], c);
+  final_sub(r, s0, s1, s2, s3);   // q < 2^255: the sum has no carry out
+}
+__attribute__((always_inline)) inline void sub_mod(uint64_t *r, const uint64_t *a, const uint64_t *b) {   // a, b < q
+  carry_t c = 0;
+  const uint64_t d0 = sbb(a[0], b[0], c), d1 = sbb(a[1], b[1], c), d2 = sbb(a[2], b[2], c), d3 = sbb(a[3], b[3], c);
+  const uint64_t m = 0 - (uint64_t)c;   // borrowed: add q back
+  c = 0;
+  r[0] = adc(d0, MOD[0] & m, c); r[1] = adc(d1, MOD[1] & m, c); r[2] = adc(d2, MOD[2] & m, c); r[3] = adc(d3, MOD[3] & m, c);
+}
+// 4x64 CIOS Montgomery product, fully unrolled (synthesis is the serial part of create_proof): r = a * b / 2^256 mod q.
+// PRECONDITION: a < q; b may be ANY 256-bit value (every running sum then stays below 2q + q * 2^64 - five limbs inside a
+// row, four between rows - and the result is below 2q before its correction).
+#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__)
+// mulx + the two independent carry chains of adcx / adox: one row of the product and one reduction step per asm block
+// (compilers do not generate dual carry chains from C: the u128 form below compiles to ~250 instructions, this to ~150;
+// 25 instead of 38-41 ns per product in a dependent chain on the build host, tools/host_synthesis.py for the whole).
+#define BH_FR_ROW0(bi)                                                                                               \
+  asm("mulx %[a0], %[t0], %[t1]\n\t"                                                                                 \
+      "mulx %[a1], %%rax, %[t2]\n\t add %%rax, %[t1]\n\t"                                                            \
+      "mulx %[a2], %%rax, %[t3]\n\t adc %%rax, %[t2]\n\t"                                                            \
+      "mulx %[a3], %%rax, %[t4]\n\t adc %%rax, %[t3]\n\t adc $0, %[t4]\n\t"                                          \
+      : [t0] "=&r"(t0), [t1] "=&r"(t1), [t2] "=&r"(t2), [t3] "=&r"(t3), [t4] "=&r"(t4)                               \
+      : "d"(bi), [a0] "m"(a[0]), [a1] "m"(a[1]), [a2] "m"(a[2]), [a3] "m"(a[3])                                      \
+      : "rax", "cc")
+#define BH_FR_ROW(bi)                                                                                                \
+  asm("xorl %%eax, %%eax\n\t"                                                                                        \
+      "mulx %[a0], %[lo], %[hi]\n\t adcx %[lo], %[t0]\n\t adox %[hi], %[t1]\n\t"                                     \
+      "mulx %[a1], %[lo], %[hi]\n\t adcx %[lo], %[t1]\n\t adox %[hi], %[t2]\n\t"                                     \
+      "mulx %[a2], %[lo], %[hi]\n\t adcx %[lo], %[t2]\n\t adox %[hi], %[t3]\n\t"                                     \
+      "mulx %[a3], %[lo], %[t4]\n\t adcx %[lo], %[t3]\n\t"                                                           \
+      "mov $0, %[lo]\n\t adox %[lo], %[t4]\n\t adcx %[lo], %[t4]\n\t"                                                \
+      : [t0] "+r"(t0), [t1] "+r"(t1), [t2] "+r"(t2), [t3] "+r"(t3), [t4] "=&r"(t4), [lo] "=&r"(lo), [hi] "=&r"(hi)   \
+      : "d"(bi), [a0] "m"(a[0]), [a1] "m"(a[1]), [a2] "m"(a[2]), [a3] "m"(a[3])                                      \
+      : "rax", "cc")
+// t += (t0 * INV mod 2^64) * q, then one limb down (the low limb is zero by construction)
+#define BH_FR_REDUCE()                                                                                               \
+  {                                                                                                                  \
+    const uint64_t m = t0 * INV;                                                                                     \
+    asm("xorl %%eax, %%eax\n\t"                                                                                      \
+        "mulx %[q0], %[lo], %[hi]\n\t adcx %[t0], %[lo]\n\t adox %[hi], %[t1]\n\t"                                   \
+        "mulx %[q1], %[lo], %[hi]\n\t adcx %[lo], %[t1]\n\t adox %[hi], %[t2]\n\t"                                   \
+        "mulx %[q2], %[lo], %[hi]\n\t adcx %[lo], %[t2]\n\t adox %[hi], %[t3]\n\t"                                   \
+        "mulx %[q3], %[lo], %[hi]\n\t adcx %[lo], %[t3]\n\t adox %[hi], %[t4]\n\t"                                   \
+        "mov $0, %[lo]\n\t adcx %[lo], %[t4]\n\t"                                                                    \
+        : [t0] "+r"(t0), [t1] "+r"(t1), [t2] "+r"(t2), [t3] "+r"(t3), [t4] "+r"(t4), [lo] "=&r"(lo), [hi] "=&r"(hi)  \
+        : "d"(m), [q0] "m"(MOD[0]), [q1] "m"(MOD[1]), [q2] "m"(MOD[2]), [q3] "m"(MOD[3])                             \
+        : "rax", "cc");                                                                                              \
+    t0 = t1; t1 = t2; t2 = t3; t3 = t4; t4 = 0;                                                                      \
+  }
+__attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
+  uint64_t t0, t1, t2, t3, t4, lo, hi;
+  BH_FR_ROW0(b[0]); BH_FR_REDUCE();
+  BH_FR_ROW(b[1]); BH_FR_REDUCE();
+  BH_FR_ROW(b[2]); BH_FR_REDUCE();
+  BH_FR_ROW(b[3]); BH_FR_REDUCE();
+  final_sub(r, t0, t1, t2, t3);
+}
+#undef BH_FR_ROW0
+#undef BH_FR_ROW
+#undef BH_FR_REDUCE
+#else
 __attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b) {
   uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #define BH_FR_ROW(bi)                                                                     \
@@ -72,33 +154,49 @@ __attribute__((always_inline)) inline void mont_mul(uint64_t *r, const uint64_t 
     c += t4; t3 = (uint64_t)c; t4 = t5 + (uint64_t)(c >> 64);                             \
   }
   BH_FR_ROW(b[0]) BH_FR_ROW(b[1]) BH_FR_ROW(b[2]) BH_FR_ROW(b[3])
-  uint64_t t[4] = {t0, t1, t2, t3};
-  if (t4 || geq_mod(t)) sub_mod(t);
-  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
-}
-// a * v for a ONE-limb second operand: the product rows of its three zero limbs vanish and only their reduction steps
-// remain - 24 limb products instead of 36.  Fr::from_u64 (bls12_381's `From<u64> for Scalar` is a full product with R^2)
-// is what a circuit calls for every constant it writes down; the synthetic chain circuit of BASELINE config C4 spends
-// two of its three products per constraint there.
-__attribute__((always_inline)) inline void mont_mul_u64(uint64_t *r, const uint64_t *a, uint64_t v) {
-  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-  BH_FR_ROW(v)
-#define BH_FR_REDUCE_ROW                                                                  \
-  {                                                                                       \
-    const uint64_t m = t0 * INV;                                                          \
-    u128 c = ((u128)m * MOD[0] + t0) >> 64;                                               \
-    c += (u128)m * MOD[1] + t1; t0 = (uint64_t)c; c >>= 64;                               \
-    c += (u128)m * MOD[2] + t2; t1 = (uint64_t)c; c >>= 64;                               \
-    c += (u128)m * MOD[3] + t3; t2 = (uint64_t)c; c >>= 64;                               \
-    c += t4; t3 = (uint64_t)c; t4 = (uint64_t)(c >> 64);                                  \
-  }
-  BH_FR_REDUCE_ROW BH_FR_REDUCE_ROW BH_FR_REDUCE_ROW
-#undef BH_FR_REDUCE_ROW
-  uint64_t t[4] = {t0, t1, t2, t3};
-  if (t4 || geq_mod(t)) sub_mod(t);
-  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+  final_sub(r, t0, t1, t2, t3);
 }
 #undef BH_FR_ROW
+#endif
+// v * 2^256 mod q for a 64-bit v - Fr::from_u64, what a circuit calls for every constant it writes down (bls12_381's
+// `From<u64> for Scalar` is a full Montgomery product with R^2: 36 limb products; the one-limb form of it that round 4
+// used: 24).  Here: P = v * (2^256 mod q) < 2^64 q, its quotient by q estimated from the top 64 bits of P with
+// mu = floor(2^319 / q) = 2^64 + MU_LO (Barrett; the estimate is short by at most 3), and P - Q q corrected by 2q and q
+// without branches: 9 limb products.  The synthetic chain circuit of BASELINE config C4 spends two of its three products
+// per constraint here.
+constexpr uint64_t MU_LO = 0x1aa84a76ff6f1bbeULL;
+__attribute__((always_inline)) inline void mont_from_u64(uint64_t *r, uint64_t v) {
+  // P = v * R (five limbs)
+  u128 c = (u128)R[0] * v; const uint64_t p0 = (uint64_t)c;
+  c = (c >> 64) + (u128)R[1] * v; const uint64_t p1 = (uint64_t)c;
+  c = (c >> 64) + (u128)R[2] * v; const uint64_t p2 = (uint64_t)c;
+  c = (c >> 64) + (u128)R[3] * v; const uint64_t p3 = (uint64_t)c, p4 = (uint64_t)(c >> 64);
+  // Q = floor(floor(P / 2^255) * mu / 2^64): Q <= floor(P / q) <= Q + 3
+  const uint64_t ph = (p4 << 1) | (p3 >> 63);
+  const uint64_t qh = ph + (uint64_t)(((u128)ph * MU_LO) >> 64);
+  // t = P - Q q in [0, 4q): 258 bits (the fifth limb holds two of them)
+  c = (u128)MOD[0] * qh; const uint64_t m0 = (uint64_t)c;
+  c = (c >> 64) + (u128)MOD[1] * qh; const uint64_t m1 = (uint64_t)c;
+  c = (c >> 64) + (u128)MOD[2] * qh; const uint64_t m2 = (uint64_t)c;
+  c = (c >> 64) + (u128)MOD[3] * qh; const uint64_t m3 = (uint64_t)c, m4 = (uint64_t)(c >> 64);
+  carry_t b = 0;
+  uint64_t t0 = sbb(p0, m0, b), t1 = sbb(p1, m1, b), t2 = sbb(p2, m2, b), t3 = sbb(p3, m3, b), t4 = sbb(p4, m4, b);
+  // minus 2q if that does not borrow, then minus q if that does not borrow (selections by mask: data, not branches)
+  constexpr uint64_t Q2[4] = {MOD[0] << 1, (MOD[1] << 1) | (MOD[0] >> 63), (MOD[2] << 1) | (MOD[1] >> 63), (MOD[3] << 1) | (MOD[2] >> 63)};
+  {
+    b = 0;
+    const uint64_t d0 = sbb(t0, Q2[0], b), d1 = sbb(t1, Q2[1], b), d2 = sbb(t2, Q2[2], b), d3 = sbb(t3, Q2[3], b);
+    (void)sbb(t4, 0, b);
+    const uint64_t keep = 0 - (uint64_t)b;   // all ones: it borrowed, keep t
+    t0 = sel(keep, t0, d0); t1 = sel(keep, t1, d1); t2 = sel(keep, t2, d2); t3 = sel(keep, t3, d3);
+  }
+  {   // now t < 2q < 2^256: the fifth limb is zero
+    b = 0;
+    const uint64_t d0 = sbb(t0, MOD[0], b), d1 = sbb(t1, MOD[1], b), d2 = sbb(t2, MOD[2], b), d3 = sbb(t3, MOD[3], b);
+    const uint64_t keep = 0 - (uint64_t)b;
+    r[0] = sel(keep, t0, d0); r[1] = sel(keep, t1, d1); r[2] = sel(keep, t2, d2); r[3] = sel(keep, t3, d3);
+  }
+}
 }  // namespace fr_detail
 
 struct Fr {
@@ -107,43 +205,16 @@ struct Fr {
   static Fr one() { return Fr{{fr_detail::R[0], fr_detail::R[1], fr_detail::R[2], fr_detail::R[3]}}; }
   static Fr from_u64(uint64_t v) {
     Fr r;
-    fr_detail::mont_mul_u64(r.l, fr_detail::R2, v);
+    fr_detail::mont_from_u64(r.l, v);
     return r;
   }
   static Fr from_u512(const uint64_t limbs_le[8]);   // wide reduction, as ff's Field::random does
   bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
   bool operator==(const Fr &o) const { return ((l[0] ^ o.l[0]) | (l[1] ^ o.l[1]) | (l[2] ^ o.l[2]) | (l[3] ^ o.l[3])) == 0; }
   bool operator!=(const Fr &o) const { return !(*this == o); }
-  Fr operator+(const Fr &o) const {
-    Fr r;
-    fr_detail::u128 c = 0;
-    for (int i = 0; i < 4; i++) {
-      c += (fr_detail::u128)l[i] + o.l[i];
-      r.l[i] = (uint64_t)c;
-      c >>= 64;
-    }
-    if (fr_detail::geq_mod(r.l)) fr_detail::sub_mod(r.l);
-    return r;
-  }
-  Fr operator-(const Fr &o) const {
-    Fr r;
-    fr_detail::u128 br = 0;
-    for (int i = 0; i < 4; i++) {
-      fr_detail::u128 d = (fr_detail::u128)l[i] - o.l[i] - (uint64_t)br;
-      r.l[i] = (uint64_t)d;
-      br = (d >> 64) & 1;
-    }
-    if (br) {
-      fr_detail::u128 c = 0;
-      for (int i = 0; i < 4; i++) {
-        c += (fr_detail::u128)r.l[i] + fr_detail::MOD[i];
-        r.l[i] = (uint64_t)c;
-        c >>= 64;
-      }
-    }
-    return r;
-  }
-  Fr operator*(const Fr &o) const { Fr r; fr_detail::mont_mul(r.l, l, o.l); return r; }
+  __attribute__((always_inline)) Fr operator+(const Fr &o) const { Fr r; fr_detail::add_mod(r.l, l, o.l); return r; }
+  __attribute__((always_inline)) Fr operator-(const Fr &o) const { Fr r; fr_detail::sub_mod(r.l, l, o.l); return r; }
+  __attribute__((always_inline)) Fr operator*(const Fr &o) const { Fr r; fr_detail::mont_mul(r.l, l, o.l); return r; }
   Fr neg() const { return Fr::zero() - *this; }
   void to_canonical(uint64_t out[4]) const {   // the bits of Exponent::Bits (multiexp.rs:179)
     const uint64_t one_[4] = {1, 0, 0, 0};
@@ -215,6 +286,17 @@ struct LcSink {
   void (*hook)(void *self, Variable v, const Fr &coeff) = nullptr;
   void *self = nullptr;
 };
+// Copy of a field element that was just computed: limb by limb through general registers.  A struct copy compiles to two
+// 16-byte vector moves, and a 16-byte load from a location that two 8-byte stores have just written cannot be forwarded
+// from the store buffer - it waits until both stores have reached the cache (12+ cycles, once per copy of a combination
+// whose accumulator the previous term has just updated).
+__attribute__((always_inline)) inline void copy_fresh(Fr &dst, const Fr &src) {
+  uint64_t a = src.l[0], b = src.l[1], c = src.l[2], d = src.l[3];
+#if defined(__GNUC__)
+  asm("" : "+r"(a), "+r"(b), "+r"(c), "+r"(d));   // (keeps the four loads scalar)
+#endif
+  dst.l[0] = a; dst.l[1] = b; dst.l[2] = c; dst.l[3] = d;
+}
 class LinearCombination {
  public:
   struct Term { Variable first; Fr second; };     // (variable, coefficient); an aggregate, so copies are plain memcpy
@@ -227,62 +309,79 @@ class LinearCombination {
   }
   LinearCombination() : n_(0), sink_(nullptr) {}
   LinearCombination(const LinearCombination &o) : n_(o.n_), sink_(o.sink_) {
-    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
   }
   LinearCombination(LinearCombination &&o) noexcept : n_(o.n_), sink_(o.sink_) {
-    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
   }
   LinearCombination &operator=(const LinearCombination &o) {
     if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
-    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
     return *this;
   }
   LinearCombination &operator=(LinearCombination &&o) noexcept {
     if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
-    if (sink_) acc_ = o.acc_; else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
     return *this;
   }
   // lvalue operands are copied (value semantics); a temporary is extended in place and MOVED out - returned by value,
   // so that `lc = std::move(lc) + x` is not a self-move and `auto &&r = zero() + a` does not dangle (moving an
   // evaluating combination is a 56-byte copy)
-  LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one()); return r; }
-  LinearCombination operator+(Variable v) && { push(v, Fr::one()); return std::move(*this); }
+  LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push_one(v); return r; }
+  LinearCombination operator+(Variable v) && { push_one(v); return std::move(*this); }
   LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
   LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
-  LinearCombination operator+(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
-  LinearCombination operator+(std::pair<Fr, Variable> t) && { push(t.second, t.first); return std::move(*this); }
-  LinearCombination operator-(std::pair<Fr, Variable> t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
-  LinearCombination operator-(std::pair<Fr, Variable> t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  // ((coefficient, variable) terms by reference: a 56-byte pair passed by value is copied with 16-byte loads that straddle
+  //  the 8-byte stores which have just built it - a failed store forwarding per term)
+  LinearCombination operator+(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
+  LinearCombination operator+(const std::pair<Fr, Variable> &t) && { push(t.second, t.first); return std::move(*this); }
+  LinearCombination operator-(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
+  LinearCombination operator-(const std::pair<Fr, Variable> &t) && { push(t.second, t.first.neg()); return std::move(*this); }
   size_t size() const { return n_; }
   // stored combinations only
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
   bool is_evaluating() const { return sink_ != nullptr; }
-  const Fr &value() const { return acc_; }   // evaluating combinations only
+  Fr value() const { Fr r; copy_fresh(r, acc_); return r; }   // evaluating combinations only
 
  private:
   static constexpr size_t INLINE = 4;
-  void push(Variable v, const Fr &c) {
+  // The evaluating form is the hot path of create_proof's synthesis: it is inlined into the closures, with the two rare
+  // cases (a term that needs a product; a term that is stored) out of line so that a closure stays a few dozen
+  // instructions per term.
+  __attribute__((always_inline)) const Fr *locate(Variable v) const {   // the variable's value; counts it in the density map
+    if (v.kind == Index::Input) {
+      if (sink_->input_density) sink_->input_density->inc(v.idx);
+      return sink_->inputs->data() + v.idx;
+    }
+    if (sink_->aux_density) sink_->aux_density->inc(v.idx);
+    return sink_->aux->data() + v.idx;
+  }
+  __attribute__((always_inline)) void push(Variable v, const Fr &c) {
     n_++;
-    if (sink_) {   // prover.rs:19-55 for this one term
+    if (__builtin_expect(sink_ != nullptr, 1)) {   // prover.rs:19-55 for this one term
       if (c.is_zero()) return;            // zero coefficients count for neither value nor density (:31)
-      if (sink_->hook) { sink_->hook(sink_->self, v, c); return; }
-      const Fr *value;
-      if (v.kind == Index::Input) {
-        value = sink_->inputs->data() + v.idx;
-        if (sink_->input_density) sink_->input_density->inc(v.idx);
-      } else {
-        value = sink_->aux->data() + v.idx;
-        if (sink_->aux_density) sink_->aux_density->inc(v.idx);
-      }
-      const Fr one = Fr::one();
-      // most terms carry the coefficient one (`lc + x`), then the ubiquitous `(c, CS::one())` terms: value one
-      if (c == one) acc_ = acc_ + *value;
-      else if (*value == one) acc_ = acc_ + c;
-      else acc_ = acc_ + *value * c;
+      if (__builtin_expect(sink_->hook != nullptr, 0)) { sink_->hook(sink_->self, v, c); return; }
+      const Fr *value = locate(v);
+      // most terms carry the coefficient one (`lc + x`: push_one), then the ubiquitous `(c, CS::one())` terms: value one
+      if (*value == Fr::one()) acc_ = acc_ + c;
+      else if (c == Fr::one()) acc_ = acc_ + *value;
+      else add_product(*value, c);
       return;
     }
+    push_stored(v, c);
+  }
+  __attribute__((always_inline)) void push_one(Variable v) {   // coefficient one
+    if (__builtin_expect(sink_ != nullptr && sink_->hook == nullptr, 1)) {
+      n_++;
+      acc_ = acc_ + *locate(v);
+      return;
+    }
+    push(v, Fr::one());
+  }
+  __attribute__((noinline)) void add_product(const Fr &value, const Fr &c) { acc_ = acc_ + value * c; }
+  __attribute__((noinline)) void push_stored(Variable v, const Fr &c) {
     if (n_ <= INLINE) inl_[n_ - 1] = Term{v, c}; else more_.push_back(Term{v, c});
   }
   Term inl_[INLINE];
@@ -300,14 +399,14 @@ template <class R, class... Args>
 class FunctionRef<R(Args...)> {
  public:
   template <class F>
-  FunctionRef(F &&f) : obj_((void *)&f), call_([](void *o, Args... args) -> R {
+  FunctionRef(F &&f) : obj_((void *)&f), call_([](void *o, Args &&...args) -> R {
     return (*reinterpret_cast<typename std::remove_reference<F>::type *>(o))(std::forward<Args>(args)...);
   }) {}
   R operator()(Args... args) const { return call_(obj_, std::forward<Args>(args)...); }
 
  private:
   void *obj_;
-  R (*call_)(void *, Args...);
+  R (*call_)(void *, Args &&...);   // (arguments travel by reference up to the callable: one move of a combination less)
 };
 
 typedef FunctionRef<LinearCombination(LinearCombination)> LcFn;
@@ -320,7 +419,9 @@ class ConstraintSystem {
   static Variable one() { return Variable::new_unchecked(Index::Input, 0); }
   virtual Variable alloc(ValueFn f) = 0;
   virtual Variable alloc_input(ValueFn f) = 0;
-  virtual void enforce(LcFn a, LcFn b, LcFn c) = 0;
+  // (the three callable references travel by reference: by value the third one goes over the stack as one 16-byte vector
+  //  load of two 8-byte stores, which the store buffer cannot forward - 4 % of a 2^20-constraint synthesis)
+  virtual void enforce(const LcFn &a, const LcFn &b, const LcFn &c) = 0;
 };
 
 // ---- src/lib.rs:156-159 -------------------------------------------------------------------------
@@ -388,7 +489,7 @@ class ProvingAssignment : public bellman::ConstraintSystem {
   std::vector<Fr> input_assignment, aux_assignment;
   bellman::Variable alloc(bellman::ValueFn f) override;
   bellman::Variable alloc_input(bellman::ValueFn f) override;
-  void enforce(bellman::LcFn a, bellman::LcFn b, bellman::LcFn c) override;
+  void enforce(const bellman::LcFn &a, const bellman::LcFn &b, const bellman::LcFn &c) override;
 };
 
 struct ProveTimings { float synthesis_ms, h_poly_ms, msm_ms, total_ms; };
@@ -424,7 +525,7 @@ class WitnessAssignment : public bellman::ConstraintSystem {
   std::vector<Fr> input_assignment, aux_assignment;
   bellman::Variable alloc(bellman::ValueFn f) override;
   bellman::Variable alloc_input(bellman::ValueFn f) override;
-  void enforce(bellman::LcFn, bellman::LcFn, bellman::LcFn) override {}
+  void enforce(const bellman::LcFn &, const bellman::LcFn &, const bellman::LcFn &) override {}
 };
 
 // prover.rs:182-361.  Throws bellman::SynthesisError.

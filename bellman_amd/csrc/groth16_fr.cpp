@@ -16,8 +16,9 @@ Fr Fr::from_u512(const uint64_t limbs[8]) {
   memcpy(lo.l, limbs, 32);
   memcpy(hi.l, limbs + 4, 32);
   memcpy(r2.l, FR_R2, 32);
-  // mont_mul(x, R^2) = x * R mod q for any 256-bit x: the Montgomery form of x mod q
-  const Fr lo_m = lo * r2, hi_m = hi * r2;
+  // mont_mul(R^2, x) = x * R mod q for any 256-bit x: the Montgomery form of x mod q (the FIRST operand of the product has
+  // to be below q, the second may be any 256-bit value: groth16.hpp)
+  const Fr lo_m = r2 * lo, hi_m = r2 * hi;
   return lo_m + hi_m * r2;   // Montgomery form of 2^256 is R * R = R^2
 }
 Fr Fr::pow_vartime(uint64_t e) const {

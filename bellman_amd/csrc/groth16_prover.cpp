@@ -108,7 +108,7 @@ Variable ProvingAssignment::alloc_input(ValueFn f) {
   b_input_density.add_element();
   return Variable::new_unchecked(Index::Input, input_assignment.size() - 1);
 }
-void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
+void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) {
   // inputs have full density in the A query; there is no C query (prover.rs:119-141).  The closures get combinations
   // that evaluate each term as it is added (groth16.hpp); a closure that returns some other, stored combination is
   // evaluated the classic way.  CONTRACT of the evaluating form (the reference's `eval` walks only the RETURNED
@@ -117,7 +117,7 @@ void ProvingAssignment::enforce(LcFn fa, LcFn fb, LcFn fc) {
   // and gadgets has that shape (`|lc| lc + a + (c, b)`).
   const std::vector<Fr> *in = &input_assignment, *ax = &aux_assignment;
   const LcSink sa{in, ax, nullptr, &a_aux_density}, sb{in, ax, &b_input_density, &b_aux_density}, sc{in, ax, nullptr, nullptr};
-  auto run = [&](LcFn &f, const LcSink &sink) -> Fr {
+  auto run = [&](const LcFn &f, const LcSink &sink) -> Fr {
     const LinearCombination r = f(LinearCombination::evaluating(&sink));
     return r.is_evaluating() ? r.value() : eval(r, sink.input_density, sink.aux_density, input_assignment, aux_assignment);
   };
@@ -596,10 +596,10 @@ class ShapeAssembly : public ConstraintSystem {
     Hooked *h = static_cast<Hooked *>(self);
     h->cs->add_term(h->m, v, k);
   }
-  void enforce(LcFn fa, LcFn fb, LcFn fc) override {
+  void enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) override {
     // the closures get combinations whose terms go straight into the matrices (LcSink::hook); a closure that returns
     // some other, stored combination is walked the classic way
-    LcFn *fs[3] = {&fa, &fb, &fc};
+    const LcFn *fs[3] = {&fa, &fb, &fc};
     for (int m = 0; m < 3; m++) {
       Hooked h{this, m};
       LcSink sink{nullptr, nullptr, nullptr, nullptr, &ShapeAssembly::hook, &h};

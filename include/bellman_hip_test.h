@@ -81,6 +81,11 @@ int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const 
                             size_t counts3[3], void *a, void *b, void *c, void *inputs, void *aux, uint64_t *a_aux_density,
                             uint64_t *b_input_density, uint64_t *b_aux_density);
 void bh_test_fr_from_u512_host(void *r, const void *limbs8); /* 64 bytes LE -> Montgomery Fr (create_random_proof's sampling) */
+/* host only: the scalar-field arithmetic of the C++ mirror (bellman::Fr, csrc/groth16.hpp - what circuits and the
+ * linear-combination evaluation compute with during synthesis), n operations on arrays of 32-byte Montgomery elements:
+ * op 0 r = a + b, 1 r = a - b, 2 r = a * b (b may be ANY 256-bit value), 3 r = -a, 4 r = Fr::from_u64(low limb of a),
+ * 5 r = canonical limbs of a (to_canonical), 6 r = a^-1 (a != 0) */
+void bh_test_fr_ops_host(int op, void *r, const void *a, const void *b, size_t n);
 
 /* host only: where bh_msm_sharded_async cuts the exponents for shards of lens[k] bases (cuts_out[n_shards + 1]), and
  * the size class the workspace pool rounds a request up to */

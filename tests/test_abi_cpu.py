@@ -240,6 +240,66 @@ def test_fr_wide_reduction_host():
         assert got == (v % q) * (1 << 256) % q
 
 
+def test_mirror_scalar_field_arithmetic_host():
+    """bellman::Fr of the C++ mirror (csrc/groth16.hpp): the arithmetic circuits and the linear-combination evaluation use
+    during synthesis - branch-free add / sub, the mulx / adcx / adox Montgomery product (first operand below q, second any
+    256-bit value), Fr::from_u64 by Barrett reduction (quotient estimates short by 0 ... 3 must all be corrected),
+    to_canonical, inversion - against Python integers.  Host code, no device."""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    R = 1 << 256
+    Rinv = pow(R, -1, q)
+    M64 = (1 << 64) - 1
+
+    def arr(vals):
+        return np.array([[(v >> (64 * i)) & M64 for i in range(4)] for v in vals], dtype=np.uint64)
+
+    def ints(a):
+        return [sum(int(x) << (64 * i) for i, x in enumerate(row)) for row in a]
+
+    def run(op, a, b=None):
+        n = len(a)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        aa = arr(a)
+        bb = arr(b) if b is not None else None
+        lib.bh_test_fr_ops_host(op, out.ctypes.data_as(ctypes.c_void_p), aa.ctypes.data_as(ctypes.c_void_p),
+                                bb.ctypes.data_as(ctypes.c_void_p) if bb is not None else None, n)
+        return ints(out)
+
+    rnd = random.Random(11)
+    edge = [0, 1, 2, q - 1, q - 2, R % q, (R % q) - 1, (q + 1) // 2, (q - 1) // 2, M64, 1 << 64, (1 << 255) % q, q >> 1, q >> 64]
+    xs = edge + [rnd.randrange(q) for _ in range(3000)]
+    # every edge value against every edge value, then random pairs
+    a = [x for x in edge for _ in edge] + xs
+    b = [y for _ in edge for y in edge] + [rnd.randrange(q) for _ in xs]
+    assert run(0, a, b) == [(x + y) % q for x, y in zip(a, b)]
+    assert run(1, a, b) == [(x - y) % q for x, y in zip(a, b)]
+    assert run(2, a, b) == [x * y * Rinv % q for x, y in zip(a, b)]
+    assert run(3, a) == [(-x) % q for x in a]
+    # the second operand of a product need not be reduced (Fr::from_u512 multiplies R^2 by raw 256-bit words)
+    wide = [R - 1, R - 2, q, q + 1, 2 * q - 1, 2 * q, 2 * q + 1, (1 << 255), (1 << 255) - 1] + [rnd.getrandbits(256) for _ in range(2000)]
+    lhs = [rnd.choice(edge + [rnd.randrange(q)]) for _ in wide]
+    assert run(2, lhs, wide) == [x * y * Rinv % q for x, y in zip(lhs, wide)]
+    # from_u64: v * R mod q, incl. the values around the multiples of q / R where the quotient estimate is tightest
+    vs = [0, 1, 2, M64, M64 - 1, 1 << 63, (1 << 63) - 1, (1 << 32), (1 << 32) - 1, 0xFFFFFFFF00000001, 0x73EDA753299D7D48]
+    for k in range(1, 200):   # v with v * (R mod q) just below / above a multiple of q
+        t = k * q // (R % q)
+        vs += [v for v in (t - 1, t, t + 1, t + 2) if 0 <= v <= M64]
+    vs += [rnd.getrandbits(64) for _ in range(20000)] + [rnd.getrandbits(rnd.randrange(1, 65)) for _ in range(5000)]
+    assert run(4, vs) == [v * R % q for v in vs]
+    mont = [x * R % q for x in xs]
+    assert run(5, mont) == xs
+    inv_in = [x for x in mont if x][:300]
+    assert run(6, inv_in) == [pow(x * Rinv % q, -1, q) * R % q for x in inv_in]
+
+
 def test_lazily_reduced_fp_helpers_host():
     """The curve kernels keep Fp values in [0, 2p) (ff.cuh fpl_*): every helper must preserve the range,
     agree with the integers mod p, and treat both representatives of zero (0 and p) as zero."""
