@@ -344,6 +344,7 @@ class LinearCombination {
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
   bool is_evaluating() const { return sink_ != nullptr; }
   Fr value() const { Fr r; copy_fresh(r, acc_); return r; }   // evaluating combinations only
+  void value_into(Fr &dst) const { copy_fresh(dst, acc_); }
 
  private:
   static constexpr size_t INLINE = 4;

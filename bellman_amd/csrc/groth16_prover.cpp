@@ -117,13 +117,18 @@ void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) 
   // and gadgets has that shape (`|lc| lc + a + (c, b)`).
   const std::vector<Fr> *in = &input_assignment, *ax = &aux_assignment;
   const LcSink sa{in, ax, nullptr, &a_aux_density}, sb{in, ax, &b_input_density, &b_aux_density}, sc{in, ax, nullptr, nullptr};
-  auto run = [&](const LcFn &f, const LcSink &sink) -> Fr {
+  // (the value goes from the combination's accumulator into the vector's new slot limb by limb: handed on as an Fr it is
+  //  copied with 16-byte loads from the 8-byte stores of the last addition, which the store buffer cannot forward -
+  //  a tenth of the synthesis time of a 2^20-constraint circuit, tools/host_profile.py)
+  auto run = [&](const LcFn &f, const LcSink &sink, std::vector<Fr> &out) {
     const LinearCombination r = f(LinearCombination::evaluating(&sink));
-    return r.is_evaluating() ? r.value() : eval(r, sink.input_density, sink.aux_density, input_assignment, aux_assignment);
+    out.emplace_back();
+    if (r.is_evaluating()) r.value_into(out.back());
+    else out.back() = eval(r, sink.input_density, sink.aux_density, input_assignment, aux_assignment);
   };
-  a.push_back(run(fa, sa));
-  b.push_back(run(fb, sb));
-  c.push_back(run(fc, sc));
+  run(fa, sa, a);
+  run(fb, sb, b);
+  run(fc, sc, c);
 }
 
 namespace {

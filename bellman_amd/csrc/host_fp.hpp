@@ -24,50 +24,99 @@ static const uint64_t INV = 0x89f3fffcfffcfffdULL;
 static const uint64_t ONE[6] = {0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL,
                                 0x77ce585370525745ULL, 0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL};
 
-static inline bool geq_mod(const uint64_t *a) {
-  for (int i = 5; i >= 0; i--) {
-    if (a[i] > MOD[i]) return true;
-    if (a[i] < MOD[i]) return false;
-  }
-  return true;
-}
-static inline void sub_mod(uint64_t *a) {
-  u128 br = 0;
-  for (int i = 0; i < 6; i++) {
-    u128 d = (u128)a[i] - MOD[i] - (uint64_t)br;
-    a[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
+// Operands are canonical (below p) everywhere on the host.  The final corrections are selections by mask, not branches:
+// whether a random sum or product needs its correction is a coin flip, and these functions run in dependent chains (the
+// doubling ladder that closes every multiexp, create_proof's few scalar multiplications) where a mispredicted branch is
+// paid in full.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace hostfp
+}  // namespace bh
+#include <x86intrin.h>
+namespace bh {
+namespace hostfp {
+typedef unsigned char carry_t;
+static inline __attribute__((always_inline)) uint64_t adc(uint64_t a, uint64_t b, carry_t &c) { unsigned long long r; c = _addcarry_u64(c, a, b, &r); return r; }
+static inline __attribute__((always_inline)) uint64_t sbb(uint64_t a, uint64_t b, carry_t &c) { unsigned long long r; c = _subborrow_u64(c, a, b, &r); return r; }
+#else
+typedef uint64_t carry_t;
+static inline uint64_t adc(uint64_t a, uint64_t b, carry_t &c) { const u128 x = (u128)a + b + c; c = (uint64_t)(x >> 64); return (uint64_t)x; }
+static inline uint64_t sbb(uint64_t a, uint64_t b, carry_t &c) { const u128 x = (u128)a - b - c; c = (uint64_t)(x >> 64) & 1; return (uint64_t)x; }
+#endif
+// t < 2p in six limbs -> [0, p)
+static inline __attribute__((always_inline)) void final_sub(uint64_t *r, const uint64_t *t) {
+  carry_t b = 0;
+  uint64_t d[6];
+  d[0] = sbb(t[0], MOD[0], b); d[1] = sbb(t[1], MOD[1], b); d[2] = sbb(t[2], MOD[2], b);
+  d[3] = sbb(t[3], MOD[3], b); d[4] = sbb(t[4], MOD[4], b); d[5] = sbb(t[5], MOD[5], b);
+  const uint64_t keep = 0 - (uint64_t)b;   // all ones: t < p
+  for (int i = 0; i < 6; i++) r[i] = d[i] ^ ((d[i] ^ t[i]) & keep);
 }
 static inline void add(hfp_t &r, const hfp_t &a, const hfp_t &b) {
+  carry_t c = 0;
   uint64_t t[6];
-  u128 c = 0;
-  for (int i = 0; i < 6; i++) {
-    c += (u128)a.l[i] + b.l[i];
-    t[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  if (geq_mod(t)) sub_mod(t);
-  memcpy(r.l, t, sizeof t);
+  t[0] = adc(a.l[0], b.l[0], c); t[1] = adc(a.l[1], b.l[1], c); t[2] = adc(a.l[2], b.l[2], c);
+  t[3] = adc(a.l[3], b.l[3], c); t[4] = adc(a.l[4], b.l[4], c); t[5] = adc(a.l[5], b.l[5], c);   // 2p < 2^384: no carry out
+  final_sub(r.l, t);
 }
 static inline void sub(hfp_t &r, const hfp_t &a, const hfp_t &b) {
+  carry_t c = 0;
   uint64_t t[6];
-  u128 br = 0;
-  for (int i = 0; i < 6; i++) {
-    u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)br;
-    t[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-  if (br) {
-    u128 c = 0;
-    for (int i = 0; i < 6; i++) {
-      c += (u128)t[i] + MOD[i];
-      t[i] = (uint64_t)c;
-      c >>= 64;
-    }
-  }
-  memcpy(r.l, t, sizeof t);
+  t[0] = sbb(a.l[0], b.l[0], c); t[1] = sbb(a.l[1], b.l[1], c); t[2] = sbb(a.l[2], b.l[2], c);
+  t[3] = sbb(a.l[3], b.l[3], c); t[4] = sbb(a.l[4], b.l[4], c); t[5] = sbb(a.l[5], b.l[5], c);
+  const uint64_t m = 0 - (uint64_t)c;   // borrowed: add p back
+  c = 0;
+  r.l[0] = adc(t[0], MOD[0] & m, c); r.l[1] = adc(t[1], MOD[1] & m, c); r.l[2] = adc(t[2], MOD[2] & m, c);
+  r.l[3] = adc(t[3], MOD[3] & m, c); r.l[4] = adc(t[4], MOD[4] & m, c); r.l[5] = adc(t[5], MOD[5] & m, c);
 }
+// 6x64 CIOS Montgomery product, r = a * b / 2^384 mod p; a < p, b < 2^384 (every running sum then fits seven limbs inside a
+// row and six between rows).
+#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__) && !defined(__HIP_DEVICE_COMPILE__)
+// mulx with the two carry chains of adcx / adox (compilers do not produce them from C): one product row and one reduction
+// step per asm block; the Makefile passes -mbmi2 -madx to the HOST half of the .hip files for this.
+#define BH_HFP_MULADD(src, tlo, thi) "mulx " src ", %[lo], %[hi]\n\t adcx %[lo], " tlo "\n\t adox %[hi], " thi "\n\t"
+#define BH_HFP_ROW(bi, first)                                                                                        \
+  asm("xorl %%eax, %%eax\n\t"                                                                                        \
+      BH_HFP_MULADD("%[a0]", "%[t0]", "%[t1]") BH_HFP_MULADD("%[a1]", "%[t1]", "%[t2]")                              \
+      BH_HFP_MULADD("%[a2]", "%[t2]", "%[t3]") BH_HFP_MULADD("%[a3]", "%[t3]", "%[t4]")                              \
+      BH_HFP_MULADD("%[a4]", "%[t4]", "%[t5]")                                                                       \
+      "mulx %[a5], %[lo], %[t6]\n\t adcx %[lo], %[t5]\n\t"                                                           \
+      "mov $0, %[lo]\n\t adox %[lo], %[t6]\n\t adcx %[lo], %[t6]\n\t"                                                \
+      : [t0] "+r"(t0), [t1] "+r"(t1), [t2] "+r"(t2), [t3] "+r"(t3), [t4] "+r"(t4), [t5] "+r"(t5), [t6] "=&r"(t6),    \
+        [lo] "=&r"(lo), [hi] "=&r"(hi)                                                                               \
+      : "d"(bi), [a0] "m"(a.l[0]), [a1] "m"(a.l[1]), [a2] "m"(a.l[2]), [a3] "m"(a.l[3]), [a4] "m"(a.l[4]),           \
+        [a5] "m"(a.l[5])                                                                                             \
+      : "rax", "cc")
+#define BH_HFP_REDUCE()                                                                                              \
+  {                                                                                                                  \
+    const uint64_t m = t0 * INV;                                                                                     \
+    asm("xorl %%eax, %%eax\n\t"                                                                                      \
+        "mulx %[q0], %[lo], %[hi]\n\t adcx %[t0], %[lo]\n\t adox %[hi], %[t1]\n\t"                                   \
+        BH_HFP_MULADD("%[q1]", "%[t1]", "%[t2]") BH_HFP_MULADD("%[q2]", "%[t2]", "%[t3]")                            \
+        BH_HFP_MULADD("%[q3]", "%[t3]", "%[t4]") BH_HFP_MULADD("%[q4]", "%[t4]", "%[t5]")                            \
+        BH_HFP_MULADD("%[q5]", "%[t5]", "%[t6]")                                                                     \
+        "mov $0, %[lo]\n\t adcx %[lo], %[t6]\n\t"                                                                    \
+        : [t0] "+r"(t0), [t1] "+r"(t1), [t2] "+r"(t2), [t3] "+r"(t3), [t4] "+r"(t4), [t5] "+r"(t5), [t6] "+r"(t6),   \
+          [lo] "=&r"(lo), [hi] "=&r"(hi)                                                                             \
+        : "d"(m), [q0] "m"(MOD[0]), [q1] "m"(MOD[1]), [q2] "m"(MOD[2]), [q3] "m"(MOD[3]), [q4] "m"(MOD[4]),          \
+          [q5] "m"(MOD[5])                                                                                           \
+        : "rax", "cc");                                                                                              \
+    t0 = t1; t1 = t2; t2 = t3; t3 = t4; t4 = t5; t5 = t6;                                                            \
+  }
+static inline void mul(hfp_t &r, const hfp_t &a, const hfp_t &b) {
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6, lo, hi;
+  BH_HFP_ROW(b.l[0], 1); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[1], 0); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[2], 0); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[3], 0); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[4], 0); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[5], 0); BH_HFP_REDUCE();
+  const uint64_t t[6] = {t0, t1, t2, t3, t4, t5};
+  final_sub(r.l, t);
+}
+#undef BH_HFP_MULADD
+#undef BH_HFP_ROW
+#undef BH_HFP_REDUCE
+#else
 static inline void mul(hfp_t &r, const hfp_t &a, const hfp_t &b) {
   uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 6; i++) {
@@ -79,7 +128,6 @@ static inline void mul(hfp_t &r, const hfp_t &a, const hfp_t &b) {
     }
     c += t[6];
     t[6] = (uint64_t)c;
-    t[7] = (uint64_t)(c >> 64);
     const uint64_t m = t[0] * INV;
     c = ((u128)m * MOD[0] + t[0]) >> 64;
     for (int j = 1; j < 6; j++) {
@@ -89,11 +137,11 @@ static inline void mul(hfp_t &r, const hfp_t &a, const hfp_t &b) {
     }
     c += t[6];
     t[5] = (uint64_t)c;
-    t[6] = t[7] + (uint64_t)(c >> 64);
+    t[6] = 0;
   }
-  if (t[6] || geq_mod(t)) sub_mod(t);
-  memcpy(r.l, t, 6 * sizeof(uint64_t));
+  final_sub(r.l, t);
 }
+#endif
 static inline bool is_zero(const hfp_t &a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
 static inline bool eq(const hfp_t &a, const hfp_t &b) {
   uint64_t o = 0;
