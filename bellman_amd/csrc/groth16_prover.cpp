@@ -574,8 +574,10 @@ class ShapeAssembly : public ConstraintSystem {
   // chain: 2 new ones per constraint) pays one compare and one append per term instead of a node allocation and a
   // rehash - the one-time capture of 2^20 constraints 1.32 -> 0.42 s in the build container (bh_test_capture_check).  A collision only stores a
   // constant twice (the table may hold duplicates: terms carry an index, csrc/r1cs.hip).
+  // A cache entry is (32 hash bits | table index): the stored coefficient is only looked at when the hash bits agree - for a
+  // circuit of distinct coefficients every probe would otherwise be a cache miss into a table of tens of megabytes.
   static constexpr size_t CACHE_SLOTS = size_t(1) << 16;
-  std::vector<uint32_t> coeff_cache;
+  std::vector<uint64_t> coeff_cache;
   const Fr one_ = Fr::one();
   ShapeAssembly() : coeff_cache(CACHE_SLOTS, 0) {   // 0 = the constant one (never looked up): an empty slot
     coeffs.push_back(Fr::one());
@@ -589,9 +591,13 @@ class ShapeAssembly : public ConstraintSystem {
       terms[m].push_back(Term{v.kind, (uint32_t)v.idx, 0});
       return;
     }
-    uint32_t &slot = coeff_cache[FrHash()(k) & (CACHE_SLOTS - 1)];
-    if (slot == 0 || !(coeffs[slot] == k)) {
+    const uint64_t h = FrHash()(k);
+    uint64_t &entry = coeff_cache[h & (CACHE_SLOTS - 1)];
+    const uint64_t tag = h & 0xffffffff00000000ULL;
+    uint32_t slot = (uint32_t)entry;
+    if (slot == 0 || (entry & 0xffffffff00000000ULL) != tag || !(coeffs[slot] == k)) {
       slot = (uint32_t)coeffs.size();
+      entry = tag | slot;
       coeffs.push_back(k);
     }
     terms[m].push_back(Term{v.kind, (uint32_t)v.idx, slot});
