@@ -238,10 +238,15 @@ struct IoError : std::runtime_error {
 
 // ---- src/lib.rs:163-185 -------------------------------------------------------------------------
 enum class Index { Input, Aux };
+// One 64-bit word (the index, with the kind in the top bit), not the two-field struct of the reference's `Variable(Index)`:
+// circuits copy variables all the time (`x = next;`), a 16-byte struct is copied with ONE vector load, and a variable that
+// `alloc` has just returned in two registers sits in memory as two 8-byte stores - which cannot be forwarded to that load
+// (6 % of the witness generation of a 2^20-constraint chain, tools/host_profile.py).
 struct Variable {
-  Index kind;
-  size_t idx;
-  static Variable new_unchecked(Index k, size_t i) { return Variable{k, i}; }
+  uint64_t bits;
+  static Variable new_unchecked(Index k, size_t i) { return Variable{(uint64_t)i | (k == Index::Aux ? uint64_t(1) << 63 : 0)}; }
+  Index kind() const { return (bits >> 63) ? Index::Aux : Index::Input; }
+  size_t idx() const { return (size_t)(bits & ~(uint64_t(1) << 63)); }
 };
 
 // ---- src/multiexp.rs:117-157 --------------------------------------------------------------------
@@ -352,12 +357,13 @@ class LinearCombination {
   // cases (a term that needs a product; a term that is stored) out of line so that a closure stays a few dozen
   // instructions per term.
   __attribute__((always_inline)) const Fr *locate(Variable v) const {   // the variable's value; counts it in the density map
-    if (v.kind == Index::Input) {
-      if (sink_->input_density) sink_->input_density->inc(v.idx);
-      return sink_->inputs->data() + v.idx;
+    const size_t i = v.idx();
+    if (v.kind() == Index::Input) {
+      if (sink_->input_density) sink_->input_density->inc(i);
+      return sink_->inputs->data() + i;
     }
-    if (sink_->aux_density) sink_->aux_density->inc(v.idx);
-    return sink_->aux->data() + v.idx;
+    if (sink_->aux_density) sink_->aux_density->inc(i);
+    return sink_->aux->data() + i;
   }
   __attribute__((always_inline)) void push(Variable v, const Fr &c) {
     n_++;

@@ -29,12 +29,12 @@ static inline Fr eval(const LinearCombination &lc, DensityTracker *input_density
     const Fr &coeff = lc[t].second;
     if (coeff.is_zero()) continue;          // zero coefficients count for neither value nor density (:31)
     const Fr *value;
-    if (var.kind == Index::Input) {
-      value = &input_assignment[var.idx];
-      if (input_density) input_density->inc(var.idx);
+    if (var.kind() == Index::Input) {
+      value = &input_assignment[var.idx()];
+      if (input_density) input_density->inc(var.idx());
     } else {
-      value = &aux_assignment[var.idx];
-      if (aux_density) aux_density->inc(var.idx);
+      value = &aux_assignment[var.idx()];
+      if (aux_density) aux_density->inc(var.idx());
     }
     // most terms carry the coefficient one (`lc + x`), then the ubiquitous `(c, CS::one())` terms: value one
     if (coeff == one) acc = acc + *value;
@@ -588,7 +588,7 @@ class ShapeAssembly : public ConstraintSystem {
   void add_term(int m, const Variable &v, const Fr &k) {
     if (k.is_zero()) return;     // prover.rs:31: no value, no density
     if (k == one_) {             // the usual `lc + x` term: coefficient table entry 0, no hash lookup
-      terms[m].push_back(Term{v.kind, (uint32_t)v.idx, 0});
+      terms[m].push_back(Term{v.kind(), (uint32_t)v.idx(), 0});
       return;
     }
     const uint64_t h = FrHash()(k);
@@ -600,7 +600,7 @@ class ShapeAssembly : public ConstraintSystem {
       entry = tag | slot;
       coeffs.push_back(k);
     }
-    terms[m].push_back(Term{v.kind, (uint32_t)v.idx, slot});
+    terms[m].push_back(Term{v.kind(), (uint32_t)v.idx(), slot});
   }
   struct Hooked { ShapeAssembly *cs; int m; };
   static void hook(void *self, Variable v, const Fr &k) {
