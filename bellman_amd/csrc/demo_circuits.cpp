@@ -94,6 +94,43 @@ class ChainCircuit : public Circuit {
   }
 };
 
+// Every way a linear combination can reach `enforce` through the mirror (test fixture: tests/circuits.py::forms_circuit is
+// the same circuit against the oracle's ConstraintSystem).  Per round i, on variables v (aux), w (aux), p (a public input
+// every third round) and constants k, k2 from SplitMix64(seed):
+//   A: evaluating terms that need a product ((k, v): coefficient and value both != 1), `-`, a zero coefficient, a repeat
+//   B: a STORED combination built from LinearCombination::zero(), ignoring the closure's argument - five or six terms, so
+//      that it spills out of the inline storage - with both kinds of variable
+//   C: the argument returned untouched by every third round (the empty combination), else `lc + out`
+// The constraints are not meant to be satisfiable: ProvingAssignment evaluates whatever it is given.
+class FormsCircuit : public Circuit {
+ public:
+  uint64_t seed;
+  size_t rounds;
+  Fr x0;
+  void synthesize(ConstraintSystem &cs) override {
+    uint64_t st = seed;
+    Fr v_value = x0, w_value = x0 * x0 + Fr::from_u64(3);
+    Variable v = cs.alloc([&] { return v_value; });
+    Variable w = cs.alloc([&] { return w_value; });
+    for (size_t i = 0; i < rounds; i++) {
+      const Fr k = Fr::from_u64(ChainCircuit::splitmix(st)), k2 = Fr::from_u64(ChainCircuit::splitmix(st) | 1);
+      const Fr out_value = (v_value * k - w_value) * k2;
+      Variable out = (i % 3 == 2) ? cs.alloc_input([&] { return out_value; }) : cs.alloc([&] { return out_value; });
+      const Variable one = ConstraintSystem::one();
+      cs.enforce(
+          [&](LinearCombination lc) { return lc + std::make_pair(k, v) - w - std::make_pair(k2, one) + std::make_pair(Fr::zero(), out) + v; },
+          [&](LinearCombination) {
+            LinearCombination s = LinearCombination::zero() + v + std::make_pair(k2, w) - std::make_pair(k, one) + one - out;
+            if (i & 1) s = s + std::make_pair(k, out);
+            return s;
+          },
+          [&](LinearCombination lc) { return (i % 3 == 0) ? lc : lc + out; });
+      v = w; v_value = w_value;
+      w = out; w_value = out_value;
+    }
+  }
+};
+
 }  // namespace groth16
 
 template <class F>
@@ -109,6 +146,13 @@ static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const
   }
   if (circuit_kind == 1) {   // chain: witness = x0, `size` rounds
     ChainCircuit c;
+    c.seed = seed; c.rounds = size;
+    c.x0 = Fr::zero();
+    if (witness) memcpy(&c.x0, witness, 32);
+    return f(c);
+  }
+  if (circuit_kind == 2) {   // every form of linear combination (test fixture): witness = x0, `size` rounds
+    FormsCircuit c;
     c.seed = seed; c.rounds = size;
     c.x0 = Fr::zero();
     if (witness) memcpy(&c.x0, witness, 32);

@@ -101,3 +101,38 @@ def chain_assignment_fast(rounds, seed, x0):
     b_input_density = [True, False]
     return dict(a=a_ev, b=b_ev, c=c_ev, input_assignment=[1, out], aux_assignment=xs,
                 a_aux_density=a_aux_density, b_input_density=b_input_density, b_aux_density=b_aux_density)
+
+
+def forms_circuit(rounds, seed, x0):
+    """FormsCircuit::synthesize of csrc/demo_circuits.cpp: every way a linear combination can reach `enforce` through the
+    C++ mirror - evaluating terms that need a product, subtraction, zero coefficients, repeated variables, stored
+    combinations of five and six terms that ignore the closure's argument, the empty combination.  Written against the
+    ConstraintSystem interface of oracle/pyref/core.py (the terms of `LinearCombination(Q)` are what the C++ stored
+    combination holds)."""
+    from oracle.pyref.core import LinearCombination
+
+    def synth(cs):
+        st = seed & MASK64
+        v_v = x0 % Q
+        w_v = (v_v * v_v + 3) % Q
+        v = cs.alloc(lambda: v_v)
+        w = cs.alloc(lambda: w_v)
+        for i in range(rounds):
+            st, k = _splitmix(st)
+            st, k2 = _splitmix(st)
+            k, k2 = k % Q, (k2 | 1) % Q
+            out_v = (v_v * k - w_v) * k2 % Q
+            out = cs.alloc_input(lambda: out_v) if i % 3 == 2 else cs.alloc(lambda: out_v)
+            one = cs.one()
+
+            def b_side(_lc):
+                s = LinearCombination(Q) + v + (k2, w) - (k, one) + one - out
+                if i & 1:
+                    s = s + (k, out)
+                return s
+
+            cs.enforce(lambda lc: lc + (k, v) - w - (k2, one) + (0, out) + v, b_side, (lambda lc: lc) if i % 3 == 0 else (lambda lc: lc + out))
+            v, v_v = w, w_v
+            w, w_v = out, out_v
+
+    return synth

@@ -86,6 +86,42 @@ def test_demo_assignment_matches_the_python_restatement():
         assert list(bits) == list(f[key]), key
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 7, 200])
+def test_every_form_of_linear_combination_matches_the_oracle(rounds):
+    """The C++ mirror's ProvingAssignment on FormsCircuit (evaluating terms with a product, `-`, zero coefficients, stored
+    combinations that spill out of the inline storage, the empty combination, public inputs in the middle) == the oracle's
+    ProvingAssignment (oracle/pyref/prover.py, prover.rs:57-162) on tests.circuits.forms_circuit: evaluations, assignments
+    and the three density maps; and the structure capture of the same circuit agrees with its own ProvingAssignment
+    (bh_test_capture_check: the captured matrices times the assignment).  Host code only."""
+    import ctypes
+
+    from bellman_amd import _lib
+    from bellman_amd import groth16 as pg
+    from oracle import cref
+    from oracle.pyref import prover as oprover
+    from oracle.pyref.core import INPUT, Variable
+    from tests import circuits
+
+    seed, x0 = 7 + rounds, 0x1234567890ABCDEF
+    asg = pg.demo_assignment(2, rounds, seed, [x0])
+    pa = oprover.ProvingAssignment(circuits.Q)
+    pa.alloc_input(lambda: 1)
+    circuits.forms_circuit(rounds, seed, x0)(pa)
+    for i in range(len(pa.input_assignment)):   # prover.rs:208-215
+        pa.enforce(lambda lc: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
+    for key in ("a", "b", "c", "input_assignment", "aux_assignment"):
+        assert cref.arr_to_ints(cref.fr_from_mont(asg[key])) == [v % circuits.Q for v in getattr(pa, key)], key
+    for key in ("a_aux_density", "b_input_density", "b_aux_density"):
+        want = getattr(pa, key).bv
+        bits = np.unpackbits(asg[key].view(np.uint8), bitorder="little")[:len(want)].astype(bool)
+        assert list(bits) == [bool(b) for b in want], key
+    lib = _lib.load()
+    lib.bh_test_capture_check.restype = ctypes.c_double
+    out4 = (ctypes.c_size_t * 4)()
+    ms = lib.bh_test_capture_check(2, ctypes.c_size_t(rounds), ctypes.c_uint64(seed), out4)
+    assert ms >= 0 and out4[0] == len(pa.a) and out4[3] == 0, list(out4)
+
+
 def test_prover_rs_patch_and_shim_are_consistent():
     patch = open(os.path.join(ROOT, "shim", "patches", "bellman-hip.patch")).read()
     assert "+++ b/groth16/src/prover.rs" in patch and "+++ b/groth16/Cargo.toml" in patch
