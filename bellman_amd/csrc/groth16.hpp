@@ -290,6 +290,16 @@ struct LcSink {
   // records the structure of the circuit - the R1CS capture - takes the terms straight into its matrices)
   void (*hook)(void *self, Variable v, const Fr &coeff) = nullptr;
   void *self = nullptr;
+  // the running value of the combination bound to this sink.  It lives HERE, not in the LinearCombination objects that
+  // travel through `|lc| lc + a + b` (one copy, one or two moves and a return per closure): those then carry two words,
+  // and the accumulator is updated in place instead of being copied from object to object between additions (synthesis
+  // of the 2^20-constraint chain 139 -> 125 ms in the build container).  Consequence, and the CONTRACT of enforce's closures:
+  // every term added to ANY copy of the closure's argument counts - in the value as in the density maps.  A closure returns a
+  // combination derived linearly from its argument (`|lc| lc + a + (c, b)`, as every closure of the reference's circuits and
+  // gadgets does; in Rust `lc + a` consumes `lc`, so using it twice takes an explicit clone) or a stored combination that
+  // it built from LinearCombination::zero() without touching its argument.  Counting the terms in the sink as well, to
+  // detect the misuse, was measured at 5 % of the synthesis and left out.
+  mutable Fr acc = Fr::zero();
 };
 // Copy of a field element that was just computed: limb by limb through general registers.  A struct copy compiles to two
 // 16-byte vector moves, and a 16-byte load from a location that two 8-byte stores have just written cannot be forwarded
@@ -309,26 +319,26 @@ class LinearCombination {
   static LinearCombination evaluating(const LcSink *sink) {
     LinearCombination r;
     r.sink_ = sink;
-    r.acc_ = Fr::zero();
+    sink->acc = Fr::zero();
     return r;
   }
   LinearCombination() : n_(0), sink_(nullptr) {}
   LinearCombination(const LinearCombination &o) : n_(o.n_), sink_(o.sink_) {
-    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+    if (!sink_) { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
   }
   LinearCombination(LinearCombination &&o) noexcept : n_(o.n_), sink_(o.sink_) {
-    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+    if (!sink_) { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
   }
   LinearCombination &operator=(const LinearCombination &o) {
     if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
-    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
+    if (!sink_) { memcpy(inl_, o.inl_, sizeof inl_); more_ = o.more_; }
     return *this;
   }
   LinearCombination &operator=(LinearCombination &&o) noexcept {
     if (this == &o) return *this;
     n_ = o.n_; sink_ = o.sink_;
-    if (sink_) copy_fresh(acc_, o.acc_); else { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
+    if (!sink_) { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
     return *this;
   }
   // lvalue operands are copied (value semantics); a temporary is extended in place and MOVED out - returned by value,
@@ -348,8 +358,8 @@ class LinearCombination {
   // stored combinations only
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
   bool is_evaluating() const { return sink_ != nullptr; }
-  Fr value() const { Fr r; copy_fresh(r, acc_); return r; }   // evaluating combinations only
-  void value_into(Fr &dst) const { copy_fresh(dst, acc_); }
+  Fr value() const { Fr r; copy_fresh(r, sink_->acc); return r; }   // evaluating combinations only
+  void value_into(Fr &dst) const { copy_fresh(dst, sink_->acc); }
 
  private:
   static constexpr size_t INLINE = 4;
@@ -372,8 +382,9 @@ class LinearCombination {
       if (__builtin_expect(sink_->hook != nullptr, 0)) { sink_->hook(sink_->self, v, c); return; }
       const Fr *value = locate(v);
       // most terms carry the coefficient one (`lc + x`: push_one), then the ubiquitous `(c, CS::one())` terms: value one
-      if (*value == Fr::one()) acc_ = acc_ + c;
-      else if (c == Fr::one()) acc_ = acc_ + *value;
+      Fr &acc = sink_->acc;
+      if (*value == Fr::one()) acc = acc + c;
+      else if (c == Fr::one()) acc = acc + *value;
       else add_product(*value, c);
       return;
     }
@@ -382,12 +393,12 @@ class LinearCombination {
   __attribute__((always_inline)) void push_one(Variable v) {   // coefficient one
     if (__builtin_expect(sink_ != nullptr && sink_->hook == nullptr, 1)) {
       n_++;
-      acc_ = acc_ + *locate(v);
+      sink_->acc = sink_->acc + *locate(v);
       return;
     }
     push(v, Fr::one());
   }
-  __attribute__((noinline)) void add_product(const Fr &value, const Fr &c) { acc_ = acc_ + value * c; }
+  __attribute__((noinline)) void add_product(const Fr &value, const Fr &c) { sink_->acc = sink_->acc + value * c; }
   __attribute__((noinline)) void push_stored(Variable v, const Fr &c) {
     if (n_ <= INLINE) inl_[n_ - 1] = Term{v, c}; else more_.push_back(Term{v, c});
   }
@@ -395,7 +406,6 @@ class LinearCombination {
   std::vector<Term> more_;
   size_t n_;
   const LcSink *sink_;
-  Fr acc_;
 };
 
 // Non-owning callable reference (two pointers, never allocates): the C++ stand-in for the

@@ -113,8 +113,9 @@ void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) 
   // that evaluate each term as it is added (groth16.hpp); a closure that returns some other, stored combination is
   // evaluated the classic way.  CONTRACT of the evaluating form (the reference's `eval` walks only the RETURNED
   // combination, prover.rs:19-55): a closure returns a combination derived linearly from its argument - terms added to a
-  // copy that is then discarded would still count in the density maps.  Every closure of the reference's own circuits
-  // and gadgets has that shape (`|lc| lc + a + (c, b)`).
+  // copy that is then discarded would still count in the value and in the density maps (the accumulator lives in the sink,
+  // groth16.hpp LcSink::acc) - or a stored combination built without touching the argument.  Every closure of the
+  // reference's own circuits and gadgets has the first shape (`|lc| lc + a + (c, b)`).
   const std::vector<Fr> *in = &input_assignment, *ax = &aux_assignment;
   const LcSink sa{in, ax, nullptr, &a_aux_density}, sb{in, ax, &b_input_density, &b_aux_density}, sc{in, ax, nullptr, nullptr};
   // (the value goes from the combination's accumulator into the vector's new slot limb by limb: handed on as an Fr it is
@@ -615,7 +616,7 @@ class ShapeAssembly : public ConstraintSystem {
       Hooked h{this, m};
       LcSink sink{nullptr, nullptr, nullptr, nullptr, &ShapeAssembly::hook, &h};
       const LinearCombination r = (*fs[m])(LinearCombination::evaluating(&sink));
-      if (!r.is_evaluating())
+        if (!r.is_evaluating())
         for (size_t i = 0; i < r.size(); i++) add_term(m, r[i].first, r[i].second);
       row_ptr[m].push_back((uint32_t)terms[m].size());
     }
