@@ -6,6 +6,9 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <x86intrin.h>   // _addcarry_u64 / _subborrow_u64
+#endif
 
 namespace bh {
 
@@ -29,11 +32,6 @@ static const uint64_t ONE[6] = {0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x
 // doubling ladder that closes every multiexp, create_proof's few scalar multiplications) where a mispredicted branch is
 // paid in full.
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-}  // namespace hostfp
-}  // namespace bh
-#include <x86intrin.h>
-namespace bh {
-namespace hostfp {
 typedef unsigned char carry_t;
 static inline __attribute__((always_inline)) uint64_t adc(uint64_t a, uint64_t b, carry_t &c) { unsigned long long r; c = _addcarry_u64(c, a, b, &r); return r; }
 static inline __attribute__((always_inline)) uint64_t sbb(uint64_t a, uint64_t b, carry_t &c) { unsigned long long r; c = _subborrow_u64(c, a, b, &r); return r; }
