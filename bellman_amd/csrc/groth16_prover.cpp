@@ -566,9 +566,17 @@ struct FrHash {
 class ShapeAssembly : public ConstraintSystem {
  public:
   size_t num_inputs = 0, num_aux = 0;
-  struct Term { Index kind; uint32_t idx, coeff; };
-  std::vector<uint32_t> row_ptr[3];
-  std::vector<Term> terms[3];
+  // the matrices in the layout bh_r1cs_create takes (CSR: row_ptr, variable, coefficient-table index), written once.  A
+  // variable is stored as its index with AUX_BIT for an aux variable until the capture ends: only then is the number
+  // of inputs known, and `finish` turns every entry into its column (inputs first, then aux) in place.
+  static constexpr uint32_t AUX_BIT = 0x80000000u;
+  std::vector<uint32_t> row_ptr[3], var[3], coeff[3];
+  static uint32_t pack(const Variable &v) { return (uint32_t)v.idx() | (v.kind() == Index::Aux ? AUX_BIT : 0u); }
+  void finish() {
+    const uint32_t ni = (uint32_t)num_inputs;
+    for (auto &vm : var)
+      for (uint32_t &x : vm) x = (x & AUX_BIT) ? ni + (x & ~AUX_BIT) : x;
+  }
   std::vector<Fr> coeffs;
   // Coefficients are shared through a direct-mapped cache of table indices, not an exact map: a circuit's constants
   // (round constants, powers of two) repeat and hit; a circuit whose coefficients are all different (the synthetic
@@ -589,7 +597,7 @@ class ShapeAssembly : public ConstraintSystem {
   void add_term(int m, const Variable &v, const Fr &k) {
     if (k.is_zero()) return;     // prover.rs:31: no value, no density
     if (k == one_) {             // the usual `lc + x` term: coefficient table entry 0, no hash lookup
-      terms[m].push_back(Term{v.kind(), (uint32_t)v.idx(), 0});
+      var[m].push_back(pack(v)); coeff[m].push_back(0);
       return;
     }
     const uint64_t h = FrHash()(k);
@@ -601,7 +609,7 @@ class ShapeAssembly : public ConstraintSystem {
       entry = tag | slot;
       coeffs.push_back(k);
     }
-    terms[m].push_back(Term{v.kind(), (uint32_t)v.idx(), slot});
+    var[m].push_back(pack(v)); coeff[m].push_back(slot);
   }
   struct Hooked { ShapeAssembly *cs; int m; };
   static void hook(void *self, Variable v, const Fr &k) {
@@ -618,7 +626,7 @@ class ShapeAssembly : public ConstraintSystem {
       const LinearCombination r = (*fs[m])(LinearCombination::evaluating(&sink));
         if (!r.is_evaluating())
         for (size_t i = 0; i < r.size(); i++) add_term(m, r[i].first, r[i].second);
-      row_ptr[m].push_back((uint32_t)terms[m].size());
+      row_ptr[m].push_back((uint32_t)var[m].size());
     }
   }
 };
@@ -632,6 +640,9 @@ static void capture_shape(Circuit &shape_of, ShapeAssembly &cs) {
     cs.enforce([i](LinearCombination lc) { return lc + Variable::new_unchecked(Index::Input, i); },
                [](LinearCombination lc) { return lc; }, [](LinearCombination lc) { return lc; });
   }
+  if (cs.num_inputs + cs.num_aux >= ShapeAssembly::AUX_BIT)   // columns are 32-bit on the device (csrc/r1cs.hip)
+    throw std::invalid_argument("R1CS capture: more than 2^31 variables");
+  cs.finish();
 }
 // host-only self check (bh_test_capture_check): the captured matrices times the assignment a ProvingAssignment
 // computes for the same circuit must give that assignment's a, b, c rows.  out4 = [constraints, terms, coefficients in
@@ -655,14 +666,14 @@ double capture_check_for_tests(Circuit &shape_of, Circuit &proved, size_t out4[4
     for (size_t r = 0; r < rows; r++) {
       Fr acc = Fr::zero();
       for (uint32_t t = cs.row_ptr[m][r]; t < cs.row_ptr[m][r + 1]; t++) {
-        const auto &term = cs.terms[m][t];
-        const Fr &v = term.kind == Index::Input ? pa.input_assignment[term.idx] : pa.aux_assignment[term.idx];
-        acc = acc + cs.coeffs[term.coeff] * v;
+        const uint32_t col = cs.var[m][t];   // (after finish: inputs first, then aux)
+        const Fr &v = col < cs.num_inputs ? pa.input_assignment[col] : pa.aux_assignment[col - cs.num_inputs];
+        acc = acc + cs.coeffs[cs.coeff[m][t]] * v;
       }
       if (!(acc == (*want[m])[r])) bad++;
     }
   }
-  out4[0] = rows; out4[1] = cs.terms[0].size() + cs.terms[1].size() + cs.terms[2].size(); out4[2] = cs.coeffs.size(); out4[3] = bad;
+  out4[0] = rows; out4[1] = cs.var[0].size() + cs.var[1].size() + cs.var[2].size(); out4[2] = cs.coeffs.size(); out4[3] = bad;
   return ms;
 }
 
@@ -670,16 +681,8 @@ R1cs::R1cs(Circuit &shape_of, bh_ctx *ctx) {
   ShapeAssembly cs;
   capture_shape(shape_of, cs);
   num_inputs = cs.num_inputs; num_aux = cs.num_aux; num_constraints = cs.row_ptr[0].size() - 1;
-  std::vector<uint32_t> var[3], coeff[3];
   bh_csr abc[3];
-  for (int m = 0; m < 3; m++) {
-    var[m].reserve(cs.terms[m].size()); coeff[m].reserve(cs.terms[m].size());
-    for (const auto &t : cs.terms[m]) {
-      var[m].push_back(t.kind == Index::Input ? t.idx : (uint32_t)(num_inputs + t.idx));   // inputs first, then aux
-      coeff[m].push_back(t.coeff);
-    }
-    abc[m] = bh_csr{cs.row_ptr[m].data(), var[m].data(), coeff[m].data()};
-  }
+  for (int m = 0; m < 3; m++) abc[m] = bh_csr{cs.row_ptr[m].data(), cs.var[m].data(), cs.coeff[m].data()};
   check(bh_r1cs_create(ctx, num_inputs, num_aux, num_constraints, abc, cs.coeffs.data(), cs.coeffs.size(), &handle));
 }
 R1cs::R1cs(bh_r1cs *existing) : handle(existing) {
