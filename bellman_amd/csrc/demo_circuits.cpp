@@ -131,6 +131,79 @@ class FormsCircuit : public Circuit {
   }
 };
 
+// A circuit whose STRUCTURE is drawn from SplitMix64(seed) - how many variables a round allocates and of which kind, and for
+// each of a constraint's three combinations: empty, a chain of 1..9 terms on the closure's argument, or a stored
+// combination of 0..9 terms built from zero(); each term +v, -v, +(k, v) or -(k, v) with k from {0, 1, -1, small, random}
+// and v any variable allocated so far (ONE included).  tests/circuits.py::random_circuit draws the same sequence.
+// Test fixture (not satisfiable): the mirror's ProvingAssignment and structure capture against the oracle's.
+class RandomCircuit : public Circuit {
+ public:
+  uint64_t seed;
+  size_t rounds;
+  Fr x0;
+  struct Draw {
+    uint64_t st;
+    uint64_t next() { return ChainCircuit::splitmix(st); }
+    uint64_t below(uint64_t n) { return next() % n; }
+  };
+  void synthesize(ConstraintSystem &cs) override {
+    Draw d{seed};
+    std::vector<Variable> vars;
+    vars.push_back(ConstraintSystem::one());
+    Fr value = x0;
+    auto fresh_value = [&] { value = value * value + Fr::from_u64(d.next()); return value; };
+    auto coefficient = [&]() -> Fr {
+      switch (d.below(5)) {
+        case 0: return Fr::zero();
+        case 1: return Fr::one();
+        case 2: return Fr::one().neg();
+        case 3: return Fr::from_u64(d.below(16));
+        default: return Fr::from_u64(d.next()) * Fr::from_u64(d.next());
+      }
+    };
+    struct TermSpec { int op; Fr k; Variable v; };
+    struct Side { int form; std::vector<TermSpec> terms; };
+    auto apply = [](LinearCombination lc, const std::vector<TermSpec> &terms) {
+      for (const TermSpec &t : terms) {
+        switch (t.op) {
+          case 0: lc = std::move(lc) + t.v; break;
+          case 1: lc = std::move(lc) - t.v; break;
+          case 2: lc = std::move(lc) + std::make_pair(t.k, t.v); break;
+          default: lc = std::move(lc) - std::make_pair(t.k, t.v); break;
+        }
+      }
+      return lc;
+    };
+    for (size_t i = 0; i < rounds; i++) {
+      const uint64_t n_new = d.below(3);
+      for (uint64_t j = 0; j < n_new; j++) {
+        const bool input = d.below(4) == 0;
+        const Fr v = fresh_value();
+        vars.push_back(input ? cs.alloc_input([&] { return v; }) : cs.alloc([&] { return v; }));
+      }
+      Side side[3];
+      for (Side &s : side) {
+        s.form = (int)d.below(3);
+        const uint64_t n_terms = s.form == 0 ? 0 : (s.form == 1 ? 1 + d.below(9) : d.below(10));
+        for (uint64_t t = 0; t < n_terms; t++) {
+          TermSpec ts;
+          ts.op = (int)d.below(4);
+          ts.k = ts.op >= 2 ? coefficient() : Fr::one();
+          ts.v = vars[d.below(vars.size())];
+          s.terms.push_back(ts);
+        }
+      }
+      auto closure = [&](const Side &s) {
+        return [&s, &apply](LinearCombination lc) {
+          if (s.form == 2) return apply(LinearCombination::zero(), s.terms);   // stored; the argument is not touched
+          return apply(std::move(lc), s.terms);                                // (form 0: no terms - the argument itself)
+        };
+      };
+      cs.enforce(closure(side[0]), closure(side[1]), closure(side[2]));
+    }
+  }
+};
+
 }  // namespace groth16
 
 template <class F>
@@ -146,6 +219,13 @@ static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const
   }
   if (circuit_kind == 1) {   // chain: witness = x0, `size` rounds
     ChainCircuit c;
+    c.seed = seed; c.rounds = size;
+    c.x0 = Fr::zero();
+    if (witness) memcpy(&c.x0, witness, 32);
+    return f(c);
+  }
+  if (circuit_kind == 3) {   // structure drawn from the seed (test fixture): witness = x0, `size` rounds
+    RandomCircuit c;
     c.seed = seed; c.rounds = size;
     c.x0 = Fr::zero();
     if (witness) memcpy(&c.x0, witness, 32);

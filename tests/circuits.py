@@ -136,3 +136,80 @@ def forms_circuit(rounds, seed, x0):
             w, w_v = out, out_v
 
     return synth
+
+
+def random_circuit(rounds, seed, x0):
+    """RandomCircuit::synthesize of csrc/demo_circuits.cpp: the structure of every constraint is drawn from
+    SplitMix64(seed) - the same draws in the same order as the C++ fixture."""
+    from oracle.pyref.core import LinearCombination
+
+    class Draw:
+        def __init__(self, st):
+            self.st = st & MASK64
+
+        def next(self):
+            self.st, z = _splitmix(self.st)
+            return z
+
+        def below(self, n):
+            return self.next() % n
+
+    def synth(cs):
+        d = Draw(seed)
+        vs = [cs.one()]
+        value = [x0 % Q]
+
+        def fresh_value():
+            value[0] = (value[0] * value[0] + d.next()) % Q
+            return value[0]
+
+        def coefficient():
+            c = d.below(5)
+            if c == 0:
+                return 0
+            if c == 1:
+                return 1
+            if c == 2:
+                return Q - 1
+            if c == 3:
+                return d.below(16)
+            a = d.next()
+            return a * d.next() % Q
+
+        def apply(lc, terms):
+            for op, k, v in terms:
+                if op == 0:
+                    lc = lc + v
+                elif op == 1:
+                    lc = lc - v
+                elif op == 2:
+                    lc = lc + (k, v)
+                else:
+                    lc = lc - (k, v)
+            return lc
+
+        for _ in range(rounds):
+            for _j in range(d.below(3)):
+                is_input = d.below(4) == 0
+                v = fresh_value()
+                vs.append(cs.alloc_input(lambda: v) if is_input else cs.alloc(lambda: v))
+            sides = []
+            for _s in range(3):
+                form = d.below(3)
+                n_terms = 0 if form == 0 else (1 + d.below(9) if form == 1 else d.below(10))
+                terms = []
+                for _t in range(n_terms):
+                    op = d.below(4)
+                    k = coefficient() if op >= 2 else 1
+                    terms.append((op, k, vs[d.below(len(vs))]))
+                sides.append((form, terms))
+
+            def closure(side):
+                form, terms = side
+                if form == 2:
+                    return lambda _lc: apply(LinearCombination(Q), terms)
+                return lambda lc: apply(lc, terms)
+
+            cs.enforce(closure(sides[0]), closure(sides[1]), closure(sides[2]))
+
+    return synth

@@ -86,11 +86,13 @@ def test_demo_assignment_matches_the_python_restatement():
         assert list(bits) == list(f[key]), key
 
 
-@pytest.mark.parametrize("rounds", [1, 2, 7, 200])
-def test_every_form_of_linear_combination_matches_the_oracle(rounds):
+@pytest.mark.parametrize("kind,rounds", [(2, 1), (2, 2), (2, 7), (2, 200), (3, 1), (3, 5), (3, 60), (3, 400), (3, 401), (3, 1500)])
+def test_every_form_of_linear_combination_matches_the_oracle(kind, rounds):
     """The C++ mirror's ProvingAssignment on FormsCircuit (evaluating terms with a product, `-`, zero coefficients, stored
     combinations that spill out of the inline storage, the empty combination, public inputs in the middle) == the oracle's
-    ProvingAssignment (oracle/pyref/prover.py, prover.rs:57-162) on tests.circuits.forms_circuit: evaluations, assignments
+    ProvingAssignment (oracle/pyref/prover.py, prover.rs:57-162) on tests.circuits.forms_circuit - and the same for
+    RandomCircuit / random_circuit (kind 3), whose structure (variables per round, empty / chained / stored combinations
+    of up to 9 terms, +, -, coefficients 0, 1, -1, small, random, any earlier variable) is drawn from the seed: evaluations, assignments
     and the three density maps; and the structure capture of the same circuit agrees with its own ProvingAssignment
     (bh_test_capture_check: the captured matrices times the assignment).  Host code only."""
     import ctypes
@@ -103,10 +105,10 @@ def test_every_form_of_linear_combination_matches_the_oracle(rounds):
     from tests import circuits
 
     seed, x0 = 7 + rounds, 0x1234567890ABCDEF
-    asg = pg.demo_assignment(2, rounds, seed, [x0])
+    asg = pg.demo_assignment(kind, rounds, seed, [x0])
     pa = oprover.ProvingAssignment(circuits.Q)
     pa.alloc_input(lambda: 1)
-    circuits.forms_circuit(rounds, seed, x0)(pa)
+    (circuits.forms_circuit if kind == 2 else circuits.random_circuit)(rounds, seed, x0)(pa)
     for i in range(len(pa.input_assignment)):   # prover.rs:208-215
         pa.enforce(lambda lc: lc + Variable(INPUT, i), lambda lc: lc, lambda lc: lc)
     for key in ("a", "b", "c", "input_assignment", "aux_assignment"):
@@ -118,7 +120,7 @@ def test_every_form_of_linear_combination_matches_the_oracle(rounds):
     lib = _lib.load()
     lib.bh_test_capture_check.restype = ctypes.c_double
     out4 = (ctypes.c_size_t * 4)()
-    ms = lib.bh_test_capture_check(2, ctypes.c_size_t(rounds), ctypes.c_uint64(seed), out4)
+    ms = lib.bh_test_capture_check(kind, ctypes.c_size_t(rounds), ctypes.c_uint64(seed), out4)
     assert ms >= 0 and out4[0] == len(pa.a) and out4[3] == 0, list(out4)
 
 
