@@ -124,6 +124,32 @@ def test_every_form_of_linear_combination_matches_the_oracle(kind, rounds):
     assert ms >= 0 and out4[0] == len(pa.a) and out4[3] == 0, list(out4)
 
 
+def test_mirror_under_sanitizers(tmp_path):
+    """tests/cpp/mirror_sanitized.cpp: synthesis of the fixture circuits through the mirror (inline-assembly field
+    arithmetic, evaluating / stored combinations, capture) under ASan + UBSan; every captured matrix must reproduce its
+    ProvingAssignment."""
+    import shutil
+    import subprocess
+
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = shutil.which("clang++") or shutil.which("g++")
+    csrc = os.path.join(ROOT, "bellman_amd", "csrc")
+    libdir = os.path.join(ROOT, "bellman_amd", "lib")
+    exe = str(tmp_path / "mirror_sanitized.bin")
+    cmd = [cxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-mbmi2", "-madx", "-std=c++17",
+           os.path.join(ROOT, "tests", "cpp", "mirror_sanitized.cpp")] + \
+          [os.path.join(csrc, f) for f in ("demo_circuits.cpp", "groth16_prover.cpp", "groth16_fr.cpp")] + \
+          ["-o", exe, "-L" + libdir, "-lbellman_hip", "-Wl,-rpath," + libdir]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "sanitizer" in (build.stderr + build.stdout).lower():
+        pytest.skip("no sanitizer runtime for this compiler")
+    assert build.returncode == 0, build.stderr[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0 and "synthesis ms" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 def test_prover_rs_patch_and_shim_are_consistent():
     patch = open(os.path.join(ROOT, "shim", "patches", "bellman-hip.patch")).read()
     assert "+++ b/groth16/src/prover.rs" in patch and "+++ b/groth16/Cargo.toml" in patch
