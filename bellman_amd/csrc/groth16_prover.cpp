@@ -624,7 +624,7 @@ class ShapeAssembly : public ConstraintSystem {
       Hooked h{this, m};
       LcSink sink{nullptr, nullptr, nullptr, nullptr, &ShapeAssembly::hook, &h};
       const LinearCombination r = (*fs[m])(LinearCombination::evaluating(&sink));
-        if (!r.is_evaluating())
+      if (!r.is_evaluating())
         for (size_t i = 0; i < r.size(); i++) add_term(m, r[i].first, r[i].second);
       row_ptr[m].push_back((uint32_t)var[m].size());
     }
