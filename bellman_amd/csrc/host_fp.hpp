@@ -72,7 +72,7 @@ static inline void sub(hfp_t &r, const hfp_t &a, const hfp_t &b) {
 // mulx with the two carry chains of adcx / adox (compilers do not produce them from C): one product row and one reduction
 // step per asm block; the Makefile passes -mbmi2 -madx to the HOST half of the .hip files for this.
 #define BH_HFP_MULADD(src, tlo, thi) "mulx " src ", %[lo], %[hi]\n\t adcx %[lo], " tlo "\n\t adox %[hi], " thi "\n\t"
-#define BH_HFP_ROW(bi, first)                                                                                        \
+#define BH_HFP_ROW(bi)                                                                                               \
   asm("xorl %%eax, %%eax\n\t"                                                                                        \
       BH_HFP_MULADD("%[a0]", "%[t0]", "%[t1]") BH_HFP_MULADD("%[a1]", "%[t1]", "%[t2]")                              \
       BH_HFP_MULADD("%[a2]", "%[t2]", "%[t3]") BH_HFP_MULADD("%[a3]", "%[t3]", "%[t4]")                              \
@@ -102,12 +102,12 @@ static inline void sub(hfp_t &r, const hfp_t &a, const hfp_t &b) {
   }
 static inline void mul(hfp_t &r, const hfp_t &a, const hfp_t &b) {
   uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6, lo, hi;
-  BH_HFP_ROW(b.l[0], 1); BH_HFP_REDUCE();
-  BH_HFP_ROW(b.l[1], 0); BH_HFP_REDUCE();
-  BH_HFP_ROW(b.l[2], 0); BH_HFP_REDUCE();
-  BH_HFP_ROW(b.l[3], 0); BH_HFP_REDUCE();
-  BH_HFP_ROW(b.l[4], 0); BH_HFP_REDUCE();
-  BH_HFP_ROW(b.l[5], 0); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[0]); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[1]); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[2]); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[3]); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[4]); BH_HFP_REDUCE();
+  BH_HFP_ROW(b.l[5]); BH_HFP_REDUCE();
   const uint64_t t[6] = {t0, t1, t2, t3, t4, t5};
   final_sub(r.l, t);
 }
