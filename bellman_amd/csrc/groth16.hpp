@@ -341,19 +341,20 @@ class LinearCombination {
     if (!sink_) { memcpy(inl_, o.inl_, sizeof inl_); more_ = std::move(o.more_); }
     return *this;
   }
+  // (always_inline: as calls from a closure into the header's out-of-line copy they cost 4 % of a 2^20-constraint synthesis)
   // lvalue operands are copied (value semantics); a temporary is extended in place and MOVED out - returned by value,
   // so that `lc = std::move(lc) + x` is not a self-move and `auto &&r = zero() + a` does not dangle (moving an
   // evaluating combination is a 56-byte copy)
-  LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push_one(v); return r; }
-  LinearCombination operator+(Variable v) && { push_one(v); return std::move(*this); }
-  LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
-  LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
+  __attribute__((always_inline)) LinearCombination operator+(Variable v) const & { LinearCombination r(*this); r.push_one(v); return r; }
+  __attribute__((always_inline)) LinearCombination operator+(Variable v) && { push_one(v); return std::move(*this); }
+  __attribute__((always_inline)) LinearCombination operator-(Variable v) const & { LinearCombination r(*this); r.push(v, Fr::one().neg()); return r; }
+  __attribute__((always_inline)) LinearCombination operator-(Variable v) && { push(v, Fr::one().neg()); return std::move(*this); }
   // ((coefficient, variable) terms by reference: a 56-byte pair passed by value is copied with 16-byte loads that straddle
   //  the 8-byte stores which have just built it - a failed store forwarding per term)
-  LinearCombination operator+(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
-  LinearCombination operator+(const std::pair<Fr, Variable> &t) && { push(t.second, t.first); return std::move(*this); }
-  LinearCombination operator-(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
-  LinearCombination operator-(const std::pair<Fr, Variable> &t) && { push(t.second, t.first.neg()); return std::move(*this); }
+  __attribute__((always_inline)) LinearCombination operator+(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first); return r; }
+  __attribute__((always_inline)) LinearCombination operator+(const std::pair<Fr, Variable> &t) && { push(t.second, t.first); return std::move(*this); }
+  __attribute__((always_inline)) LinearCombination operator-(const std::pair<Fr, Variable> &t) const & { LinearCombination r(*this); r.push(t.second, t.first.neg()); return r; }
+  __attribute__((always_inline)) LinearCombination operator-(const std::pair<Fr, Variable> &t) && { push(t.second, t.first.neg()); return std::move(*this); }
   size_t size() const { return n_; }
   // stored combinations only
   const Term &operator[](size_t i) const { return i < INLINE ? inl_[i] : more_[i - INLINE]; }
