@@ -997,9 +997,6 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   if (!ctx || !bases || !out) return BH_ERR_INVALID_ARG;
   MsmOpts opts;
   if (shard_ref_n) { opts.ref_n = shard_ref_n; opts.always_resolve_ident = true; }
-  opts.padded_bases = bases->padded;   // (read by the classic plan only)
-  const bool ptab = bases->table && bases->table_padded;
-  opts.padded_table = ptab ? bases->table : nullptr;
   if (o) {
     if (o->window_bits && (o->window_bits < 2 || o->window_bits > 24)) return BH_ERR_INVALID_ARG;
     opts.c = o->window_bits; opts.chunk = o->chunk; opts.flags = o->flags;
@@ -1010,6 +1007,20 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
   // back-pressure (src/multicore.rs:47-73): at the cap the issuing thread completes the oldest job itself
   while (!msm_slot_try_reserve(ctx->c))
     if (!msm_complete_oldest(ctx->c)) std::this_thread::yield();   // the slots are held by calls still issuing
+  // ONE snapshot of the handle's table state, taken after the slot is reserved (bh_ctx_trim leaves tables alone while a
+  // call is issuing) and under job_mu: both the pointer the job gathers from and the stride it is read at come from it
+  // (a trim + bh_bases_precompute between two reads of the handle could pair a freed table with the other stride)
+  void *tab_ptr;
+  bool ptab;
+  WindowTable tab_info;
+  {
+    std::lock_guard<std::mutex> g(ctx->c.job_mu);
+    tab_ptr = bases->table;
+    ptab = tab_ptr && bases->table_padded;
+    tab_info = bases->tab;
+    opts.padded_bases = bases->padded;   // (read by the classic plan only)
+  }
+  opts.padded_table = ptab ? tab_ptr : nullptr;
   MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);
   if (!impl) { msm_slot_release(ctx->c); return BH_ERR_HIP; }
   if (n && n <= TINY_MSM_MAX && scalars_on_host && (!density || density_on_host) && !(opts.flags & BH_MSM_NO_SMALL_PATH) &&
@@ -1048,8 +1059,8 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     }
   }
   if (rc == BH_OK)
-    rc = msm_job_enqueue(*impl, (bases->table && !ptab) ? bases->table : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
-                         opts, bases->table ? &bases->tab : nullptr);
+    rc = msm_job_enqueue(*impl, (tab_ptr && !ptab) ? tab_ptr : bases->dev, bases->n, skip, sc_dev, n, fmt, dn_dev,
+                         opts, tab_ptr ? &tab_info : nullptr);
   if (rc != BH_OK) {
     float ms[4];
     unsigned char dummy[192];

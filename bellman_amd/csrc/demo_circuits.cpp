@@ -204,6 +204,45 @@ class RandomCircuit : public Circuit {
   }
 };
 
+// Closures that BREAK the contract of the evaluating combination (groth16.hpp LcSink): after `rounds` well-behaved
+// constraints, one whose A closure - by seed % 3 - (0) adds a term to a copy of its argument and discards the copy,
+// (1) builds two combinations from its argument and returns one of them, (2) touches its argument and then returns a
+// stored combination.  The reference's `eval` would see only the returned terms; this library's closures are compiled with
+// BELLMAN_HIP_CHECK_CLOSURES, so `enforce` must refuse each of them (std::invalid_argument -> BH_ERR_INVALID_ARG).
+class MisuseCircuit : public Circuit {
+ public:
+  uint64_t seed;
+  size_t rounds;
+  Fr x0;
+  void synthesize(ConstraintSystem &cs) override {
+    Fr v_value = x0;
+    Variable v = cs.alloc([&] { return v_value; });
+    for (size_t i = 0; i < rounds; i++) {
+      const Fr sq = v_value * v_value;
+      Variable n = cs.alloc([&] { return sq; });
+      cs.enforce([&](LinearCombination lc) { return lc + v; }, [&](LinearCombination lc) { return lc + v; },
+                 [&](LinearCombination lc) { return lc + n; });
+      v = n; v_value = sq;
+    }
+    const Variable one = ConstraintSystem::one();
+    const auto same = [&](LinearCombination lc) { return lc + v; };
+    switch (seed % 3) {
+      case 0:
+        cs.enforce([&](LinearCombination lc) { LinearCombination t = lc + one; (void)t; return lc + v; }, same, same);
+        break;
+      case 1:
+        cs.enforce([&](LinearCombination lc) {
+          LinearCombination p = lc + v, q = lc + one + v;
+          return (rounds & 1) ? p : q;
+        }, same, same);
+        break;
+      default:
+        cs.enforce([&](LinearCombination lc) { LinearCombination t = std::move(lc) + v; (void)t; return LinearCombination::zero() + v; }, same, same);
+        break;
+    }
+  }
+};
+
 }  // namespace groth16
 
 template <class F>
@@ -233,6 +272,13 @@ static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const
   }
   if (circuit_kind == 2) {   // every form of linear combination (test fixture): witness = x0, `size` rounds
     FormsCircuit c;
+    c.seed = seed; c.rounds = size;
+    c.x0 = Fr::zero();
+    if (witness) memcpy(&c.x0, witness, 32);
+    return f(c);
+  }
+  if (circuit_kind == 4) {   // closures that break the contract of the evaluating combination (test fixture)
+    MisuseCircuit c;
     c.seed = seed; c.rounds = size;
     c.x0 = Fr::zero();
     if (witness) memcpy(&c.x0, witness, 32);
@@ -293,12 +339,14 @@ double bh_test_capture_check(int circuit_kind, size_t size, uint64_t seed, size_
   for (size_t i = 0; i < constants.size(); i++) constants[i] = Fr::from_u64(0x9E3779B97F4A7C15ULL * (i % 7 + 1));   // repeats: the table must share them
   Fr wit[2] = {Fr::from_u64(123456789), Fr::from_u64(987654321)};
   double ms = -1.0;
+  try {
   with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &shape) -> int {
     return with_demo_circuit(circuit_kind, size, seed, wit, constants.data(), [&](bellman::Circuit &proved) -> int {
       ms = capture_check_for_tests(shape, proved, out4);
       return 0;
     });
   });
+  } catch (...) { return -1.0; }   // (a closure refused by the checking build: MisuseCircuit)
   return ms;
 }
 int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const void *witness, const void *constants,
@@ -326,6 +374,7 @@ int bh_test_demo_assignment(int circuit_kind, size_t size, uint64_t seed, const 
       memcpy(b_aux_density, pa.b_aux_density.words(), (pa.aux_assignment.size() + 63) / 64 * 8);
       return BH_OK;
     });
+  } catch (const std::invalid_argument &) { return BH_ERR_INVALID_ARG;
   } catch (...) { return BH_ERR_HIP; }
 }
 void bh_test_fr_from_u512_host(void *r, const void *limbs8) {

@@ -43,7 +43,17 @@
 
 namespace bh {
 
-constexpr int NTT_THREADS = 256;
+#ifndef BH_FFT_X_THREADS
+#define BH_FFT_X_THREADS 256
+#endif
+constexpr int NTT_THREADS = BH_FFT_X_THREADS;          // 256: 8 elements per thread, radix-8 steps; 512: 4 elements, radix-4 steps
+constexpr int NTT_WAVES_PER_SIMD = NTT_THREADS / 128;  // two workgroups per CU
+constexpr int NTT_GMAX = NTT_THREADS == 256 ? 3 : 2;
+#ifdef BH_FFT_X_M32
+constexpr int NTT_ONE_STRIDE = 32;   // one-level tables hold 32-byte Montgomery entries, sliced after the load
+#else
+constexpr int NTT_ONE_STRIDE = 48;
+#endif
 constexpr int NTT_LOG_TILE = 11;                  // 2048 Fr per workgroup
 constexpr int NTT_TILE = 1 << NTT_LOG_TILE;
 constexpr int NTT_MAX_R = 11;                     // rows of a tile: sub-FFT size 2^r, r <= 11
@@ -137,11 +147,27 @@ struct TwReg {   // a table entry in registers: the nine 30-bit limbs
   u32 c;
 };
 typedef u32 u32x20 __attribute__((ext_vector_type(20)));   // 8 result words, 9 entry words, 3 unused
+#ifdef BH_FFT_X_GLOBAL
+#define BH_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define BH_GLOBAL_AS
+#endif
 __device__ __forceinline__ TwReg tw_load(const BTw *w) {
-  const u32x4 *q = reinterpret_cast<const u32x4 *>(w);
+  const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)w;
   TwReg t;
-  t.a = q[0]; t.b = q[1]; t.c = w->l[8];
+  t.a = q[0]; t.b = q[1]; t.c = ((const BH_GLOBAL_AS u32 *)w)[8];
   return t;
+}
+// entry `idx` of a one-level table
+__device__ __forceinline__ TwReg tw_load1(const BTw *tab, u64 idx) {
+#ifdef BH_FFT_X_M32
+  const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)((const char *)tab + idx * 32);
+  TwReg t;
+  t.a = q[0]; t.b = q[1]; t.c = 0;
+  return t;
+#else
+  return tw_load(tab + idx);
+#endif
 }
 __device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1, u32 w2, const BTw *next) {
   const TwReg n = tw_load(next);
@@ -166,8 +192,23 @@ __device__ __attribute__((noinline)) static u32x8 fr_mul_w(u32x4 a0, u32x4 a1, u
   fe_mul_b<FrParams, false>(r, a, B);
   return u32x8{r.l[0], r.l[1], r.l[2], r.l[3], r.l[4], r.l[5], r.l[6], r.l[7]};
 }
+#ifdef BH_FFT_X_M32
+__device__ __attribute__((noinline)) static u32x8 fr_mul_m(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1) {
+  fr_t a, w, r;
+  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
+  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
+  w.l[0] = w0.x; w.l[1] = w0.y; w.l[2] = w0.z; w.l[3] = w0.w;
+  w.l[4] = w1.x; w.l[5] = w1.y; w.l[6] = w1.z; w.l[7] = w1.w;
+  fe_mul<FrParams, false>(r, a, w);
+  return u32x8{r.l[0], r.l[1], r.l[2], r.l[3], r.l[4], r.l[5], r.l[6], r.l[7]};
+}
+#endif
 __device__ __forceinline__ void mul_w(fr_t &a, const TwReg &w) {
+#ifdef BH_FFT_X_M32
+  const u32x8 o = fr_mul_m(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w.a, w.b);
+#else
   const u32x8 o = fr_mul_w(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w.a, w.b, w.c);
+#endif
 #pragma unroll
   for (int i = 0; i < 8; i++) a.l[i] = o[i];
 }
@@ -224,7 +265,14 @@ __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 tota
     const u32 rest = task >> s;
     const u32 hi = rest & ((1u << hi_bits) - 1), col = rest >> hi_bits;
     const u32 pos0 = (col << r) + (hi << (s + G)) + lo;
+#if defined(BH_FFT_X_DIAG_NOTW)
+    auto tw_at = [&](int j, int t) { return master + (s + j); };   // timing only: one entry per wavefront (wrong twiddles)
+#elif defined(BH_FFT_X_LEVELS)
+    // the table of stage s + j holds w_{2^(s+j+1)}^k, k < 2^(s+j), at offset 2^(s+j) - 1: lanes with consecutive lo read consecutive entries
+    auto tw_at = [&](int j, int t) { return master + ((1u << (s + j)) - 1u) + ((u32)(t & ((1 << j) - 1)) * m + lo); };
+#else
     auto tw_at = [&](int j, int t) { return master + ((u32)(t & ((1 << j) - 1)) * m + lo) * (1024u >> (s + j)); };
+#endif
     // the task's first entry travels with the LDS reads; each product fetches the next one's (fr_mul_tw)
     constexpr int first_mul = step_next_mul<G, FIRST>(0, -1);
     TwReg cur;
@@ -304,7 +352,7 @@ __device__ __forceinline__ TileGeo tile_geo(const NttPass &a, u64 t) {
 // left a third of the wave cycles waiting (profiles/r4_final_pmc_g2_pairs_and_fft.json: SQ_WAIT_ANY 32 %): all eight
 // entries of a thread are loaded at once, beside the data, before the first product.
 template <bool ONE>
-__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kernel(NttPass a) {
   __shared__ uint4 plane0[NTT_PLANE];
   __shared__ uint4 plane1[NTT_PLANE];
   const u32 R = 1u << a.r, C = 1u << a.log_c;
@@ -347,10 +395,9 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
       if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
     if (ONE && a.pre1) {   // one product per element; entry of element e = tid + i * 256: lanes read consecutive entries
-      const BTw *tab = a.pre1 + tile_first + tid;
       TwReg w[PER];
 #pragma unroll
-      for (int i = 0; i < PER; i++) w[i] = tw_load(tab + i * NTT_THREADS);
+      for (int i = 0; i < PER; i++) w[i] = tw_load1(a.pre1, tile_first + tid + i * NTT_THREADS);
 #pragma unroll
       for (int i = 0; i < PER; i++) mul_w(v[i], w[i]);
     } else if (!ONE && a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
@@ -381,8 +428,8 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
     bool first = true;
     while (left) {
       __syncthreads();
-      const u32 g = (left == 4) ? 2 : (left >= 3 ? 3 : left);
-      if (g == 3) { if (first) ntt_step<3, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<3, false>(plane0, plane1, tid, total, a.r, s, a.master); }
+      const u32 g = NTT_GMAX == 2 ? (left >= 2 ? 2 : 1) : (left == 4) ? 2 : (left >= 3 ? 3 : left);
+      if (NTT_GMAX == 3 && g == 3) { if (first) ntt_step<3, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<3, false>(plane0, plane1, tid, total, a.r, s, a.master); }
       else if (g == 2) { if (first) ntt_step<2, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<2, false>(plane0, plane1, tid, total, a.r, s, a.master); }
       else { if (first) ntt_step<1, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<1, false>(plane0, plane1, tid, total, a.r, s, a.master); }
       s += g; left -= g; first = false;
@@ -400,7 +447,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(NttPass a) {
       TwReg w[PER];
       if (one_level) {
 #pragma unroll
-        for (int i = 0; i < PER; i++) w[i] = tw_load(one_level + tile_first + tid + i * NTT_THREADS);
+        for (int i = 0; i < PER; i++) w[i] = tw_load1(one_level, tile_first + tid + i * NTT_THREADS);
       }
 #pragma unroll
       for (int i = 0; i < PER; i++) {
@@ -520,13 +567,32 @@ __global__ __launch_bounds__(NTT_THREADS) void gen_tile_table_kernel(BTw *out, N
     fr_t acc = tab.scale;
     for (int k = 0; k < 32; k++)
       if ((x >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
+#ifdef BH_FFT_X_M32
+    st_fr(reinterpret_cast<fr_t *>(out) + (t << NTT_LOG_TILE) + e, acc);
+#else
     BTw w;
     fe_to_bform<FrParams>(w.l, acc);
     uint4 *q = reinterpret_cast<uint4 *>(out + (t << NTT_LOG_TILE) + e);
     q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
     q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
     q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
+#endif
   }
+}
+// the in-tile twiddles by stage: entry 2^L - 1 + k = w_2048^(k << (10 - L)) = w_{2^(L+1)}^k, k < 2^L, L <= 10 (2047 entries)
+__global__ void gen_level_table_kernel(BTw *out, PowTable tab) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2047u) return;
+  const u32 L = 31u - __clz(i + 1u), k = i + 1u - (1u << L), x = k << (10u - L);
+  fr_t acc = tab.scale;
+  for (int b = 0; b < 10; b++)
+    if ((x >> b) & 1) fe_mul(acc, acc, tab.p2[b]);
+  BTw w;
+  fe_to_bform<FrParams>(w.l, acc);
+  uint4 *q = reinterpret_cast<uint4 *>(out + i);
+  q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+  q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+  q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
 }
 
 // ---- element-wise domain ops -----------------------------------------------------------------
@@ -699,8 +765,15 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
   if (!c.fft_master[dir]) {   // w_2048^(+-i), i < 1024
     fr_t w = fr_domain_omega_host(NTT_LOG_TILE);
     if (inverse) fe_inv(w, w);
+#ifdef BH_FFT_X_LEVELS
+    if (hipMalloc((void **)&new_master, 2048 * sizeof(BTw)) != hipSuccess) return fail(BH_ERR_HIP);
+    fresh.push_back(new_master);
+    hipLaunchKernelGGL(gen_level_table_kernel, dim3(8), dim3(256), 0, st, new_master, make_pow_table(w, one));
+    if (hipGetLastError() != hipSuccess) return fail(BH_ERR_HIP);
+#else
     int rc = make(&new_master, 1024, w, one);
     if (rc) return fail(rc);
+#endif
   }
   auto it = c.fft_tables.find(log_n);
   FftTables t = it != c.fft_tables.end() ? it->second : FftTables();
@@ -737,7 +810,7 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     // entry t * 2048 + e of a table belongs to element e of tile t of its pass (gen_tile_table_kernel)
     auto tile_table = [&](BTw **dst, uint32_t p, uint32_t s_bits, int kind, const fr_t &base, const fr_t &scale) {
       BTw *tab_p = nullptr;
-      if (hipMalloc((void **)&tab_p, n * sizeof(BTw)) != hipSuccess) return false;
+      if (hipMalloc((void **)&tab_p, n * (size_t)NTT_ONE_STRIDE) != hipSuccess) return false;
       fresh.push_back(tab_p);
       const NttPass geo = pass_geometry(log_n, pr, pL, p, s_bits);
       hipLaunchKernelGGL(gen_tile_table_kernel, dim3((u32)(n >> NTT_LOG_TILE)), dim3(NTT_THREADS), 0, st, tab_p, geo,

@@ -298,8 +298,11 @@ struct LcSink {
   // combination derived linearly from its argument (`|lc| lc + a + (c, b)`, as every closure of the reference's circuits and
   // gadgets does; in Rust `lc + a` consumes `lc`, so using it twice takes an explicit clone) or a stored combination that
   // it built from LinearCombination::zero() without touching its argument.  Counting the terms in the sink as well, to
-  // detect the misuse, was measured at 5 % of the synthesis and left out.
+  // detect the misuse, was measured at 5 % of the synthesis: it is compiled into the closures of a translation unit built
+  // with -DBELLMAN_HIP_CHECK_CLOSURES=1 (the test library, a user's debug build) and nowhere else; `enforce` compares
+  // whenever the closure's unit counted (pushed != 0) and throws std::invalid_argument for a closure that breaks the contract.
   mutable Fr acc = Fr::zero();
+  mutable size_t pushed = 0;   // terms added through ANY copy of the closure's argument (counted by checking builds only)
 };
 // Copy of a field element that was just computed: limb by limb through general registers.  A struct copy compiles to two
 // 16-byte vector moves, and a 16-byte load from a location that two 8-byte stores have just written cannot be forwarded
@@ -320,6 +323,7 @@ class LinearCombination {
     LinearCombination r;
     r.sink_ = sink;
     sink->acc = Fr::zero();
+    sink->pushed = 0;
     return r;
   }
   LinearCombination() : n_(0), sink_(nullptr) {}
@@ -379,6 +383,9 @@ class LinearCombination {
   __attribute__((always_inline)) void push(Variable v, const Fr &c) {
     n_++;
     if (__builtin_expect(sink_ != nullptr, 1)) {   // prover.rs:19-55 for this one term
+#ifdef BELLMAN_HIP_CHECK_CLOSURES
+      sink_->pushed++;
+#endif
       if (c.is_zero()) return;            // zero coefficients count for neither value nor density (:31)
       if (__builtin_expect(sink_->hook != nullptr, 0)) { sink_->hook(sink_->self, v, c); return; }
       const Fr *value = locate(v);
@@ -394,6 +401,9 @@ class LinearCombination {
   __attribute__((always_inline)) void push_one(Variable v) {   // coefficient one
     if (__builtin_expect(sink_ != nullptr && sink_->hook == nullptr, 1)) {
       n_++;
+#ifdef BELLMAN_HIP_CHECK_CLOSURES
+      sink_->pushed++;
+#endif
       sink_->acc = sink_->acc + *locate(v);
       return;
     }

@@ -123,6 +123,10 @@ void ProvingAssignment::enforce(const LcFn &fa, const LcFn &fb, const LcFn &fc) 
   //  a tenth of the synthesis time of a 2^20-constraint circuit, tools/host_profile.py)
   auto run = [&](const LcFn &f, const LcSink &sink, std::vector<Fr> &out) {
     const LinearCombination r = f(LinearCombination::evaluating(&sink));
+    // a closure compiled with BELLMAN_HIP_CHECK_CLOSURES counted every term it added to any copy of its argument: the
+    // returned combination must carry exactly those (prover.rs:19-55 evaluates the returned combination and nothing else)
+    if (sink.pushed && (!r.is_evaluating() || r.size() != sink.pushed))
+      throw std::invalid_argument("enforce: the closure added terms to a copy of its argument that it did not return");
     out.emplace_back();
     if (r.is_evaluating()) r.value_into(out.back());
     else out.back() = eval(r, sink.input_density, sink.aux_density, input_assignment, aux_assignment);
@@ -624,6 +628,8 @@ class ShapeAssembly : public ConstraintSystem {
       Hooked h{this, m};
       LcSink sink{nullptr, nullptr, nullptr, nullptr, &ShapeAssembly::hook, &h};
       const LinearCombination r = (*fs[m])(LinearCombination::evaluating(&sink));
+      if (sink.pushed && (!r.is_evaluating() || r.size() != sink.pushed))   // (checking builds: see ProvingAssignment::enforce)
+        throw std::invalid_argument("enforce: the closure added terms to a copy of its argument that it did not return");
       if (!r.is_evaluating())
         for (size_t i = 0; i < r.size(); i++) add_term(m, r[i].first, r[i].second);
       row_ptr[m].push_back((uint32_t)var[m].size());

@@ -151,11 +151,15 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   // s_waitcnt vmcnt(0) (ec.cuh).  With one resident wavefront per SIMD the two dependent loads of an iteration were
   // 21 % of the kernel's time (profiles/r2_call8_pmc_g2_accumulate.json).
   constexpr bool PIPELINED = F::LANES == 1 && F::WORDS == 24;
+  // record `idx` of the vector the accumulation gathers from: every variant reads at the caller's record stride
+  auto base_at = [&](u32 idx) {
+    return reinterpret_cast<const Affine<typename F::Mem> *>(reinterpret_cast<const char *>(bases) + (size_t)idx * base_stride);
+  };
   if constexpr (PIPELINED) {
     u64 e = src[v.begin];
     u64 e1 = v.begin + 1 < v.end ? src[v.begin + 1] : 0;
     Affine<F> q;
-    load_affine<F>(q, bases + ((u32)e & 0x7fffffffu));
+    load_affine<F>(q, base_at((u32)e & 0x7fffffffu));
     for (u32 p = v.begin; p < v.end; p++) {
       const u32 d = (u32)(e >> 32);
       if (d != cur) {   // bucket `cur` ends inside this chunk
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
       Affine<F> qn = q;
       u64 e2 = 0;
       auto prefetch = [&]() {
-        if (p + 1 < v.end) load_affine<F>(qn, bases + ((u32)e1 & 0x7fffffffu));
+        if (p + 1 < v.end) load_affine<F>(qn, base_at((u32)e1 & 0x7fffffffu));
         if (p + 2 < v.end) e2 = src[p + 2];
       };
       if (aff_is_identity(q)) {
@@ -190,8 +194,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
         cur = d;
       }
       Affine<F> q;
-      load_affine<F>(q, reinterpret_cast<const Affine<typename F::Mem> *>(reinterpret_cast<const char *>(bases) +
-                                                                          (size_t)((u32)e & 0x7fffffffu) * base_stride));
+      load_affine<F>(q, base_at((u32)e & 0x7fffffffu));
       if (aff_is_identity(q)) { saw_identity = true; continue; }
       if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
       xyzz_madd(acc, q);

@@ -203,11 +203,23 @@ class Parameters:
         lib = _lib.load()
         n = ctypes.c_size_t()
         check(lib.bh_groth16_params_write(self._h, None, 0, ctypes.byref(n)), "Parameters.write")
-        out = bytearray(n.value)   # (a bytes-like Vec<u8>: compares equal to bytes; no second copy of half a gigabyte)
-        view = (ctypes.c_ubyte * n.value).from_buffer(out)
+        out = ctypes.create_string_buffer(n.value)
+        check(lib.bh_groth16_params_write(self._h, ctypes.cast(out, ctypes.c_void_p), n.value, ctypes.byref(n)), "Parameters.write")
+        return out.raw   # immutable, hashable bytes like the reference's Vec<u8> handed to a writer; write_into avoids the copy
+
+    def write_into(self, buffer):
+        """Parameters::write into a caller-provided writable buffer (bytearray, numpy uint8, mmap ...): no second copy of a
+        CRS of half a gigabyte.  Returns the number of bytes written; the buffer must hold at least that many."""
+        lib = _lib.load()
+        n = ctypes.c_size_t()
+        check(lib.bh_groth16_params_write(self._h, None, 0, ctypes.byref(n)), "Parameters.write")
+        mv = memoryview(buffer).cast("B")
+        if mv.readonly or len(mv) < n.value:
+            raise ValueError("write_into needs a writable buffer of at least %d bytes" % n.value)
+        view = (ctypes.c_ubyte * len(mv)).from_buffer(mv)
         check(lib.bh_groth16_params_write(self._h, ctypes.cast(view, ctypes.c_void_p), n.value, ctypes.byref(n)), "Parameters.write")
         del view
-        return out
+        return n.value
 
     def vk_ext(self):
         """gamma_g2 ([24] uint64) and ic ([n,12] uint64): the verifier-side key elements"""

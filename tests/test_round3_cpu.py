@@ -213,3 +213,26 @@ def test_structure_capture_matches_proving_assignment(kind, size, table):
     rows, terms, coeffs, bad = list(out)
     assert bad == 0 and rows >= size and terms > rows
     assert coeffs == table
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("rounds", [0, 3, 64])
+def test_closures_that_discard_terms_are_refused(variant, rounds):
+    """[r5] The mirror's evaluating LinearCombination counts a term the moment it is added (value and density maps live in
+    the sink, groth16.hpp), whereas the reference's `eval` walks only the combination a closure RETURNS
+    (groth16/src/prover.rs:19-55).  A closure that adds a term to a copy of its argument and discards the copy, builds two
+    combinations and returns one, or touches its argument and returns a stored combination, would therefore give other
+    densities than bellman - MisuseCircuit (fixture kind 4) does each of these after `rounds` well-behaved constraints.  The
+    test library's closures are compiled with BELLMAN_HIP_CHECK_CLOSURES (term count in the sink): ProvingAssignment::enforce
+    and the structure capture refuse them (std::invalid_argument -> BH_ERR_INVALID_ARG); the well-behaved kinds pass
+    through the same checking build in every other test of this file."""
+    import ctypes
+
+    from bellman_amd import _lib
+    from bellman_amd import groth16 as pg
+    with pytest.raises(AssertionError, match="invalid argument"):   # BH_ERR_INVALID_ARG (the reference would panic)
+        pg.demo_assignment(4, rounds, variant, [0x55AA55AA])
+    lib = _lib.load()
+    lib.bh_test_capture_check.restype = ctypes.c_double
+    out4 = (ctypes.c_size_t * 4)()
+    assert lib.bh_test_capture_check(4, ctypes.c_size_t(rounds), ctypes.c_uint64(variant), out4) < 0
