@@ -161,7 +161,7 @@ def load():
     lib.bh_msm_async_dev_opts.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, c.POINTER(vp)]
     lib.bh_fixed_base_mul_dev.argtypes = [vp, i32, vp, vp, sz, i32, vp, vp]
     lib.bh_runtime_configure.argtypes = []
-    lib.bh_ctx_set_limits.argtypes = [vp, u32, sz, sz]
+    lib.bh_ctx_set_limits.argtypes = [vp, u32, sz, sz, sz]
     lib.bh_ctx_info.argtypes = [vp, vp]
     lib.bh_scalars_register.argtypes = [vp, vp, sz, i32, c.POINTER(vp)]
     lib.bh_scalars_adopt_dev.argtypes = [vp, vp, sz, i32, i32, c.POINTER(vp)]

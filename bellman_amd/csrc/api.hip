@@ -350,6 +350,8 @@ int bh_ctx_create(int device, bh_ctx **out) {
   {
     const char *e = getenv("BELLMAN_HIP_TABLE_BUDGET_MB");
     ctx->c.table_budget = (e && *e) ? (size_t)strtoull(e, nullptr, 10) << 20 : ctx->c.hbm_total / 4;
+    const char *ef = getenv("BELLMAN_HIP_FFT_TABLE_BUDGET_MB");
+    ctx->c.fft_table_budget = (ef && *ef) ? (size_t)strtoull(ef, nullptr, 10) << 20 : ctx->c.hbm_total / 8;
   }
   {
     const char *e = getenv("BELLMAN_HIP_POOL_CAP_MB");
@@ -361,11 +363,13 @@ int bh_ctx_create(int device, bh_ctx **out) {
   *out = ctx;
   return BH_OK;
 }
-int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes) {
+int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes,
+                      size_t fft_table_budget_bytes) {
   if (!ctx) return BH_ERR_INVALID_ARG;
   if (max_jobs_in_flight) ctx->c.max_jobs = max_jobs_in_flight;
   if (pool_cap_bytes != (size_t)-1) ctx->c.pool.set_cap(pool_cap_bytes);
   if (table_budget_bytes != (size_t)-1) { std::lock_guard<std::mutex> g(ctx->c.job_mu); ctx->c.table_budget = table_budget_bytes; }
+  if (fft_table_budget_bytes != (size_t)-1) { std::lock_guard<std::mutex> g(ctx->c.fft_mu); ctx->c.fft_table_budget = fft_table_budget_bytes; }
   return BH_OK;
 }
 int bh_ctx_info(bh_ctx *ctx, bh_ctx_info_t *info) {
@@ -384,6 +388,11 @@ int bh_ctx_info(bh_ctx *ctx, bh_ctx_info_t *info) {
     std::lock_guard<std::mutex> g(ctx->c.job_mu);
     info->table_bytes = ctx->c.table_bytes;
     info->table_budget = ctx->c.table_budget;
+  }
+  {
+    std::lock_guard<std::mutex> g(ctx->c.fft_mu);
+    info->fft_table_bytes = ctx->c.fft_table_bytes;
+    info->fft_table_budget = ctx->c.fft_table_budget;
   }
   return BH_OK;
 }
@@ -413,9 +422,12 @@ int bh_ctx_trim(bh_ctx *ctx) {
     }
   }
   {
+    std::unique_lock<std::shared_mutex> ex(ctx->c.fft_use_mu);   // no transform between its table lookup and its launches
+    BH_HIP_CHECK(hipDeviceSynchronize());
     std::lock_guard<std::mutex> g(ctx->c.fft_mu);
     for (auto &kv : ctx->c.fft_tables) fft_tables_free(kv.second);
     ctx->c.fft_tables.clear();
+    ctx->c.fft_table_bytes = 0;
     fft_master_free(ctx->c);
   }
   return BH_OK;

@@ -9,6 +9,7 @@
 #include <list>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "../../include/bellman_hip.h"
@@ -151,6 +152,10 @@ struct FftTables {
   bool one_level = false, one_level_failed = false;
   BTw *tw1[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   BTw *coset1 = nullptr, *icoset1 = nullptr;
+  // [r5] what this size holds in device memory and when it was last used: the cache is bounded (Context::fft_table_budget),
+  // least recently used sizes go first
+  size_t bytes = 0;
+  uint64_t last_use = 0;
 };
 
 struct Context {
@@ -160,6 +165,13 @@ struct Context {
   std::mutex fft_mu;
   std::map<uint32_t, FftTables> fft_tables;  // keyed by log_n
   BTw *fft_master[2] = {nullptr, nullptr};   // omega_2048^(+-i), i < 1024: in-tile twiddles of every pass
+  // [r5] The per-size tables are a cache with a budget (bh_ctx_set_limits; default an eighth of the device's memory): a
+  // size whose complete one-level set would not fit runs on the small two-level tables, and building a table that does
+  // not fit beside the others first drops the least recently used OTHER sizes.  Dropping needs the tables idle: a transform
+  // holds fft_use_mu shared from get_tables to its last launch, the evictor takes it exclusively and synchronises the device.
+  size_t fft_table_bytes = 0, fft_table_budget = 0;
+  uint64_t fft_tick = 0;
+  std::shared_mutex fft_use_mu;
   int num_cus = 256;
   std::mutex job_mu;
   std::vector<JobResources> job_pool;

@@ -739,16 +739,48 @@ static NttPass pass_geometry(uint32_t log_n, const uint32_t *r, uint32_t L, uint
   return a;
 }
 
+// internal return code of get_tables: `*evict_need` bytes of OTHER sizes' tables have to go first (fft_evict), then call again
+constexpr int BH_FFT_EVICT = -1000;
+// the complete one-level set of a size: an inter-pass twiddle table per non-last pass and direction, 7^i, 7^-i
+static size_t one_level_set_bytes(uint32_t log_n, uint32_t L) { return (size_t)(2 * (L - 1) + 2) * ((size_t)NTT_ONE_STRIDE << log_n); }
+
 static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bool need_coset, bool need_icoset,
-                      hipStream_t st, FftTables *out, const BTw **master) {
+                      hipStream_t st, FftTables *out, const BTw **master, size_t *evict_need) {
   std::lock_guard<std::mutex> g(c.fft_mu);
   fr_t one;
   fe_one(one);
   const int dir = inverse ? 1 : 0;
+  auto it = c.fft_tables.find(log_n);
+  FftTables t = it != c.fft_tables.end() ? it->second : FftTables();
+  const u64 n = (u64)1 << log_n;
+  uint32_t pr[3] = {0, 0, 0}, pL = 1;
+  plan_passes(log_n, pr, &pL);
+  // One-level tables (n entries each: 0.13 GB at 2^22, 0.5 GB at 2^24) where the size's COMPLETE set fits the cache's
+  // budget - so that dropping the other sizes always makes room for whichever of its tables is asked for next, and the
+  // kind of tables a size uses never changes while it is cached (the inverse twiddle table carries the 1/n: the two kinds
+  // are never mixed within a size).  A size that holds two-level tables (over budget, a failed allocation) keeps them.
+  static const bool one_level_on = [] { const char *e = getenv("BELLMAN_HIP_FFT_ONE_LEVEL"); return !(e && *e == '0'); }();
+  const bool has_two_level = t.tw_lo[0] || t.tw_lo[1] || t.coset_lo || t.icoset_lo;
+  bool one_level = one_level_on && log_n >= 12 && log_n <= 24 && !t.one_level_failed && !has_two_level &&
+                   (t.one_level || one_level_set_bytes(log_n, pL) <= c.fft_table_budget);
+  const size_t entry_bytes = (size_t)NTT_ONE_STRIDE << log_n;
+  const size_t others = c.fft_table_bytes - (it != c.fft_tables.end() ? it->second.bytes : 0);
+  if (one_level) {
+    size_t need = 0;
+    if (need_tw && !t.tw1[dir][0]) need += (size_t)(pL - 1) * entry_bytes;
+    if (need_coset && !t.coset1) need += entry_bytes;
+    if (need_icoset && !t.icoset1) need += entry_bytes;
+    if (need && c.fft_table_bytes + need > c.fft_table_budget) {
+      if (others) { *evict_need = need; return BH_FFT_EVICT; }   // (nothing built yet: nothing to undo)
+      if (!t.one_level) one_level = false;   // the budget was lowered under this call: two-level tables
+      // (a size that already runs on one-level tables completes its set: at most its own set over the new budget)
+    }
+  }
   // Everything new is built into locals and PUBLISHED into the context only after every allocation and launch of
   // this call succeeded (and the generating stream drained): a failed hipMalloc / launch leaves the cache exactly as
   // it was, so a retry regenerates instead of running a kernel with half a table pair (null *_hi pointer).
   std::vector<BTw *> fresh;   // freed on failure
+  size_t fresh_bytes = 0;
   auto fail = [&](int rc) {
     (void)hipStreamSynchronize(st);
     for (BTw *p : fresh) (void)hipFree(p);
@@ -757,12 +789,12 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
   auto make = [&](BTw **dst, u64 count, const fr_t &base, const fr_t &scale) -> int {
     BTw *p = nullptr;
     int rc = make_btw_table(&p, count, base, scale, st);
-    if (p) fresh.push_back(p);
+    if (p) { fresh.push_back(p); fresh_bytes += count * sizeof(BTw); }
     if (rc == BH_OK) *dst = p;
     return rc;
   };
   BTw *new_master = nullptr;
-  if (!c.fft_master[dir]) {   // w_2048^(+-i), i < 1024
+  if (!c.fft_master[dir]) {   // the in-tile twiddles (96 KiB, shared by every size: not part of the budget)
     fr_t w = fr_domain_omega_host(NTT_LOG_TILE);
     if (inverse) fe_inv(w, w);
 #ifdef BH_FFT_X_LEVELS
@@ -773,11 +805,9 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
 #else
     int rc = make(&new_master, 1024, w, one);
     if (rc) return fail(rc);
+    fresh_bytes -= 1024 * sizeof(BTw);
 #endif
   }
-  auto it = c.fft_tables.find(log_n);
-  FftTables t = it != c.fft_tables.end() ? it->second : FftTables();
-  const u64 n = (u64)1 << log_n;
   if (!t.init) {
     t.lb = (log_n + 1) / 2;
     fr_t nn = fr_from_u64_host(n);
@@ -787,31 +817,16 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
     if (rc) return fail(rc);
     t.init = true;
   }
-  // One-level tables in element order where they fit comfortably (n x 48 B each: 0.2 GB at 2^22, 0.8 GB at 2^24).  A
-  // failed allocation falls back to the two-level tables for this size for good (the decision is part of the cached
-  // state: the inverse twiddle table carries the 1/n, so the two kinds are never mixed within a size).
-  static const bool one_level_on = [] { const char *e = getenv("BELLMAN_HIP_FFT_ONE_LEVEL"); return !(e && *e == '0'); }();
-  uint32_t pr[3] = {0, 0, 0}, pL = 1;
-  plan_passes(log_n, pr, &pL);
-  bool one_level = one_level_on && log_n >= 12 && log_n <= 24 && !t.one_level_failed &&
-                   !(t.tw_lo[0] || t.tw_lo[1] || t.coset_lo || t.icoset_lo);
   if (one_level) {
-    const size_t mark = fresh.size();
-    auto one_level_fail = [&]() {
-      (void)hipStreamSynchronize(st);
-      (void)hipGetLastError();
-      for (size_t i = mark; i < fresh.size(); i++) (void)hipFree(fresh[i]);
-      fresh.resize(mark);
-      t.one_level_failed = true;
-      one_level = false;
-    };
+    const size_t mark = fresh.size(), mark_bytes = fresh_bytes;
     FftTables t1 = t;
     bool ok = true;
     // entry t * 2048 + e of a table belongs to element e of tile t of its pass (gen_tile_table_kernel)
     auto tile_table = [&](BTw **dst, uint32_t p, uint32_t s_bits, int kind, const fr_t &base, const fr_t &scale) {
       BTw *tab_p = nullptr;
-      if (hipMalloc((void **)&tab_p, n * (size_t)NTT_ONE_STRIDE) != hipSuccess) return false;
+      if (hipMalloc((void **)&tab_p, entry_bytes) != hipSuccess) return false;
       fresh.push_back(tab_p);
+      fresh_bytes += entry_bytes;
       const NttPass geo = pass_geometry(log_n, pr, pL, p, s_bits);
       hipLaunchKernelGGL(gen_tile_table_kernel, dim3((u32)(n >> NTT_LOG_TILE)), dim3(NTT_THREADS), 0, st, tab_p, geo,
                          make_pow_table(base, scale), kind);
@@ -836,7 +851,25 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
       for (uint32_t p = 0; p + 1 < pL; p++) s_last += pr[p];
       ok = tile_table(&t1.icoset1, pL - 1, s_last, 2, ginv, one);
     }
-    if (ok) { t = t1; t.one_level = true; } else one_level_fail();
+    if (ok) { t = t1; t.one_level = true; }
+    else {
+      (void)hipStreamSynchronize(st);
+      (void)hipGetLastError();
+      if (t.one_level || others) {
+        // The size already runs on one-level tables (its inverse twiddles carry the 1/n): it must not fall back to the
+        // two-level kind half way (a forward call whose allocation failed after an inverse call had built its
+        // tables ran the one-level kernel with null table pointers) - make room by dropping the other sizes, and if
+        // there is nothing to drop the call fails.  A size without tables yet also tries that before it gives up.
+        for (BTw *p : fresh) (void)hipFree(p);
+        if (others) { *evict_need = (size_t)-1; return BH_FFT_EVICT; }
+        return BH_ERR_HIP;
+      }
+      for (size_t i = mark; i < fresh.size(); i++) (void)hipFree(fresh[i]);
+      fresh.resize(mark);
+      fresh_bytes = mark_bytes;
+      t.one_level_failed = true;   // this size stays on the two-level tables for good
+      one_level = false;
+    }
   }
   const u64 n_lo = (u64)1 << t.lb, n_hi = (u64)1 << (log_n - t.lb);
   auto two_level = [&](BTw **lo, BTw **hi, const fr_t &base, const fr_t &scale) -> int {
@@ -868,10 +901,45 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
   // tables are generated on `st`; later users may be on other streams
   if (!fresh.empty() && hipStreamSynchronize(st) != hipSuccess) return fail(BH_ERR_HIP);
   if (new_master) c.fft_master[dir] = new_master;
+  t.bytes += fresh_bytes;
+  t.last_use = ++c.fft_tick;
+  c.fft_table_bytes += fresh_bytes;
   c.fft_tables[log_n] = t;
   *out = t;
   *master = c.fft_master[dir];
   return BH_OK;
+}
+
+// drops the least recently used sizes other than `keep_log_n` until `need` more bytes fit the budget ((size_t)-1: all of
+// them).  Exclusive: no transform is between its get_tables and its last launch, and the device is drained before a free.
+static void fft_evict(Context &c, uint32_t keep_log_n, size_t need) {
+  std::unique_lock<std::shared_mutex> ex(c.fft_use_mu);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> g(c.fft_mu);
+  for (;;) {
+    if (need != (size_t)-1 && c.fft_table_bytes + need <= c.fft_table_budget) break;
+    auto victim = c.fft_tables.end();
+    for (auto i = c.fft_tables.begin(); i != c.fft_tables.end(); ++i)
+      if (i->first != keep_log_n && i->second.bytes && (victim == c.fft_tables.end() || i->second.last_use < victim->second.last_use)) victim = i;
+    if (victim == c.fft_tables.end()) break;
+    c.fft_table_bytes -= victim->second.bytes;
+    fft_tables_free(victim->second);
+    c.fft_tables.erase(victim);
+  }
+}
+// get_tables with the cache's eviction round trips; on BH_OK `use` holds fft_use_mu shared - keep it until the last launch
+// that reads the tables has been enqueued
+static int acquire_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bool need_coset, bool need_icoset, hipStream_t st,
+                          FftTables *out, const BTw **master, std::shared_lock<std::shared_mutex> &use) {
+  for (int attempt = 0; attempt < 4; attempt++) {
+    use = std::shared_lock<std::shared_mutex>(c.fft_use_mu);
+    size_t need = 0;
+    const int rc = get_tables(c, log_n, inverse, need_tw, need_coset, need_icoset, st, out, master, &need);
+    if (rc != BH_FFT_EVICT) { if (rc != BH_OK) use.unlock(); return rc; }
+    use.unlock();
+    fft_evict(c, log_n, need);
+  }
+  return BH_ERR_HIP;
 }
 
 // data: device, 2^log_n Montgomery Fr, in place.  scratch: device, same size (ping-pong for the
@@ -889,8 +957,14 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
   plan_passes(log_n, r, &L);
   FftTables tab;
   const BTw *master = nullptr;
-  int rc = get_tables(c, log_n, inverse, L > 1, mode == BH_COSET_FFT, mode == BH_ICOSET_FFT, st, &tab, &master);
+  std::shared_lock<std::shared_mutex> use;   // the tables stay cached until this call's launches are enqueued (fft_evict)
+  int rc = acquire_tables(c, log_n, inverse, L > 1, mode == BH_COSET_FFT, mode == BH_ICOSET_FFT, st, &tab, &master, use);
   if (rc) return rc;
+  // one kind of tables per size: the one-level kernel multiplies by whatever its table pointers say, so every table
+  // this call needs has to be there (get_tables guarantees it; a null pointer here would be a silently wrong transform)
+  if (tab.one_level && ((L > 1 && !tab.tw1[inverse ? 1 : 0][0]) || (mode == BH_COSET_FFT && !tab.coset1) ||
+                        (mode == BH_ICOSET_FFT && !tab.icoset1)))
+    return BH_ERR_HIP;
   uint32_t s = 0;
   for (uint32_t p = 0; p < L; p++) {
     NttPass a = pass_geometry(log_n, r, L, p, s);
@@ -943,7 +1017,8 @@ int fr_sub_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st) {
 static int cached_zinv(Context &c, uint32_t log_n, hipStream_t st, fr_t *out) {
   FftTables tab;
   const BTw *master = nullptr;
-  int rc = get_tables(c, log_n, false, false, false, false, st, &tab, &master);
+  std::shared_lock<std::shared_mutex> use;
+  int rc = acquire_tables(c, log_n, false, false, false, false, st, &tab, &master, use);
   if (rc) return rc;
   *out = tab.zinv;
   return BH_OK;

@@ -207,6 +207,12 @@ class Parameters:
         check(lib.bh_groth16_params_write(self._h, ctypes.cast(out, ctypes.c_void_p), n.value, ctypes.byref(n)), "Parameters.write")
         return out.raw   # immutable, hashable bytes like the reference's Vec<u8> handed to a writer; write_into avoids the copy
 
+    def serialized_len(self):
+        """byte length of Parameters::write's output"""
+        n = ctypes.c_size_t()
+        check(_lib.load().bh_groth16_params_write(self._h, None, 0, ctypes.byref(n)), "Parameters.write")
+        return n.value
+
     def write_into(self, buffer):
         """Parameters::write into a caller-provided writable buffer (bytearray, numpy uint8, mmap ...): no second copy of a
         CRS of half a gigabyte.  Returns the number of bytes written; the buffer must hold at least that many."""

@@ -29,13 +29,14 @@ class Worker:
     def synchronize(self):
         check(self._lib.bh_ctx_synchronize(self._ctx))
 
-    def set_limits(self, max_jobs_in_flight=0, pool_cap_bytes=None, table_budget_bytes=None):
+    def set_limits(self, max_jobs_in_flight=0, pool_cap_bytes=None, table_budget_bytes=None, fft_table_budget_bytes=None):
         """bh_ctx_set_limits: jobs in flight before an issuing thread completes the oldest one itself (the
         Worker::compute back-pressure of src/multicore.rs:47-73), cap of the workspace pool, budget of automatic
-        window tables.  None = leave unchanged."""
+        window tables, budget of the cached per-size FFT tables.  None = leave unchanged."""
         keep = ctypes.c_size_t(-1).value
         check(self._lib.bh_ctx_set_limits(self._ctx, max_jobs_in_flight, keep if pool_cap_bytes is None else pool_cap_bytes,
-                                          keep if table_budget_bytes is None else table_budget_bytes))
+                                          keep if table_budget_bytes is None else table_budget_bytes,
+                                          keep if fft_table_budget_bytes is None else fft_table_budget_bytes))
 
     def info(self):
         """bh_ctx_info as a dict (device, CUs, HBM, hardware-queue request, jobs in flight, pool and table bytes)."""
@@ -44,7 +45,8 @@ class Worker:
                         ("hw_queues_requested", ctypes.c_uint32), ("hw_queues_set_before_hip_init", ctypes.c_uint32),
                         ("max_jobs_in_flight", ctypes.c_uint32), ("jobs_in_flight", ctypes.c_uint32),
                         ("pool_bytes_held", ctypes.c_uint64), ("pool_bytes_idle", ctypes.c_uint64),
-                        ("table_bytes", ctypes.c_uint64), ("table_budget", ctypes.c_uint64)]
+                        ("table_bytes", ctypes.c_uint64), ("table_budget", ctypes.c_uint64),
+                        ("fft_table_bytes", ctypes.c_uint64), ("fft_table_budget", ctypes.c_uint64)]
         i = _Info()
         check(self._lib.bh_ctx_info(self._ctx, ctypes.byref(i)))
         return {k: getattr(i, k) for k, _ in _Info._fields_}

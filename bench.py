@@ -97,7 +97,8 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     # the serialized form and back (Parameters::write / Parameters::read, groth16/src/lib.rs:258-398): the proofs
     # below use the parameters that came through the reader with `checked = true`
     t0 = time.perf_counter()
-    blob = params.write()
+    blob = bytearray(params.serialized_len())   # (the writer's buffer; Parameters.write() would add a copy into immutable bytes)
+    params.write_into(blob)
     write_ms = (time.perf_counter() - t0) * 1e3
     params.release()
     t0 = time.perf_counter()

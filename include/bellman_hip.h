@@ -76,8 +76,15 @@ int bh_runtime_configure(void);
  *                       flight as above, and only fails (BH_ERR_HIP) when nothing is left to wait for.  The same
  *                       happens when hipMalloc itself fails.
  *   table_budget_bytes  total size of the window tables built AUTOMATICALLY at registration (bh_bases_register etc.;
- *                       default a quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB); bh_ctx_trim drops them. */
-int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes);
+ *                       default a quarter of the device's memory, BELLMAN_HIP_TABLE_BUDGET_MB); bh_ctx_trim drops them.
+ *   fft_table_budget_bytes  total size of the cached per-size FFT tables (default an eighth of the device's memory,
+ *                       BELLMAN_HIP_FFT_TABLE_BUDGET_MB).  From 2^12 to 2^24 points a domain size caches n-entry
+ *                       twiddle / coset tables (32 bytes per entry; up to 4 tables at two passes, 6 at three: 0.5 GB at
+ *                       2^22, 3.2 GB at 2^24); a size whose complete set exceeds the budget runs on its small two-level
+ *                       tables instead (two products per factor, same results), and a table that does not fit beside
+ *                       the others first drops the least recently used other sizes.  bh_ctx_trim drops them all. */
+int bh_ctx_set_limits(bh_ctx *ctx, uint32_t max_jobs_in_flight, size_t pool_cap_bytes, size_t table_budget_bytes,
+                      size_t fft_table_budget_bytes);
 typedef struct {
   int32_t device;
   uint32_t num_cus;
@@ -87,6 +94,7 @@ typedef struct {
                                               caller's environment): the request can have taken effect */
   uint32_t max_jobs_in_flight, jobs_in_flight;
   uint64_t pool_bytes_held, pool_bytes_idle, table_bytes, table_budget;
+  uint64_t fft_table_bytes, fft_table_budget;   /* the cached per-size FFT tables (bh_ctx_set_limits) */
 } bh_ctx_info_t;
 int bh_ctx_info(bh_ctx *ctx, bh_ctx_info_t *info);
 

@@ -74,6 +74,8 @@ pub struct BhCtxInfo {
     pub pool_bytes_idle: u64,
     pub table_bytes: u64,
     pub table_budget: u64,
+    pub fft_table_bytes: u64,
+    pub fft_table_budget: u64,
 }
 
 pub const BH_OK: c_int = 0;
@@ -105,7 +107,7 @@ extern "C" {
     pub fn bh_ctx_log_num_cus(ctx: *const BhCtx) -> u32;
     pub fn bh_version() -> *const c_char;
     pub fn bh_runtime_configure() -> c_int;
-    pub fn bh_ctx_set_limits(ctx: *mut BhCtx, max_jobs_in_flight: u32, pool_cap_bytes: usize, table_budget_bytes: usize) -> c_int;
+    pub fn bh_ctx_set_limits(ctx: *mut BhCtx, max_jobs_in_flight: u32, pool_cap_bytes: usize, table_budget_bytes: usize, fft_table_budget_bytes: usize) -> c_int;
     pub fn bh_ctx_info(ctx: *mut BhCtx, info: *mut BhCtxInfo) -> c_int;
     pub fn bh_dev_alloc(ctx: *mut BhCtx, bytes: usize, dev_ptr: *mut *mut c_void) -> c_int;
     pub fn bh_dev_free(ctx: *mut BhCtx, dev_ptr: *mut c_void) -> c_int;

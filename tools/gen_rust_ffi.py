@@ -104,7 +104,7 @@ def render(decls):
         "pub struct BhCtxInfo {", "    pub device: i32,", "    pub num_cus: u32,", "    pub hbm_bytes: u64,",
         "    pub hw_queues_requested: u32,", "    pub hw_queues_set_before_hip_init: u32,", "    pub max_jobs_in_flight: u32,",
         "    pub jobs_in_flight: u32,", "    pub pool_bytes_held: u64,", "    pub pool_bytes_idle: u64,", "    pub table_bytes: u64,",
-        "    pub table_budget: u64,", "}",
+        "    pub table_budget: u64,", "    pub fft_table_bytes: u64,", "    pub fft_table_budget: u64,", "}",
         "",
     ]
     consts = [("BH_OK", 0), ("BH_ERR_UNEXPECTED_IDENTITY", 1), ("BH_ERR_UNEXPECTED_EOF", 2), ("BH_ERR_DEGREE_TOO_LARGE", 3),
