@@ -43,17 +43,23 @@
 
 namespace bh {
 
-#ifndef BH_FFT_X_THREADS
-#define BH_FFT_X_THREADS 256
+// Threads per workgroup (two workgroups per CU either way: 72 KiB of LDS each).  The one-level kernel runs 512 threads:
+// 4 elements per thread, radix-4 steps, 128 registers, FOUR wavefronts per SIMD - the two-level kernel (single-pass
+// sizes, sizes above 2^24) keeps 256 threads with 8 elements each and radix-8 steps (at 128 registers it spills).
+#ifndef BH_FFT_X_ONE_THREADS
+#define BH_FFT_X_ONE_THREADS 512
 #endif
-constexpr int NTT_THREADS = BH_FFT_X_THREADS;          // 256: 8 elements per thread, radix-8 steps; 512: 4 elements, radix-4 steps
-constexpr int NTT_WAVES_PER_SIMD = NTT_THREADS / 128;  // two workgroups per CU
-constexpr int NTT_GMAX = NTT_THREADS == 256 ? 3 : 2;
-#ifdef BH_FFT_X_M32
-constexpr int NTT_ONE_STRIDE = 32;   // one-level tables hold 32-byte Montgomery entries, sliced after the load
-#else
-constexpr int NTT_ONE_STRIDE = 48;
+#ifndef BH_FFT_X_WAVE_LOCAL
+#define BH_FFT_X_WAVE_LOCAL 1
 #endif
+template <bool ONE>
+struct NttCfg {
+  static constexpr int TH = ONE ? BH_FFT_X_ONE_THREADS : 256;
+  static constexpr int GMAX = TH == 256 ? 3 : 2;      // stages per register step: radix-8 or radix-4
+  static constexpr int WAVES_PER_SIMD = TH / 128;
+  static constexpr int LOG_WAVES = TH == 256 ? 2 : 3;
+};
+constexpr int NTT_ONE_STRIDE = 32;   // a one-level table entry: the 32-byte Montgomery element, sliced after the load
 constexpr int NTT_LOG_TILE = 11;                  // 2048 Fr per workgroup
 constexpr int NTT_TILE = 1 << NTT_LOG_TILE;
 constexpr int NTT_MAX_R = 11;                     // rows of a tile: sub-FFT size 2^r, r <= 11
@@ -147,27 +153,21 @@ struct TwReg {   // a table entry in registers: the nine 30-bit limbs
   u32 c;
 };
 typedef u32 u32x20 __attribute__((ext_vector_type(20)));   // 8 result words, 9 entry words, 3 unused
-#ifdef BH_FFT_X_GLOBAL
-#define BH_GLOBAL_AS __attribute__((address_space(1)))
-#else
-#define BH_GLOBAL_AS
-#endif
+#define BH_GLOBAL_AS __attribute__((address_space(1)))   // global_load, not flat_load: the tables are never in LDS
 __device__ __forceinline__ TwReg tw_load(const BTw *w) {
   const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)w;
   TwReg t;
   t.a = q[0]; t.b = q[1]; t.c = ((const BH_GLOBAL_AS u32 *)w)[8];
   return t;
 }
-// entry `idx` of a one-level table
-__device__ __forceinline__ TwReg tw_load1(const BTw *tab, u64 idx) {
-#ifdef BH_FFT_X_M32
-  const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)((const char *)tab + idx * 32);
-  TwReg t;
-  t.a = q[0]; t.b = q[1]; t.c = 0;
+// entry `idx` of a one-level table: 32 bytes (48 as pre-sliced limbs: a third more to stream per element and pass for 17
+// of a product's 290 instructions - profiles/r5_call1_fft_variants.txt)
+struct MReg { u32x4 a, b; };
+__device__ __forceinline__ MReg tw_load1(const BTw *tab, u64 idx) {
+  const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)((const char *)tab + idx * NTT_ONE_STRIDE);
+  MReg t;
+  t.a = q[0]; t.b = q[1];
   return t;
-#else
-  return tw_load(tab + idx);
-#endif
 }
 __device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1, u32 w2, const BTw *next) {
   const TwReg n = tw_load(next);
@@ -182,33 +182,19 @@ __device__ __attribute__((noinline)) static u32x20 fr_mul_tw(u32x4 a0, u32x4 a1,
   o[16] = n.c; o[17] = 0; o[18] = 0; o[19] = 0;
   return o;
 }
-// the same without the chained load: the entry is already in registers (one-level tables, loaded beside the data)
+// the same without the chained load: the entry (a 32-byte Montgomery element of a one-level table) is already in registers
 typedef u32 u32x8 __attribute__((ext_vector_type(8)));
-__device__ __attribute__((noinline)) static u32x8 fr_mul_w(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1, u32 w2) {
-  fr_t a, r;
-  a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
-  a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
-  const u32 B[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2};
-  fe_mul_b<FrParams, false>(r, a, B);
-  return u32x8{r.l[0], r.l[1], r.l[2], r.l[3], r.l[4], r.l[5], r.l[6], r.l[7]};
-}
-#ifdef BH_FFT_X_M32
 __device__ __attribute__((noinline)) static u32x8 fr_mul_m(u32x4 a0, u32x4 a1, u32x4 w0, u32x4 w1) {
   fr_t a, w, r;
   a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w;
   a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w;
   w.l[0] = w0.x; w.l[1] = w0.y; w.l[2] = w0.z; w.l[3] = w0.w;
   w.l[4] = w1.x; w.l[5] = w1.y; w.l[6] = w1.z; w.l[7] = w1.w;
-  fe_mul<FrParams, false>(r, a, w);
+  fe_mul<FrParams, false>(r, a, w);   // lazily reduced: < 1.91 q for a < 2q and a canonical entry
   return u32x8{r.l[0], r.l[1], r.l[2], r.l[3], r.l[4], r.l[5], r.l[6], r.l[7]};
 }
-#endif
-__device__ __forceinline__ void mul_w(fr_t &a, const TwReg &w) {
-#ifdef BH_FFT_X_M32
+__device__ __forceinline__ void mul_w(fr_t &a, const MReg &w) {
   const u32x8 o = fr_mul_m(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w.a, w.b);
-#else
-  const u32x8 o = fr_mul_w(u32x4{a.l[0], a.l[1], a.l[2], a.l[3]}, u32x4{a.l[4], a.l[5], a.l[6], a.l[7]}, w.a, w.b, w.c);
-#endif
 #pragma unroll
   for (int i = 0; i < 8; i++) a.l[i] = o[i];
 }
@@ -254,25 +240,18 @@ __device__ __forceinline__ constexpr int step_next_mul(int j, int t) {   // (j' 
       if (step_has_mul<G, FIRST>(jj, tt)) return (jj << 8) | tt;
   return -1;
 }
-template <int G, bool FIRST>
+template <int G, bool FIRST, int TH>
 __device__ __forceinline__ void ntt_step(uint4 *p0, uint4 *p1, u32 tid, u32 total, u32 r, u32 s, const BTw *master) {
   constexpr int N = 1 << G;
   const u32 m = 1u << s;
   const u32 ntasks = total >> G;
   const u32 hi_bits = r - s - G;
-  for (u32 task = tid; task < ntasks; task += NTT_THREADS) {
+  for (u32 task = tid; task < ntasks; task += TH) {
     const u32 lo = FIRST ? 0u : (task & (m - 1));
     const u32 rest = task >> s;
     const u32 hi = rest & ((1u << hi_bits) - 1), col = rest >> hi_bits;
     const u32 pos0 = (col << r) + (hi << (s + G)) + lo;
-#if defined(BH_FFT_X_DIAG_NOTW)
-    auto tw_at = [&](int j, int t) { return master + (s + j); };   // timing only: one entry per wavefront (wrong twiddles)
-#elif defined(BH_FFT_X_LEVELS)
-    // the table of stage s + j holds w_{2^(s+j+1)}^k, k < 2^(s+j), at offset 2^(s+j) - 1: lanes with consecutive lo read consecutive entries
-    auto tw_at = [&](int j, int t) { return master + ((1u << (s + j)) - 1u) + ((u32)(t & ((1 << j) - 1)) * m + lo); };
-#else
     auto tw_at = [&](int j, int t) { return master + ((u32)(t & ((1 << j) - 1)) * m + lo) * (1024u >> (s + j)); };
-#endif
     // the task's first entry travels with the LDS reads; each product fetches the next one's (fr_mul_tw)
     constexpr int first_mul = step_next_mul<G, FIRST>(0, -1);
     TwReg cur;
@@ -352,7 +331,8 @@ __device__ __forceinline__ TileGeo tile_geo(const NttPass &a, u64 t) {
 // left a third of the wave cycles waiting (profiles/r4_final_pmc_g2_pairs_and_fft.json: SQ_WAIT_ANY 32 %): all eight
 // entries of a thread are loaded at once, beside the data, before the first product.
 template <bool ONE>
-__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kernel(NttPass a) {
+__global__ __launch_bounds__(NttCfg<ONE>::TH, NttCfg<ONE>::WAVES_PER_SIMD) void ntt_pass_kernel(NttPass a) {
+  constexpr int TH = NttCfg<ONE>::TH, GMAX = NttCfg<ONE>::GMAX;
   __shared__ uint4 plane0[NTT_PLANE];
   __shared__ uint4 plane1[NTT_PLANE];
   const u32 R = 1u << a.r, C = 1u << a.log_c;
@@ -378,14 +358,14 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
   const u32 lb_mask = (1u << a.lb) - 1;
   // All of a thread's loads are issued before anything else happens: a loop of "load, wait, multiply, store to LDS"
   // exposed the full memory latency once per element (8 times per tile, a third of the kernel's time).
-  constexpr int PER = NTT_TILE / NTT_THREADS;   // elements per thread
+  constexpr int PER = NTT_TILE / TH;   // elements per thread
   {
     fr_t v[PER];
     u64 gi[PER];
     u32 slot[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      const u32 e = tid + (u32)i * NTT_THREADS;
+      const u32 e = tid + (u32)i * TH;
       u32 row, col;
       if (!a.is_last) { row = e >> a.log_c; col = e & (C - 1); }   // consecutive lanes -> consecutive columns
       else { col = e >> a.r; row = e & (R - 1); }                  // consecutive lanes -> consecutive rows
@@ -395,23 +375,23 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
       if (e < total) v[i] = ld_fr(vin + gi[i]);
     }
     if (ONE && a.pre1) {   // one product per element; entry of element e = tid + i * 256: lanes read consecutive entries
-      TwReg w[PER];
+      MReg w[PER];
 #pragma unroll
-      for (int i = 0; i < PER; i++) w[i] = tw_load1(a.pre1, tile_first + tid + i * NTT_THREADS);
+      for (int i = 0; i < PER; i++) w[i] = tw_load1(a.pre1, tile_first + tid + i * TH);
 #pragma unroll
       for (int i = 0; i < PER; i++) mul_w(v[i], w[i]);
     } else if (!ONE && a.pre_lo) {   // input element g times pre_hi[g >> lb] * pre_lo[g & mask]: one chain of products (fr_mul_tw)
       const BTw *ph[PER], *pl[PER];
 #pragma unroll
       for (int i = 0; i < PER; i++) {
-        const bool live = tid + (u32)i * NTT_THREADS < total;
+        const bool live = tid + (u32)i * TH < total;
         ph[i] = a.pre_hi + (live ? (u32)(gi[i] >> a.lb) : 0u);
         pl[i] = a.pre_lo + (live ? ((u32)gi[i] & lb_mask) : 0u);
       }
       TwReg cur = tw_load(ph[0]);
 #pragma unroll
       for (int i = 0; i < PER; i++) {
-        if (tid + (u32)i * NTT_THREADS < total) {
+        if (tid + (u32)i * TH < total) {
           mul_tw(v[i], cur, pl[i]);
           mul_tw(v[i], cur, i + 1 < PER ? ph[i + 1] : a.pre_hi);
         }
@@ -419,20 +399,29 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
     }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      if (tid + (u32)i * NTT_THREADS < total) tile_st(plane0, plane1, slot[i], v[i]);
+      if (tid + (u32)i * TH < total) tile_st(plane0, plane1, slot[i], v[i]);
     }
   }
   // ---- the r DIT stages: radix-8 steps, then what is left (4 = 2 + 2 rather than 3 + 1) ---------------------
   {
     u32 s = 0, left = a.r;
-    bool first = true;
+    bool first = true, prev_local = false;
+    u32 prev_g = 0;
     while (left) {
-      __syncthreads();
-      const u32 g = NTT_GMAX == 2 ? (left >= 2 ? 2 : 1) : (left == 4) ? 2 : (left >= 3 ? 3 : left);
-      if (NTT_GMAX == 3 && g == 3) { if (first) ntt_step<3, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<3, false>(plane0, plane1, tid, total, a.r, s, a.master); }
-      else if (g == 2) { if (first) ntt_step<2, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<2, false>(plane0, plane1, tid, total, a.r, s, a.master); }
-      else { if (first) ntt_step<1, true>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<1, false>(plane0, plane1, tid, total, a.r, s, a.master); }
+      const u32 g = GMAX == 2 ? (left >= 2 ? 2 : 1) : (left == 4) ? 2 : (left >= 3 ? 3 : left);
+      // A step whose tasks are one per thread over a full tile keeps every wavefront inside its own block of 2048 / waves
+      // consecutive LDS positions as long as the task's span 2^(s+g) fits the block (the top bits of a position are then
+      // the top bits of the task index, i.e. the wavefront): between two such steps of the same shape nothing crosses a
+      // wavefront, and a wavefront's LDS operations execute in order - no s_barrier, only a compiler fence.
+      const bool local = BH_FFT_X_WAVE_LOCAL && total == (u32)NTT_TILE && (total >> g) == (u32)TH &&
+                         (u32)NTT_LOG_TILE >= g + s + (u32)NttCfg<ONE>::LOG_WAVES;
+      if (local && prev_local && g == prev_g) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      else __syncthreads();
+      if (GMAX == 3 && g == 3) { if (first) ntt_step<3, true, TH>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<3, false, TH>(plane0, plane1, tid, total, a.r, s, a.master); }
+      else if (g == 2) { if (first) ntt_step<2, true, TH>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<2, false, TH>(plane0, plane1, tid, total, a.r, s, a.master); }
+      else { if (first) ntt_step<1, true, TH>(plane0, plane1, tid, total, a.r, s, a.master); else ntt_step<1, false, TH>(plane0, plane1, tid, total, a.r, s, a.master); }
       s += g; left -= g; first = false;
+      prev_local = local; prev_g = g;
     }
   }
   __syncthreads();
@@ -444,14 +433,14 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
     u64 gi[PER];
     if constexpr (ONE) {
       const BTw *one_level = !a.is_last ? a.tw1 : a.post1;
-      TwReg w[PER];
+      MReg w[PER];
       if (one_level) {
 #pragma unroll
-        for (int i = 0; i < PER; i++) w[i] = tw_load1(one_level, tile_first + tid + i * NTT_THREADS);
+        for (int i = 0; i < PER; i++) w[i] = tw_load1(one_level, tile_first + tid + i * TH);
       }
 #pragma unroll
       for (int i = 0; i < PER; i++) {
-        const u32 e = tid + (u32)i * NTT_THREADS;
+        const u32 e = tid + (u32)i * TH;
         const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
         v[i] = tile_ld(plane0, plane1, (col << a.r) + row);
         gi[i] = out_base + row * out_row_stride + col * out_col_stride;
@@ -467,7 +456,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
     const BTw *hi_tab = !a.is_last ? a.tw_hi : a.post_hi, *lo_tab = !a.is_last ? a.tw_lo : a.post_lo;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      const u32 e = tid + (u32)i * NTT_THREADS;
+      const u32 e = tid + (u32)i * TH;
       const bool live = e < total;
       const u32 row = e >> a.log_c, col = e & (C - 1);   // consecutive lanes -> consecutive columns
       if (live) v[i] = tile_ld(plane0, plane1, (col << a.r) + row);
@@ -482,7 +471,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
       TwReg cur = tw_load(ph[0]);
 #pragma unroll
       for (int i = 0; i < PER; i++) {
-        if (tid + (u32)i * NTT_THREADS < total) {
+        if (tid + (u32)i * TH < total) {
           mul_tw(v[i], cur, pl[i]);
           mul_tw(v[i], cur, i + 1 < PER ? ph[i + 1] : hi_tab);
         }
@@ -491,13 +480,13 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_pass_kern
       TwReg cur = tw_load(a.post_const);
 #pragma unroll
       for (int i = 0; i < PER; i++) {
-        if (tid + (u32)i * NTT_THREADS < total) mul_tw(v[i], cur, a.post_const);
+        if (tid + (u32)i * TH < total) mul_tw(v[i], cur, a.post_const);
       }
     }
     }   // two-level tables
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-      const u32 e = tid + (u32)i * NTT_THREADS;
+      const u32 e = tid + (u32)i * TH;
       if (e < total) {
         if (a.is_last) frl_canon(v[i]);   // what leaves the transform is the canonical field element
         st_fr(vout + gi[i], v[i]);
@@ -548,12 +537,12 @@ __global__ void gen_btw_kernel(BTw *out, u64 n, PowTable tab) {
 //   kind 0  x = the inter-pass twiddle exponent of element e in the STORE phase of a non-last pass (`ex`),
 //   kind 1  x = the index of the element the LOAD phase reads as its element e (coset factors g^i of the first pass),
 //   kind 2  x = the index the STORE phase of the last pass writes its element e to (7^-i of icoset_fft)
-__global__ __launch_bounds__(NTT_THREADS) void gen_tile_table_kernel(BTw *out, NttPass a, PowTable tab, int kind) {
+__global__ __launch_bounds__(256) void gen_tile_table_kernel(BTw *out, NttPass a, PowTable tab, int kind) {
   const u64 t = blockIdx.x;
   const TileGeo tg = tile_geo(a, t);
   const u32 R = 1u << a.r, C = 1u << a.log_c;
   const u32 n_mask = (a.log_n >= 32) ? 0xffffffffu : ((1u << a.log_n) - 1);
-  for (u32 e = threadIdx.x; e < (u32)NTT_TILE; e += NTT_THREADS) {
+  for (u32 e = threadIdx.x; e < (u32)NTT_TILE; e += 256) {
     u32 x;
     if (kind == 1) {
       u32 row, col;
@@ -567,34 +556,9 @@ __global__ __launch_bounds__(NTT_THREADS) void gen_tile_table_kernel(BTw *out, N
     fr_t acc = tab.scale;
     for (int k = 0; k < 32; k++)
       if ((x >> k) & 1) fe_mul(acc, acc, tab.p2[k]);
-#ifdef BH_FFT_X_M32
     st_fr(reinterpret_cast<fr_t *>(out) + (t << NTT_LOG_TILE) + e, acc);
-#else
-    BTw w;
-    fe_to_bform<FrParams>(w.l, acc);
-    uint4 *q = reinterpret_cast<uint4 *>(out + (t << NTT_LOG_TILE) + e);
-    q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
-    q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
-    q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
-#endif
   }
 }
-// the in-tile twiddles by stage: entry 2^L - 1 + k = w_2048^(k << (10 - L)) = w_{2^(L+1)}^k, k < 2^L, L <= 10 (2047 entries)
-__global__ void gen_level_table_kernel(BTw *out, PowTable tab) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2047u) return;
-  const u32 L = 31u - __clz(i + 1u), k = i + 1u - (1u << L), x = k << (10u - L);
-  fr_t acc = tab.scale;
-  for (int b = 0; b < 10; b++)
-    if ((x >> b) & 1) fe_mul(acc, acc, tab.p2[b]);
-  BTw w;
-  fe_to_bform<FrParams>(w.l, acc);
-  uint4 *q = reinterpret_cast<uint4 *>(out + i);
-  q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
-  q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
-  q[2] = make_uint4(w.l[8], 0u, 0u, 0u);
-}
-
 // ---- element-wise domain ops -----------------------------------------------------------------
 __global__ void fr_mul_assign_kernel(fr_t *a, const fr_t *b, u64 n) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -797,16 +761,9 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
   if (!c.fft_master[dir]) {   // the in-tile twiddles (96 KiB, shared by every size: not part of the budget)
     fr_t w = fr_domain_omega_host(NTT_LOG_TILE);
     if (inverse) fe_inv(w, w);
-#ifdef BH_FFT_X_LEVELS
-    if (hipMalloc((void **)&new_master, 2048 * sizeof(BTw)) != hipSuccess) return fail(BH_ERR_HIP);
-    fresh.push_back(new_master);
-    hipLaunchKernelGGL(gen_level_table_kernel, dim3(8), dim3(256), 0, st, new_master, make_pow_table(w, one));
-    if (hipGetLastError() != hipSuccess) return fail(BH_ERR_HIP);
-#else
     int rc = make(&new_master, 1024, w, one);
     if (rc) return fail(rc);
     fresh_bytes -= 1024 * sizeof(BTw);
-#endif
   }
   if (!t.init) {
     t.lb = (log_n + 1) / 2;
@@ -828,7 +785,7 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
       fresh.push_back(tab_p);
       fresh_bytes += entry_bytes;
       const NttPass geo = pass_geometry(log_n, pr, pL, p, s_bits);
-      hipLaunchKernelGGL(gen_tile_table_kernel, dim3((u32)(n >> NTT_LOG_TILE)), dim3(NTT_THREADS), 0, st, tab_p, geo,
+      hipLaunchKernelGGL(gen_tile_table_kernel, dim3((u32)(n >> NTT_LOG_TILE)), dim3(256), 0, st, tab_p, geo,
                          make_pow_table(base, scale), kind);
       if (hipGetLastError() != hipSuccess) return false;
       *dst = tab_p;
@@ -990,8 +947,8 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
     a.lb = tab.lb;
     const u64 tiles = ((u64)1 << log_n) >> (r[p] + a.log_c);
     if (n_more && L != 1) return BH_ERR_INVALID_ARG;
-    if (tab.one_level) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((u32)tiles, 1 + n_more), dim3(NTT_THREADS), 0, st, a);
+    if (tab.one_level) hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3((u32)tiles, 1 + n_more), dim3(NttCfg<true>::TH), 0, st, a);
+    else hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3((u32)tiles, 1 + n_more), dim3(NttCfg<false>::TH), 0, st, a);
     BH_HIP_CHECK(hipGetLastError());
     s += r[p];
   }

@@ -19,18 +19,31 @@ def brev(x, bits):
     return r
 
 
-def step_groups(r):
-    """the stage groups of an r-stage sub-FFT: radix-8 steps, 4 = 2 + 2, then what is left"""
+def step_groups(r, gmax=3):
+    """the stage groups of an r-stage sub-FFT: radix-8 steps, 4 = 2 + 2, then what is left (the 256-thread kernel);
+    radix-4 steps, then what is left (gmax = 2: the 512-thread kernel of the one-level tables)"""
     out, left = [], r
     while left:
-        g = 2 if left == 4 else (3 if left >= 3 else left)
+        if gmax == 2:
+            g = 2 if left >= 2 else 1
+        else:
+            g = 2 if left == 4 else (3 if left >= 3 else left)
         out.append(g)
         left -= g
     return out
 
 
-def ntt_step(tile, total, r, s, g, first, master, master_bits, mod, threads):
-    """ntt_step<G, FIRST>: tile is the flat LDS array indexed col * R + pos"""
+def step_is_wave_local(total, log_tile, g, s, threads):
+    """fft.hip: a step with one task per thread over a full tile whose task span 2^(s+g) fits a wavefront's block of
+    tile / waves positions"""
+    waves = max(1, threads // 64)
+    log_waves = waves.bit_length() - 1
+    return total == (1 << log_tile) and (total >> g) == threads and log_tile >= g + s + log_waves
+
+
+def ntt_step(tile, total, r, s, g, first, master, master_bits, mod, threads, by_wave=None):
+    """ntt_step<G, FIRST>: tile is the flat LDS array indexed col * R + pos.  by_wave: dict wavefront -> set of the
+    positions it touched (filled for the barrier check of ntt_model)"""
     m = 1 << s
     ntasks = total >> g
     hi_bits = r - s - g
@@ -45,6 +58,8 @@ def ntt_step(tile, total, r, s, g, first, master, master_bits, mod, threads):
             idxs = [pos0 + (t << s) for t in range(1 << g)]
             assert not (touched & set(idxs)), "two tasks own one element"
             touched |= set(idxs)
+            if by_wave is not None:
+                by_wave.setdefault(tid >> 6, set()).update(idxs)
             e = [tile[i] for i in idxs]
             for j in range(g):
                 for t in range(1 << g):
@@ -64,7 +79,7 @@ def ntt_step(tile, total, r, s, g, first, master, master_bits, mod, threads):
 
 
 def ntt_model(data, mod, omega, log_n, inverse=False, pre_g=None, post_g=None, post_scale=1, post_const=None,
-              log_tile=11, max_r=11, threads=256):
+              log_tile=11, max_r=11, threads=256, gmax=3, barriers_skipped=None):
     """omega: primitive 2^log_n-th root.  pre_g: multiply input i by pre_g^i (coset_fft); post_g / post_scale:
     multiply output k by post_scale * post_g^k (icoset_fft); post_const: multiply every output (ifft's 1/n)."""
     n = 1 << log_n
@@ -156,10 +171,20 @@ def ntt_model(data, mod, omega, log_n, inverse=False, pre_g=None, post_g=None, p
                     v = v * pre[1][g >> lb] % mod * pre[0][g & mask] % mod
                 tile[(col << rp) + brev(row, rp)] = v
             sbits, first = 0, True
-            for g_ in step_groups(rp):
-                ntt_step(tile, total, rp, sbits, g_, first, master, master_bits, mod, threads)
+            prev_local, prev_g, prev_sets = False, 0, None
+            for g_ in step_groups(rp, gmax):
+                local = step_is_wave_local(total, log_tile, g_, sbits, threads)
+                sets = {}
+                ntt_step(tile, total, rp, sbits, g_, first, master, master_bits, mod, threads, by_wave=sets)
+                if local and prev_local and g_ == prev_g:
+                    # the kernel has no s_barrier between these two steps: every wavefront must stay inside what it
+                    # alone touched in the previous step
+                    assert sets == prev_sets, "a step without a barrier crosses wavefronts"
+                    if barriers_skipped is not None:
+                        barriers_skipped.append((rp, sbits))
                 sbits += g_
                 first = False
+                prev_local, prev_g, prev_sets = local, g_, sets
             for e in range(total):
                 row, col = e >> log_c, e & (C - 1)
                 v = tile[(col << rp) + row]

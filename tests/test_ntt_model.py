@@ -53,7 +53,29 @@ def test_model_real_tile_bls(log_n):
     _check(F, vals, log_n, 11, 11, 256, names=("fft", "icoset_fft") if log_n > 11 else ("fft", "ifft", "coset_fft", "icoset_fft"))
 
 
+@pytest.mark.parametrize("log_n,threads,gmax", [(11, 512, 2), (12, 512, 2), (13, 512, 2), (11, 256, 3), (13, 256, 3)])
+def test_model_real_tile_wave_local_steps(log_n, threads, gmax):
+    """[r5] The 512-thread radix-4 kernel of the one-level tables (and the 256-thread radix-8 kernel) drop the s_barrier
+    between register steps that stay inside a wavefront's own block of the tile: the model runs the same task -> thread
+    mapping and asserts, for every pair of steps the kernel's rule leaves without a barrier, that each wavefront touches
+    exactly the positions it touched in the step before - and that the transform is still the serial FFT."""
+    F = Bls12.Fr
+    rnd = random.Random(100 + log_n)
+    vals = [rnd.randrange(F.r) for _ in range(1 << log_n)]
+    d = EvaluationDomain.from_coeffs(F, vals)
+    d.fft(Worker(1))
+    skipped = []
+    got = ntt_model(vals, F.r, d.omega, log_n, log_tile=11, max_r=11, threads=threads, gmax=gmax, barriers_skipped=skipped)
+    assert got == d.coeffs
+    assert skipped, "no barrier was dropped at all"
+    if (log_n, threads) == (11, 512):
+        assert sorted(set(skipped)) == [(11, 2), (11, 4), (11, 6)]     # steps at s = 0, 2, 4, 6 share one barrier
+    if (log_n, threads) == (11, 256):
+        assert sorted(set(skipped)) == [(11, 3), (11, 6)]
+
+
 def test_plan_shapes():
+    assert step_groups(11, 2) == [2, 2, 2, 2, 2, 1] and step_groups(8, 2) == [2, 2, 2, 2] and step_groups(7, 2) == [2, 2, 2, 1]
     assert plan_passes(10) == [10] and plan_passes(11) == [11]
     assert plan_passes(12) == [6, 6]
     assert plan_passes(20) == [10, 10]
