@@ -13,9 +13,22 @@
 //             loops: one chunk per host thread), the serial Fr -> Exponent passes (prover.rs:241-261), and
 //             8 x bh_msm_async with canonical host scalars - each multiexp re-reads its `Arc<Vec<Exponent>>`
 //             (src/hip.rs exponent_words) and uploads it again.
-// Both end with the unchanged tail of create_proof (prover.rs:320-360), here the mirror's assemble_proof.
+//   mode 2  [r5] "multiexp.rs + domain.rs patched only", second form of that patch level (shim/patches, feature `hip`):
+//             the call sites of prover.rs:221-318 are again UNCHANGED, but
+//               * an `EvaluationDomain` keeps its vector in HBM between calls: the first transform uploads `coeffs`,
+//                 ifft / coset_fft / mul_assign / sub_assign / divide_by_z_on_coset / icoset_fft run on the device vector
+//                 (bh_fft_fr_dev, bh_fr_*_dev), `into_coeffs` / `as_ref` download it - 3 uploads + 1 download per proof
+//                 instead of 7 round trips, no host pointwise passes;
+//               * `Exponent::from(&Scalar)` (src/multiexp.rs:172-184, in the patched file) keeps the element as it is in
+//                 memory (`Exponent::Raw`: classification only, no Montgomery reduction) - the serial maps of
+//                 prover.rs:241-261 become copies - and the patched `multiexp` gathers an `Arc<Vec<Exponent>>` into
+//                 contiguous words on the worker's threads ONCE per Arc (a cache keyed by the Arc's pointer, as for base
+//                 vectors), registers it (bh_scalars_register, Montgomery) and issues bh_msm_async_scalars: the aux
+//                 assignment is uploaded once for its four multiexps.
+// All end with the unchanged tail of create_proof (prover.rs:320-360), here the mirror's assemble_proof.
 #include <string.h>
 
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -50,6 +63,10 @@ struct Jobs {
 };
 struct ScalarsHandle {
   bh_scalars *s = nullptr;
+  ScalarsHandle() = default;
+  ScalarsHandle(ScalarsHandle &&o) noexcept : s(o.s) { o.s = nullptr; }
+  ScalarsHandle(const ScalarsHandle &) = delete;
+  ScalarsHandle &operator=(const ScalarsHandle &) = delete;
   ~ScalarsHandle() { if (s) bh_scalars_release(s); }
 };
 // wait order of prover.rs:339-354: a_inputs, a_aux, b_g1_inputs, b_g1_aux, b_g2_inputs, b_g2_aux, h, l
@@ -170,11 +187,113 @@ MsmSums issue_unpatched_prover(Parameters &p, const CallSiteInputs &in) {
   multiexp(p.b_g2, b_in_total, aux_exps, in.b_aux_density, B2_AUX);     // :318
   return wait_all(jobs, p);
 }
+// ---- mode 2 ----------------------------------------------------------------------------------------------------------
+// the patched EvaluationDomain: `coeffs` on the host, its device copy while the last operation ran there
+struct DeviceDomain {
+  bh_ctx *ctx;
+  std::vector<Fr> coeffs;
+  uint32_t exp;
+  void *dev = nullptr;
+  bool host_valid = true;
+  DeviceDomain(bh_ctx *c, const Fr *v, size_t n, size_t m, uint32_t e) : ctx(c), coeffs(m, Fr::zero()), exp(e) {
+    if (n) memcpy(coeffs.data(), v, n * 32);   // from_coeffs (domain.rs:47-79): padded on the host
+  }
+  DeviceDomain(const DeviceDomain &) = delete;
+  // (the Rust DeviceVec's Drop: the operations on the vector were only enqueued - wait before the block returns to the pool)
+  ~DeviceDomain() { if (dev) { (void)bh_ctx_synchronize(ctx); (void)bh_dev_free(ctx, dev); } }
+  void to_device() {
+    if (!dev) {
+      check(bh_dev_alloc(ctx, coeffs.size() * 32, &dev));
+      check(bh_dev_upload(ctx, dev, coeffs.data(), coeffs.size() * 32));
+    }
+    host_valid = false;
+  }
+  void transform(int mode) { to_device(); check(bh_fft_fr_dev(ctx, dev, exp, mode, nullptr)); }
+  void mul_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_mul_assign_dev(ctx, dev, o.dev, coeffs.size(), nullptr)); }
+  void sub_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_sub_assign_dev(ctx, dev, o.dev, coeffs.size(), nullptr)); }
+  void divide_by_z_on_coset() { to_device(); check(bh_fr_divide_by_z_on_coset_dev(ctx, dev, exp, nullptr)); }
+  std::vector<Fr> into_coeffs() {   // domain.rs:42-45: the download (bh_dev_download synchronises the context stream)
+    if (!host_valid) check(bh_dev_download(ctx, coeffs.data(), dev, coeffs.size() * 32));
+    host_valid = true;
+    return std::move(coeffs);
+  }
+};
+// `.map(|s| s.into())` with Exponent::Raw: zero / one are still classified (multiexp.rs:174-177), nothing is converted
+std::vector<Fr> to_raw_exponents(const Fr *v, size_t n) {
+  std::vector<Fr> out(n);
+  const Fr one = Fr::one();
+  size_t special = 0;
+  for (size_t i = 0; i < n; i++) {
+    special += v[i].is_zero() || v[i] == one;   // (the tag a Rust enum would store)
+    out[i] = v[i];
+  }
+  (void)special;
+  return out;
+}
+MsmSums issue_unpatched_prover_resident(Parameters &p, const CallSiteInputs &in) {
+  bh_ctx *ctx = p.ctx;
+  uint32_t exp = 0;
+  size_t m = 1;
+  while (m < in.n_cons) {
+    m *= 2;
+    exp++;
+    if (exp >= 32) throw SynthesisError(BH_ERR_DEGREE_TOO_LARGE, "PolynomialDegreeTooLarge");
+  }
+  // the Arc<Vec<Exponent>> cache of the patched multiexp: one registration per distinct vector, alive until the jobs end
+  std::vector<std::pair<const Fr *, ScalarsHandle>> registered;
+  registered.reserve(4);
+  std::vector<Fr> h_exps, in_exps, aux_exps;
+  Jobs jobs;
+  {
+    DeviceDomain a(ctx, in.a, in.n_cons, m, exp);
+    std::unique_ptr<DeviceDomain> b(new DeviceDomain(ctx, in.b, in.n_cons, m, exp)), c(new DeviceDomain(ctx, in.c, in.n_cons, m, exp));
+    for (DeviceDomain *v : {&a, b.get(), c.get()}) {   // prover.rs:222-230
+      v->transform(BH_IFFT);
+      v->transform(BH_COSET_FFT);
+    }
+    a.mul_assign(*b);                         // :232
+    b.reset();                                // :233 drop(b)
+    a.sub_assign(*c);                         // :234
+    c.reset();                                // :235 drop(c)
+    a.divide_by_z_on_coset();                 // :236
+    a.transform(BH_ICOSET_FFT);               // :237
+    std::vector<Fr> av = a.into_coeffs();
+    av.resize(m - 1);                         // :238-239
+    h_exps = to_raw_exponents(av.data(), av.size());   // :241-242
+  }
+  auto multiexp = [&](bh_bases *bases, size_t skip, const std::vector<Fr> &exps, const uint64_t *density, int slot) {
+    bh_scalars *sc = nullptr;
+    for (auto &r : registered) if (r.first == exps.data()) sc = r.second.s;
+    if (!sc) {
+      // gather into contiguous words on the worker's threads (a Vec<Exponent> has a tag per element), then one upload
+      std::vector<Fr> words(exps.size());
+      scope(exps.size(), [&](size_t lo, size_t hi) { memcpy(words.data() + lo, exps.data() + lo, (hi - lo) * 32); });
+      registered.emplace_back(exps.data(), ScalarsHandle());
+      check(bh_scalars_register(ctx, words.data(), words.size(), BH_SCALARS_MONT, &registered.back().second.s));
+      sc = registered.back().second.s;
+    }
+    const size_t n = exps.size();
+    check(bh_msm_async_scalars(ctx, bases, skip, sc, 0, n, density, density ? n : 0, nullptr, &jobs.j[slot]));
+  };
+  multiexp(p.h, 0, h_exps, nullptr, H);              // :244
+  in_exps = to_raw_exponents(in.inputs, in.n_in);    // :247-261
+  aux_exps = to_raw_exponents(in.aux, in.n_aux);
+  const size_t b_in_total = popcount_bits(in.b_input_density, in.n_in);
+  multiexp(p.l, 0, aux_exps, nullptr, L);                               // :263-268
+  multiexp(p.a, 0, in_exps, nullptr, A_IN);                             // :275-280
+  multiexp(p.a, in.n_in, aux_exps, in.a_aux_density, A_AUX);            // :281-286
+  multiexp(p.b_g1, 0, in_exps, in.b_input_density, B1_IN);              // :296-301
+  multiexp(p.b_g1, b_in_total, aux_exps, in.b_aux_density, B1_AUX);     // :302-307
+  multiexp(p.b_g2, 0, in_exps, in.b_input_density, B2_IN);              // :312-317
+  multiexp(p.b_g2, b_in_total, aux_exps, in.b_aux_density, B2_AUX);     // :318
+  return wait_all(jobs, p);
+}
 }  // namespace
 
 static Proof prove_via_call_sites(Parameters &params, const CallSiteInputs &in, const Fr &r, const Fr &s, int mode, float *ms2) {
   const double t0 = now_ms();
-  const MsmSums sums = mode ? issue_patched(params, in) : issue_unpatched_prover(params, in);
+  const MsmSums sums = mode == 1 ? issue_patched(params, in) : mode == 2 ? issue_unpatched_prover_resident(params, in)
+                                                                          : issue_unpatched_prover(params, in);
   const double t1 = now_ms();
   Proof p = assemble_proof(params, sums, r, s);   // prover.rs:320-360
   if (ms2) { ms2[0] = (float)(t1 - t0); ms2[1] = (float)(now_ms() - t0); }
@@ -189,7 +308,7 @@ extern "C" int bh_test_groth16_prove_via_call_sites(bh_params *params, int mode,
                                                     const uint64_t *b_aux_density, const void *r, const void *s,
                                                     void *proof_out, float *ms2) {
   using namespace groth16;
-  if (!params || !r || !s || !proof_out || (mode != 0 && mode != 1)) return BH_ERR_INVALID_ARG;
+  if (!params || !r || !s || !proof_out || mode < 0 || mode > 2) return BH_ERR_INVALID_ARG;
   if ((n_constraints && (!a_evals || !b_evals || !c_evals)) || (n_inputs && (!input_assignment || !b_input_density)) ||
       (n_aux && (!aux_assignment || !a_aux_density || !b_aux_density)))
     return BH_ERR_INVALID_ARG;

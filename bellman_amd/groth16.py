@@ -631,14 +631,18 @@ def prove_via_call_sites(params, asg, r, s, patched_prover, timings=None):
     """The h block + eight multiexps issued as bellman's create_proof issues them through the Rust shim:
     patched_prover=True  - groth16/src/prover.rs patched (scalars registered once, h block in one device call);
     patched_prover=False - only multiexp.rs / domain.rs patched (7 host FFT round trips, host pointwise passes, serial
-                           Fr -> Exponent, 8 multiexps each uploading its scalars).
+                           Fr -> Exponent, 8 multiexps each uploading its scalars);
+    patched_prover="resident" - the same patch level with the EvaluationDomain's vector kept in HBM between its calls,
+                           `Exponent::from` deferred (no conversion on the host) and each shared exponent vector
+                           uploaded once (csrc/groth16_callsites.cpp mode 2).
     timings: [issue + waits, total] host ms."""
     lib = _lib.load()
     rs = fr_to_mont_array([r, s])
     out = np.zeros(48, dtype=np.uint64)
     tm = (ctypes.c_float * 2)()
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    check(lib.bh_test_groth16_prove_via_call_sites(params._h, 1 if patched_prover else 0, p(asg["a"]), p(asg["b"]), p(asg["c"]),
+    mode = 2 if patched_prover == "resident" else 1 if patched_prover else 0
+    check(lib.bh_test_groth16_prove_via_call_sites(params._h, mode, p(asg["a"]), p(asg["b"]), p(asg["c"]),
                                                    asg["a"].shape[0], p(asg["input_assignment"]), asg["input_assignment"].shape[0],
                                                    p(asg["aux_assignment"]), asg["aux_assignment"].shape[0], p(asg["a_aux_density"]),
                                                    p(asg["b_input_density"]), p(asg["b_aux_density"]), p(rs[0:1]), p(rs[1:2]), p(out), tm),

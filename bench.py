@@ -176,8 +176,9 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     # The drop-in as a patched bellman drives it (shim/patches/bellman-hip.patch; the C calls are issued by the C++
     # transcription csrc/groth16_callsites.cpp - no Rust toolchain here): the h block + eight multiexps of
     # prover.rs:217-318 on an assignment synthesised beforehand (synthesis is the same host work in every variant),
-    # (a) with groth16/src/prover.rs patched, (b) with only multiexp.rs / domain.rs patched; (c) the mirror's own
-    # bh_groth16_prove_assignment.  All three must give the same proof.
+    # (a) with groth16/src/prover.rs patched, (b) with only multiexp.rs / domain.rs patched (the shipped form with a
+    # device-resident EvaluationDomain, and the round-4 form with a round trip per call); (c) the mirror's own
+    # bh_groth16_prove_assignment.  All must give the same proof.
     asg = pg.demo_assignment(1, rounds, CIRCUIT_SEED, [987654321 + proofs])
     call_sites = {}
     ref_tm = []
@@ -189,7 +190,8 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
             ref_tm.append((time.perf_counter() - t0) * 1e3)
     assert ref_proof.a.tobytes() == last.a.tobytes() and ref_proof.b.tobytes() == last.b.tobytes() and \
         ref_proof.c.tobytes() == last.c.tobytes()
-    for name, patched in (("create_proof_via_patched_call_sites", True), ("create_proof_via_multiexp_and_fft_call_sites_only", False)):
+    for name, patched in (("create_proof_via_patched_call_sites", True), ("create_proof_via_multiexp_and_fft_call_sites_only", "resident"),
+                          ("create_proof_via_multiexp_and_fft_call_sites_only_round4_patch", False)):
         ws = []
         for i in range(proofs + 1):
             t0 = time.perf_counter()
@@ -204,11 +206,16 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "groth16/src/prover.rs patched: bh_scalars_register x2 (Montgomery, shared by the multiexps that use them), "
         "bh_msm_async_scalars x8, bh_h_poly_fr_scalars x1 (h coefficients stay in HBM), bh_msm_wait x8; host tail prover.rs:320-360")
     call_sites["create_proof_via_multiexp_and_fft_call_sites_only"]["calls"] = (
-        "only src/multiexp.rs + src/domain.rs patched: 7 x bh_fft_fr on host vectors (upload + download each), mul/sub/divide_by_z "
+        "only src/multiexp.rs + src/domain.rs (+ src/hip.rs) patched, prover.rs untouched: an EvaluationDomain keeps its vector in HBM "
+        "between its calls (3 uploads, 7 x bh_fft_fr_dev, bh_fr_mul_assign_dev / sub_assign / divide_by_z_on_coset on the device, 1 "
+        "download at into_coeffs); Exponent::from(&Scalar) defers the conversion (Montgomery words handed to the device); every "
+        "Arc<Vec<Exponent>> gathered on the worker's threads and registered once (bh_scalars_register x3), bh_msm_async_scalars x8")
+    call_sites["create_proof_via_multiexp_and_fft_call_sites_only_round4_patch"]["calls"] = (
+        "the round-4 form of that patch level: 7 x bh_fft_fr on host vectors (upload + download each), mul/sub/divide_by_z "
         "on the host (one chunk per host thread), serial Fr -> Exponent passes (prover.rs:241-261), 8 x bh_msm_async with "
         "canonical host scalars (each uploads its vector again)")
     call_sites["bh_groth16_prove_assignment_same_inputs"] = {"ms_after_synthesis": round(float(np.mean(ref_tm)), 2)}
-    call_sites["note"] = ("all three proofs asserted bit-identical; host synthesis (ms_host_synthesis above) precedes each of them "
+    call_sites["note"] = ("all four proofs asserted bit-identical; host synthesis (ms_host_synthesis above) precedes each of them "
                           "in a real create_proof")
     cpu = None
     if cpu_baseline:

@@ -51,6 +51,7 @@ pub struct Context {
     layout: layout::Layout,
     g1_cache: Mutex<BasesCache<G1Affine>>,
     g2_cache: Mutex<BasesCache<G2Affine>>,
+    scalars_cache: Mutex<HashMap<(usize, usize), CachedScalars>>,
 }
 // the library is thread-safe and re-entrant per context (include/bellman_hip.h: "one per (process, GPU); thread-safe")
 unsafe impl Send for Context {}
@@ -71,7 +72,13 @@ pub fn context() -> Option<&'static Context> {
             if rc != ffi::BH_OK || raw.is_null() {
                 return None;
             }
-            Some(Context { raw, layout, g1_cache: Mutex::new(BasesCache::new()), g2_cache: Mutex::new(BasesCache::new()) })
+            Some(Context {
+                raw,
+                layout,
+                g1_cache: Mutex::new(BasesCache::new()),
+                g2_cache: Mutex::new(BasesCache::new()),
+                scalars_cache: Mutex::new(HashMap::new()),
+            })
         })
         .as_ref()
 }
@@ -140,6 +147,36 @@ impl Context {
         c.map.insert(key, CachedBases { owner: Arc::downgrade(v), dev });
         Ok(dev as *const _)
     }
+}
+
+/// A vector of Montgomery scalars in HBM, owned (freed on drop): the device copy of an `EvaluationDomain`'s `coeffs`.
+pub struct DeviceVec {
+    ctx: *mut ffi::BhCtx,
+    dev: *mut c_void,
+    len: usize,
+}
+unsafe impl Send for DeviceVec {}
+impl DeviceVec {
+    pub fn len(&self) -> usize {
+        self.len
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len == 0
+    }
+}
+impl Drop for DeviceVec {
+    fn drop(&mut self) {
+        // the operations on the vector were enqueued on the context stream and the block goes back to a pool that other
+        // streams allocate from: wait for them first (prover.rs drops `b` right after `a.mul_assign(&worker, &b)`)
+        unsafe {
+            ffi::bh_ctx_synchronize(self.ctx);
+            ffi::bh_dev_free(self.ctx, self.dev);
+        }
+    }
+}
+struct CachedScalars {
+    owner: Weak<dyn std::any::Any + Send + Sync>,
+    dev: Arc<Scalars>,
 }
 
 /// Density map of a multiexp as the C ABI wants it: `None` = `FullDensity` (src/multiexp.rs:95-115), else the
@@ -321,6 +358,65 @@ impl Context {
     pub fn fft(&self, data: &mut [Scalar], log_n: u32, mode: c_int) -> Result<(), HipError> {
         assert_eq!(data.len(), 1usize << log_n);
         check(unsafe { ffi::bh_fft_fr(self.raw, data.as_mut_ptr() as *mut c_void, log_n, mode) })
+    }
+
+    /// A host vector of Montgomery scalars -> HBM (what an `EvaluationDomain` keeps between its calls).
+    pub fn upload_fr(&self, data: &[Scalar]) -> Result<DeviceVec, HipError> {
+        let mut dev: *mut c_void = ptr::null_mut();
+        check(unsafe { ffi::bh_dev_alloc(self.raw, data.len().max(1) * 32, &mut dev) })?;
+        let v = DeviceVec { ctx: self.raw, dev, len: data.len() };
+        check(unsafe { ffi::bh_dev_upload(self.raw, dev, data.as_ptr() as *const c_void, data.len() * 32) })?;
+        Ok(v)
+    }
+    /// ... and back (synchronises the context stream: everything enqueued on the vector has finished).
+    pub fn download_fr(&self, v: &DeviceVec, out: &mut [Scalar]) -> Result<(), HipError> {
+        assert_eq!(out.len(), v.len);
+        check(unsafe { ffi::bh_dev_download(self.raw, out.as_mut_ptr() as *mut c_void, v.dev as *const c_void, v.len * 32) })
+    }
+    /// `EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}` on a vector that is already in HBM (no copies).
+    pub fn fft_dev(&self, v: &DeviceVec, log_n: u32, mode: c_int) -> Result<(), HipError> {
+        assert_eq!(v.len, 1usize << log_n);
+        check(unsafe { ffi::bh_fft_fr_dev(self.raw, v.dev, log_n, mode, ptr::null_mut()) })
+    }
+    /// `mul_assign` / `sub_assign` / `divide_by_z_on_coset` (src/domain.rs:129-189) on device vectors.
+    pub fn mul_assign_dev(&self, a: &DeviceVec, b: &DeviceVec) -> Result<(), HipError> {
+        assert_eq!(a.len, b.len);
+        check(unsafe { ffi::bh_fr_mul_assign_dev(self.raw, a.dev, b.dev as *const c_void, a.len, ptr::null_mut()) })
+    }
+    pub fn sub_assign_dev(&self, a: &DeviceVec, b: &DeviceVec) -> Result<(), HipError> {
+        assert_eq!(a.len, b.len);
+        check(unsafe { ffi::bh_fr_sub_assign_dev(self.raw, a.dev, b.dev as *const c_void, a.len, ptr::null_mut()) })
+    }
+    pub fn divide_by_z_on_coset_dev(&self, a: &DeviceVec, log_n: u32) -> Result<(), HipError> {
+        assert_eq!(a.len, 1usize << log_n);
+        check(unsafe { ffi::bh_fr_divide_by_z_on_coset_dev(self.raw, a.dev, log_n, ptr::null_mut()) })
+    }
+
+    /// The registered (device-resident) form of an `Arc<Vec<T>>` of exponents: created by `gather` the first time this
+    /// Arc is seen, then shared by every multiexp over it (prover.rs hands the same `Arc<Vec<Exponent>>` to up to four
+    /// multiexps).  Keyed like the base vectors: address + length, a `Weak` guards against a reused address.
+    pub fn scalars_for<T: Send + Sync + 'static>(
+        &self,
+        v: &Arc<Vec<T>>,
+        gather: impl FnOnce(&[T]) -> Vec<Scalar>,
+    ) -> Result<Arc<Scalars>, HipError> {
+        let key = (Arc::as_ptr(v) as usize, v.len());
+        let mut c = self.scalars_cache.lock().unwrap();
+        c.retain(|_, e| e.owner.strong_count() > 0);
+        if let Some(e) = c.get(&key) {
+            if let Some(alive) = e.owner.upgrade() {
+                if let Ok(same) = alive.downcast::<Vec<T>>() {
+                    if Arc::ptr_eq(&same, v) {
+                        return Ok(e.dev.clone());
+                    }
+                }
+            }
+        }
+        let words = gather(v.as_slice());
+        let dev = self.register_scalars(&words)?;
+        let owner: Arc<dyn std::any::Any + Send + Sync> = v.clone();
+        c.insert(key, CachedScalars { owner: Arc::downgrade(&owner), dev: dev.clone() });
+        Ok(dev)
     }
 
     /// The h block of `create_proof` (groth16/src/prover.rs:221-240) in one call: a, b, c evaluations in,

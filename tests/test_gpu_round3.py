@@ -41,7 +41,8 @@ def _p(a):
 # the drop-in as patched
 # ---------------------------------------------------------------------------------------------------------------------
 def test_call_sites_mimc_322(worker):
-    """C1 through the call sequences of the patched bellman (both patch levels) == create_proof == the oracle"""
+    """C1 through the call sequences of the patched bellman (both patch levels, the weaker one in both its forms - [r5]
+    "resident": the EvaluationDomain stays in HBM between its calls) == create_proof == the oracle"""
     from bellman_amd import groth16 as pg
     from oracle.pyref.prover import create_proof as oracle_create_proof
 
@@ -53,7 +54,7 @@ def test_call_sites_mimc_322(worker):
     pp = _product_params(worker, p)
     asg = pg.demo_assignment(0, circuits.MIMC_ROUNDS, 0, [xl, xr], cons)
     assert asg["a"].shape[0] == 646 and asg["aux_assignment"].shape[0] == 645
-    for patched in (True, False):
+    for patched in (True, False, "resident"):
         tm = [0, 0]
         got = pg.prove_via_call_sites(pp, asg, r, s, patched, tm)
         assert _same(got, want.a, want.b, want.c), patched
@@ -70,7 +71,7 @@ def test_call_sites_chain_circuit(worker, rounds):
     want = pg.create_proof_demo(pp, 1, rounds, seed, [x0], None, r, s)   # pinned to the oracle in test_gpu_groth16.py
     got_ref = pg.prove_assignment_arrays(pp, asg, r, s)
     assert _same(got_ref, want.a, want.b, want.c)
-    for patched in (True, False):
+    for patched in (True, False, "resident"):
         got = pg.prove_via_call_sites(pp, asg, r, s, patched)
         assert _same(got, want.a, want.b, want.c), patched
 
@@ -84,7 +85,7 @@ def test_call_sites_error_paths(worker):
     pp, vk, (h, l, a, b1, b2) = _chain_setup(worker, rounds, seed)
     short = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l[:-3], a, b1, b2)
     asg = pg.demo_assignment(1, rounds, seed, [x0])
-    for patched in (True, False):
+    for patched in (True, False, "resident"):
         with pytest.raises(UnexpectedEof):
             pg.prove_via_call_sites(short, asg, 5, 6, patched)
     assert worker.info()["jobs_in_flight"] == 0
@@ -95,7 +96,7 @@ def test_call_sites_error_paths(worker):
     both = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], zero1, vk["delta_g2"], h, l[:-3], a, b1, b2)
     with pytest.raises(UnexpectedIdentity):
         pg.create_proof_demo(both, 1, rounds, seed, [x0], None, 5, 6)
-    for patched in (True, False):
+    for patched in (True, False, "resident"):
         with pytest.raises(UnexpectedIdentity):
             pg.prove_via_call_sites(both, asg, 5, 6, patched)
     assert worker.info()["jobs_in_flight"] == 0
