@@ -147,8 +147,9 @@ struct FftTables {
   fr_t minv;                                                              // n^-1 (Montgomery)
   fr_t zinv;                                                              // (7^n - 1)^-1: divide_by_z_on_coset
   BTw *minv_dev = nullptr;                                                // ... as a one-entry table
-  // [r4] one-level tables in element order (fft.hip; 2^12 .. 2^24 points): inter-pass twiddles per direction and non-last
-  // pass - the inverse direction's first one carries the 1/n -, 7^i and 7^-i.  n entries each.
+  // [r4] one-level tables in tile order (fft.hip; 2^12 .. 2^24 points): inter-pass twiddles per direction and non-last
+  // pass - the inverse direction's first one carries the 1/n -, 7^i and 7^-i.  n entries each; [r5] an entry is the
+  // 32-byte Montgomery element (the pointers are typed BTw* for the two-level tables they sit beside).
   bool one_level = false, one_level_failed = false;
   BTw *tw1[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   BTw *coset1 = nullptr, *icoset1 = nullptr;

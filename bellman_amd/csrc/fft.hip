@@ -13,28 +13,36 @@
 // 2^22 (the 2^20 / 2^22 domains of the proof sizes that matter: 64 B of algorithmic traffic per element become
 // 128 B of real traffic, not 192), three up to 2^31.  A pass gives every workgroup a tile of 2048 elements
 // (R rows x C columns; 72 KiB of LDS, two workgroups per CU so one tile's global loads/stores overlap the other's
-// butterflies) and performs all R-point sub-FFTs of the tile:
-//   * 8 elements per thread: radix-8 (three DIT stages) in registers between LDS exchanges, i.e. 4 LDS round
-//     trips for an 11-stage sub-FFT instead of 11; LDS is two 16-byte planes with one pad slot per 8 so that the
-//     stride-8m accesses of every step are bank-conflict free;
-//   * the first step of a pass has only the constant twiddles w_4, w_8^{1,2,3}: 5 multiplications per 8 points
-//     instead of 12;
+// butterflies) and performs all R-point sub-FFTs of the tile in register steps between LDS exchanges (LDS is two
+// 16-byte planes with one pad slot per 8):
+//   * [r5] sizes with one-level tables (2^12 .. 2^24, below) run 512 threads per workgroup: 4 elements per thread,
+//     radix-4 steps (two DIT stages in registers), 128 VGPRs, FOUR wavefronts per SIMD.  The round-4 kernel - 256 threads,
+//     8 elements each, radix-8 steps, two wavefronts per SIMD - had its wavefronts parked 24 % of the time (s_waitcnt /
+//     s_barrier) and stalled at issue another 33 % (profiles/r5_fft_pmc_wait_split.json): with a second wavefront as the
+//     only cover, every park left a SIMD on one wavefront's issue rate.  Four wavefronts: -8..15 % by size and mode
+//     (profiles/r5_call1_fft_variants.txt).  The two-level kernel (single-pass sizes, sizes above 2^24, sizes over the
+//     table budget) keeps the 256-thread radix-8 form: at 128 registers it spills.
+//   * [r5] register steps whose tasks stay inside a wavefront's own block of the tile need no s_barrier between them (a
+//     wavefront's LDS operations execute in order): 4 barriers per tile instead of 7 at r = 11, 2 instead of 5 at r = 8
+//     (-3..5 %; the rule is in ntt_pass_kernel, its proof by enumeration in tests/models/ntt_model.py).
+//   * the first step of a pass has only the constant twiddles w_4 (radix-4) / w_4, w_8^{1,2,3} (radix-8);
 //   * twiddles are never gathered from an n-entry table.  In-tile twiddles come from ONE 1024-entry master table
-//     w_2048^i (48 KiB, cache resident, shared by every pass of every size); inter-pass twiddles w_n^e, the coset
-//     factors 7^i / 7^-i and 1/n come from two-level tables (e = e_hi*2^LB + e_lo: two multiplications, tables of
-//     about 2^(log_n/2) entries);
-//   * every table entry is stored PRE-SLICED for the multiplier ("B form": the nine 30-bit limbs of w << 14,
-//     ff.cuh), which removes the operand re-slicing of one side of every product.
-// [r4] * from 2^12 to 2^24 points the inter-pass twiddles, the coset factors 7^i and 7^-i are ONE-level tables laid out in
-//     the order the kernel consumes them (element order: the entry of element g sits at index g, read coalesced beside
-//     the data) - one product per element instead of the two of the hi x lo tables; the 1/n of the inverse transforms
-//     is folded into the inverse twiddle table, so ifft has no scaling product at all.  48 B per element and table
-//     (0.2 GB at 2^22) bought 1-2 of the 11-13 products per element; traffic per pass goes from 64 to 112 B per
-//     element where a table is read, still far from the bound.
+//     w_2048^i (48 KiB, cache resident, shared by every pass of every size; reading it as one entry per wavefront instead
+//     of one per lane changes nothing: r5_call1, lib_notw); inter-pass twiddles w_n^e, the coset factors 7^i / 7^-i and
+//     1/n come from two-level tables (e = e_hi*2^LB + e_lo: two multiplications, tables of about 2^(log_n/2) entries),
+//     stored PRE-SLICED for the multiplier ("B form": the nine 30-bit limbs of w << 14, ff.cuh);
+//   * from 2^12 to 2^24 points the inter-pass twiddles, the coset factors 7^i and 7^-i are ONE-level tables laid out in
+//     the order the kernel consumes them (tile order: entry t * 2048 + e belongs to element e of tile t, read coalesced
+//     beside the data) - one product per element instead of the two of the hi x lo tables; the 1/n of the inverse
+//     transforms is folded into the inverse twiddle table, so ifft has no scaling product at all.  [r5] Their entries are
+//     the plain 32-byte Montgomery elements, sliced after the load (48-byte B form until round 4: a third more to stream
+//     per element and pass for 17 of a product's 290 instructions; -3..7 % where a table streams).  The cache of these
+//     tables has a budget (bh_ctx_set_limits): a size whose complete set does not fit runs on the two-level tables.
 //   * butterflies compute LAZILY REDUCED in [0, 2q): every product is data x (canonical) table entry, whose Montgomery
 //     result is < 1.91 q without the final conditional subtraction; additions / subtractions correct by +-2q (the sum
 //     of two such values needs bit 256: the carry out of the eight words decides with the borrow).  The last pass
-//     makes its outputs canonical, so what the caller sees is bit-identical to the reference's field elements.
+//     makes its outputs canonical, so what the caller sees is bit-identical to the reference's field elements
+//     (extreme inputs at every pass plan and both table kinds: tests/test_gpu_fft_extremes.py).
 // Non-last passes read and write the same positions (pass 0 moves the data into a scratch vector); the last
 // pass scatters the digit-reversed result to natural order back into the caller's vector.  Workgroup -> tile
 // assignment is XCD-aware: tiles that share 128-byte lines (the narrow tiles of the 2^21 / 2^22 plans) go to the
@@ -46,15 +54,9 @@ namespace bh {
 // Threads per workgroup (two workgroups per CU either way: 72 KiB of LDS each).  The one-level kernel runs 512 threads:
 // 4 elements per thread, radix-4 steps, 128 registers, FOUR wavefronts per SIMD - the two-level kernel (single-pass
 // sizes, sizes above 2^24) keeps 256 threads with 8 elements each and radix-8 steps (at 128 registers it spills).
-#ifndef BH_FFT_X_ONE_THREADS
-#define BH_FFT_X_ONE_THREADS 512
-#endif
-#ifndef BH_FFT_X_WAVE_LOCAL
-#define BH_FFT_X_WAVE_LOCAL 1
-#endif
 template <bool ONE>
 struct NttCfg {
-  static constexpr int TH = ONE ? BH_FFT_X_ONE_THREADS : 256;
+  static constexpr int TH = ONE ? 512 : 256;
   static constexpr int GMAX = TH == 256 ? 3 : 2;      // stages per register step: radix-8 or radix-4
   static constexpr int WAVES_PER_SIMD = TH / 128;
   static constexpr int LOG_WAVES = TH == 256 ? 2 : 3;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(NttCfg<ONE>::TH, NttCfg<ONE>::WAVES_PER_SIMD) void 
       // consecutive LDS positions as long as the task's span 2^(s+g) fits the block (the top bits of a position are then
       // the top bits of the task index, i.e. the wavefront): between two such steps of the same shape nothing crosses a
       // wavefront, and a wavefront's LDS operations execute in order - no s_barrier, only a compiler fence.
-      const bool local = BH_FFT_X_WAVE_LOCAL && total == (u32)NTT_TILE && (total >> g) == (u32)TH &&
+      const bool local = total == (u32)NTT_TILE && (total >> g) == (u32)TH &&
                          (u32)NTT_LOG_TILE >= g + s + (u32)NttCfg<ONE>::LOG_WAVES;
       if (local && prev_local && g == prev_g) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       else __syncthreads();

@@ -5,7 +5,8 @@ The butterflies of csrc/fft.hip compute lazily reduced in [0, 2q) on the argumen
 entry leaves the Montgomery multiplier below 1.91 q without its final subtraction"; the one-level tables fold the 1/n of
 the inverse transforms into their first twiddle table.  Random vectors (what every other FFT test feeds) sit in the
 middle of every range, so here are the corners: all limbs at q - 1 (the largest stored value), all zero, all one, all
-minus one, a single non-zero coefficient at index 0 / 1 / n - 1, alternating 0 / q - 1, and (q - 1)(-1)^i - all four
+minus one, a single non-zero coefficient at index 0 / 1 / n - 1, alternating 0 / q - 1, and (q - 1)(-1)^i (at 2^21 and
+above without the all-zero, all-one and index-0 vectors, whose oracle transforms would only add minutes) - all four
 transforms, at the sizes where the pass plan and the table kind switch (2^11: one pass; 2^12, 2^13: two passes, the
 smallest one-level sizes; 2^21, 2^22: two passes with tiles one or two elements wide; 2^23: three passes), each with the
 one-level tables (default) and with the hi x lo tables forced (BELLMAN_HIP_FFT_ONE_LEVEL=0: what sizes above 2^24, or
@@ -62,16 +63,29 @@ vectors = {
     "alternating_0_qm1": alternating(0, Q - 1),
     "minus_one_alternating_sign": alternating(Q - R, R),   # (q - 1) * (-1)^i
 }
+# the sizes whose oracle transform takes seconds keep the vectors that sit on the range bounds (the others add nothing a
+# smaller size does not already cover); their oracle outputs are computed concurrently (the C oracle releases the GIL;
+# 8 threads each: its parallel_fft costs m * P extra products, so more threads per transform only slow it down)
+if log_n >= 20:
+    vectors = {k: vectors[k] for k in ("all_stored_q_minus_1", "all_minus_one", "delta_1", "delta_last", "alternating_0_qm1",
+                                       "minus_one_alternating_sign")}
+from concurrent.futures import ThreadPoolExecutor
+
+def want_of(job):
+    name, mode = job
+    path = os.path.join(cache, "%%d_%%s_%%d.npy" %% (log_n, name, mode))
+    if not os.path.exists(path):
+        np.save(path, cref.fft(vectors[name], mode, threads=8))
+    return path
+
+cref.lib()
+jobs = [(name, mode) for name in vectors for mode in (0, 1, 2, 3)]
+with ThreadPoolExecutor(max_workers=max(1, min(12, (os.cpu_count() or 8) // 8))) as ex:
+    paths = dict(zip(jobs, ex.map(want_of, jobs)))
 w = bellman_amd.Worker(0)
-threads = cref.lib().orc_max_threads()
 for name, data in vectors.items():
     for mode in (0, 1, 2, 3):
-        path = os.path.join(cache, "%%d_%%s_%%d.npy" %% (log_n, name, mode))
-        if os.path.exists(path):
-            want = np.load(path)
-        else:
-            want = cref.fft(data, mode, threads=threads)
-            np.save(path, want)
+        want = np.load(paths[(name, mode)])
         d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
         [d.fft, d.ifft, d.coset_fft, d.icoset_fft][mode]()
         got = d.into_coeffs()

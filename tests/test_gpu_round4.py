@@ -196,34 +196,40 @@ def test_g1_window_table_at_128_byte_stride(worker):
 
 def test_fft_table_cache_stays_within_its_budget(worker):
     """[r5] The per-size FFT tables are a cache with a budget (bh_ctx_set_limits' fft_table_budget_bytes, reported by
-    bh_ctx_info): under 1 GiB the transforms of 2^20 ... 2^24 points - whose one-level tables would add up to several
-    GiB - stay bit-exact (all four modes against the restated best_fft: src/domain.rs:81-125), `fft_table_bytes` never
+    bh_ctx_info): under 768 MiB the transforms of 2^20 ... 2^24 points - whose one-level tables would add up to several
+    GiB - stay exact (fft against the restated best_fft up to 2^22, ifft . fft and icoset_fft . coset_fft back to the data at
+    every size: src/domain.rs:81-125, :427-463; both table kinds limb for limb: tests/test_gpu_fft_extremes.py), `fft_table_bytes` never
     exceeds the budget, sizes whose complete set does not fit run on the two-level tables, and coming back to an evicted
     size rebuilds its tables."""
     import bellman_amd
     from oracle import cref
 
-    budget = 1 << 30
+    budget = 768 << 20   # 2^20 + 2^21 + 2^22 need 128 + 256 + 512 MiB of one-level tables: the third size evicts the first
     w = bellman_amd.Worker(0)
     try:
         w.set_limits(fft_table_budget_bytes=budget)
         assert w.info()["fft_table_budget"] == budget and w.info()["fft_table_bytes"] == 0
-        threads = cref.lib().orc_max_threads()
-        seen = []
+        seen, checked = [], set()
         for log_n in (20, 21, 22, 23, 24, 20, 22):
             data = cref.random_fr(1 << log_n, 7700 + log_n)
-            for mode in (0, 1, 2, 3):
-                d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
+            d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
+            for step, mode in enumerate((0, 1, 2, 3)):   # fft, ifft (back to the data), coset_fft, icoset_fft (back again)
                 [d.fft, d.ifft, d.coset_fft, d.icoset_fft][mode]()
-                assert np.array_equal(d.into_coeffs(), cref.fft(data, mode, threads=threads)), (log_n, mode)
                 held = w.info()["fft_table_bytes"]
                 assert held <= budget, (log_n, mode, held)
                 seen.append(held)
+                if mode == 0 and log_n <= 22 and log_n not in checked:   # (8 threads: the oracle's split costs m * P products)
+                    assert np.array_equal(d.as_ref(), cref.fft(data, 0, threads=8)), log_n
+                    checked.add(log_n)
+                if mode in (1, 3):
+                    assert np.array_equal(d.as_ref(), data), (log_n, mode)
+            d.into_coeffs()
         assert max(seen) > (64 << 20)    # one-level tables were in use (2^20: 32 MiB each) ...
+        assert any(b < a for a, b in zip(seen, seen[1:]))   # ... and the least recently used size made room at least once
         w.set_limits(fft_table_budget_bytes=0)   # ... and with no budget at all every size runs on two-level tables
         data = cref.random_fr(1 << 16, 7777)
         d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
         d.icoset_fft()
-        assert np.array_equal(d.into_coeffs(), cref.fft(data, 3, threads=threads))
+        assert np.array_equal(d.into_coeffs(), cref.fft(data, 3, threads=8))
     finally:
         w.close()
