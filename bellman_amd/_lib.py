@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BELLMAN_HIP_LIB: another build of the SAME library (A/B runs of a kernel experiment against the shipped build, e.g.
-# tools/gpu_r4_call1.sh) - honoured only together with BELLMAN_HIP_ALLOW_LIB_OVERRIDE=1, so that a stray variable cannot
+# tools/build_variant.sh) - honoured only together with BELLMAN_HIP_ALLOW_LIB_OVERRIDE=1, so that a stray variable cannot
 # swap the library under the tests or the bench (bench.py prints bh_version() and the library's path and hash into its
 # JSON line).  Never a different implementation - there is no fallback of any kind.
 _OVERRIDE = os.environ.get("BELLMAN_HIP_LIB") if os.environ.get("BELLMAN_HIP_ALLOW_LIB_OVERRIDE") == "1" else None

@@ -662,7 +662,7 @@ def main():
     s_dev = torch.from_numpy(s_host.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
-    ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (tools/gpu_r4_*.sh)
+    ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (tools/r5/*.sh, tools/history/)
 
     def step():
         w = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s_dev.data_ptr()),
@@ -885,10 +885,10 @@ def main():
             if args.c5_proof_log_n:
                 out["create_proof_c5"] = bench_create_proof_c5(worker, args.c5_proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of this same command
-        # (tools/gpu_r3_final.sh -> profiles/r3_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
+        # (tools/r5/gpu_final.sh -> profiles/r5_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
         # read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte
         # pieces, so `traffic` carries the read-corrected (doubled FETCH_SIZE) figure and the note the raw one.
-        for name in ("r4_final_pmc_accumulate.json", "r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
+        for name in ("r5_final_pmc_accumulate.json", "r4_final_pmc_accumulate.json", "r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             except Exception:

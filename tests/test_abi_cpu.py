@@ -367,7 +367,8 @@ def test_msm_plan_invariants_host():
                     c_, W, nb, K, cpw, passes, lo, hi, pairs = (int(x) for x in out)
                     assert 2 <= c_ <= 24 and (forced == 0 or c_ == forced)
                     assert W == -(-256 // c_) and W * c_ >= 256 and nb == 1 << (c_ - 1)
-                    assert lo + hi == c_ - 1 and passes == -(-c_ // 8)
+                    # radix passes: 8 key bits each, or 10 where that is a pass less (c = 17 ... 20: [r5])
+                    assert lo + hi == c_ - 1 and passes == min(-(-c_ // 8), -(-c_ // 10)) and passes * (10 if -(-c_ // 10) < -(-c_ // 8) else 8) >= c_
                     assert K >= 1 and cpw == -(-n // K) and K >= (n >> (c_ - 1))
                     assert pairs == (W * n) & 0xFFFFFFFF
 
