@@ -188,44 +188,50 @@ MsmSums issue_unpatched_prover(Parameters &p, const CallSiteInputs &in) {
   return wait_all(jobs, p);
 }
 // ---- mode 2 ----------------------------------------------------------------------------------------------------------
-// the patched EvaluationDomain: `coeffs` on the host, its device copy while the last operation ran there
+// the patched EvaluationDomain: `coeffs` on the host, its device copy while the last operation ran there.  In Rust the
+// domain OWNS the vector it was built from (`from_coeffs(prover.a)` moves it, pads it in place) and `into_coeffs` hands the
+// same allocation back; this harness only borrows the caller's arrays, so the host vector is a view until somebody needs it
+// as a vector: the upload reads the caller's memory (the padding is zeroed on the device) and the download lands in a
+// buffer that is recycled across proofs - neither a copy nor a fresh 32 MiB of page faults that the Rust code would not have.
 struct DeviceDomain {
   bh_ctx *ctx;
-  std::vector<Fr> coeffs;
+  const Fr *src;
+  size_t n, m;
   uint32_t exp;
   void *dev = nullptr;
-  bool host_valid = true;
-  DeviceDomain(bh_ctx *c, const Fr *v, size_t n, size_t m, uint32_t e) : ctx(c), coeffs(m, Fr::zero()), exp(e) {
-    if (n) memcpy(coeffs.data(), v, n * 32);   // from_coeffs (domain.rs:47-79): padded on the host
-  }
+  DeviceDomain(bh_ctx *c, const Fr *v, size_t n_, size_t m_, uint32_t e) : ctx(c), src(v), n(n_), m(m_), exp(e) {}
   DeviceDomain(const DeviceDomain &) = delete;
   // (the Rust DeviceVec's Drop: the operations on the vector were only enqueued - wait before the block returns to the pool)
   ~DeviceDomain() { if (dev) { (void)bh_ctx_synchronize(ctx); (void)bh_dev_free(ctx, dev); } }
   void to_device() {
-    if (!dev) {
-      check(bh_dev_alloc(ctx, coeffs.size() * 32, &dev));
-      check(bh_dev_upload(ctx, dev, coeffs.data(), coeffs.size() * 32));
-    }
-    host_valid = false;
+    if (dev) return;
+    check(bh_dev_alloc(ctx, m * 32, &dev));
+    if (n < m) check(bh_dev_zero(ctx, (char *)dev + n * 32, (m - n) * 32));
+    if (n) check(bh_dev_upload(ctx, dev, src, n * 32));
   }
   void transform(int mode) { to_device(); check(bh_fft_fr_dev(ctx, dev, exp, mode, nullptr)); }
-  void mul_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_mul_assign_dev(ctx, dev, o.dev, coeffs.size(), nullptr)); }
-  void sub_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_sub_assign_dev(ctx, dev, o.dev, coeffs.size(), nullptr)); }
+  void mul_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_mul_assign_dev(ctx, dev, o.dev, m, nullptr)); }
+  void sub_assign(DeviceDomain &o) { to_device(); o.to_device(); check(bh_fr_sub_assign_dev(ctx, dev, o.dev, m, nullptr)); }
   void divide_by_z_on_coset() { to_device(); check(bh_fr_divide_by_z_on_coset_dev(ctx, dev, exp, nullptr)); }
-  std::vector<Fr> into_coeffs() {   // domain.rs:42-45: the download (bh_dev_download synchronises the context stream)
-    if (!host_valid) check(bh_dev_download(ctx, coeffs.data(), dev, coeffs.size() * 32));
-    host_valid = true;
-    return std::move(coeffs);
+  // domain.rs:42-45: the download (bh_dev_download synchronises the context stream) into the vector the domain owns
+  std::vector<Fr> &into_coeffs() {
+    static thread_local std::vector<Fr> owned;
+    to_device();
+    owned.resize(m);
+    check(bh_dev_download(ctx, owned.data(), dev, m * 32));
+    return owned;
   }
 };
-// `.map(|s| s.into())` with Exponent::Raw: zero / one are still classified (multiexp.rs:174-177), nothing is converted
+// `.map(|s| s.into()).collect()` with Exponent::Raw: zero / one are still classified (multiexp.rs:174-177), nothing is
+// converted; a fresh vector per call like the Rust `collect`
 std::vector<Fr> to_raw_exponents(const Fr *v, size_t n) {
-  std::vector<Fr> out(n);
+  std::vector<Fr> out;
+  out.reserve(n);
   const Fr one = Fr::one();
   size_t special = 0;
   for (size_t i = 0; i < n; i++) {
     special += v[i].is_zero() || v[i] == one;   // (the tag a Rust enum would store)
-    out[i] = v[i];
+    out.push_back(v[i]);
   }
   (void)special;
   return out;
@@ -257,17 +263,18 @@ MsmSums issue_unpatched_prover_resident(Parameters &p, const CallSiteInputs &in)
     c.reset();                                // :235 drop(c)
     a.divide_by_z_on_coset();                 // :236
     a.transform(BH_ICOSET_FFT);               // :237
-    std::vector<Fr> av = a.into_coeffs();
-    av.resize(m - 1);                         // :238-239
-    h_exps = to_raw_exponents(av.data(), av.size());   // :241-242
+    std::vector<Fr> &av = a.into_coeffs();
+    h_exps = to_raw_exponents(av.data(), m - 1);       // :238-242 (truncate, then the map)
   }
   auto multiexp = [&](bh_bases *bases, size_t skip, const std::vector<Fr> &exps, const uint64_t *density, int slot) {
     bh_scalars *sc = nullptr;
     for (auto &r : registered) if (r.first == exps.data()) sc = r.second.s;
     if (!sc) {
-      // gather into contiguous words on the worker's threads (a Vec<Exponent> has a tag per element), then one upload
-      std::vector<Fr> words(exps.size());
-      scope(exps.size(), [&](size_t lo, size_t hi) { memcpy(words.data() + lo, exps.data() + lo, (hi - lo) * 32); });
+      // the gather into contiguous words (a Vec<Exponent> has a tag per element; rayon's par_iter in the patch - here one
+      // plain pass, which is slower than that, not faster), then one upload
+      std::vector<Fr> words;
+      words.reserve(exps.size());
+      words.insert(words.end(), exps.begin(), exps.end());
       registered.emplace_back(exps.data(), ScalarsHandle());
       check(bh_scalars_register(ctx, words.data(), words.size(), BH_SCALARS_MONT, &registered.back().second.s));
       sc = registered.back().second.s;
