@@ -920,7 +920,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
 
   // ---- one workspace block per job, carved into its buffers (one pool round trip, one memset) ----------
   const u64 npairs = (u64)p.Wd * n;
-  const u64 ncounts = p.ncounts();
+  const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nslots = (u64)p.W * p.chunks_per_window;
   // the owner lane of a run folds at most `walk` following chunks itself; longer runs are queued for
   // msm_merge_runs_kernel (G workers per run), the longest of those for the workgroup kernel

@@ -148,47 +148,31 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ROUNDS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
 
-// RB = key bits per pass (bins = 2^RB): 8, or 10 for the window sizes where three 8-bit passes become two (c = 17 ... 20,
-// i.e. multiexps of 2^24 terms and more, whose sort is a streaming pass over gigabytes: profiles/r4_final_sizes.txt has
-// 27 of 164 ms at 2^26).  counts[(w * bins + bin) * num_tiles + tile]
-template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u64 *pairs, u32 *counts, u32 n,
                                                                 u32 shift, u32 num_tiles) {
-  constexpr u32 BINS = 1u << RB, PER = BINS / SORT_THREADS;
-  __shared__ u32 hist[BINS];
+  __shared__ u32 hist[256];
   const u32 tid = threadIdx.x, tile = blockIdx.x, w = blockIdx.y;
-#pragma unroll
-  for (u32 k = 0; k < PER; k++) hist[tid + k * SORT_THREADS] = 0;
+  hist[tid] = 0;
   __syncthreads();
   const u64 *src = pairs + (u64)w * n;
 #pragma unroll 4
   for (int r = 0; r < SORT_ROUNDS; r++) {
     u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
-    if (idx < n) atomicAdd(&hist[(u32)(src[idx] >> shift) & (BINS - 1)], 1u);
+    if (idx < n) atomicAdd(&hist[(u32)(src[idx] >> shift) & 0xff], 1u);
   }
   __syncthreads();
-#pragma unroll
-  for (u32 k = 0; k < PER; k++) {
-    const u32 bin = tid + k * SORT_THREADS;
-    counts[((u64)w * BINS + bin) * num_tiles + tile] = hist[bin];
-  }
+  counts[((u64)w * 256 + tid) * num_tiles + tile] = hist[tid];
 }
 
-template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *pairs_in, u64 *pairs_out,
                                                                    const u32 *offsets, u32 n, u32 shift,
                                                                    u32 num_tiles) {
-  constexpr u32 BINS = 1u << RB, PER = BINS / SORT_THREADS;
-  __shared__ u32 base[BINS];
-  __shared__ u32 wcnt[SORT_THREADS / 64][BINS];
+  __shared__ u32 base[256];
+  __shared__ u32 wcnt[SORT_THREADS / 64][256];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x, w = blockIdx.y;
+  base[tid] = offsets[((u64)w * 256 + tid) * num_tiles + tile];   // global position (all windows)
 #pragma unroll
-  for (u32 k = 0; k < PER; k++) {
-    const u32 bin = tid + k * SORT_THREADS;
-    base[bin] = offsets[((u64)w * BINS + bin) * num_tiles + tile];   // global position (all windows)
-#pragma unroll
-    for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][bin] = 0;
-  }
+  for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][tid] = 0;
   __syncthreads();
   const u64 *src = pairs_in + (u64)w * n;
   const u64 lt_mask = ((u64)1 << lane) - 1;
@@ -205,11 +189,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
     const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
     const bool valid = idx < n;
     const u64 key = keys[r];
-    const u32 bin = (u32)(key >> shift) & (BINS - 1);
-    // wavefront match-any over the bin: lanes with equal bins
+    const u32 bin = (u32)(key >> shift) & 0xff;
+    // wavefront match-any over the 8-bit bin: lanes with equal bins
     u64 mask = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RB; b++) {
+    for (int b = 0; b < 8; b++) {
       const u64 bal = __ballot((bin >> b) & 1);
       mask &= ((bin >> b) & 1) ? bal : ~bal;
     }
@@ -222,14 +206,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
       pairs_out[off] = key;
     }
     __syncthreads();
+    u32 tot = 0;
 #pragma unroll
-    for (u32 k = 0; k < PER; k++) {
-      const u32 b2 = tid + k * SORT_THREADS;
-      u32 tot = 0;
-#pragma unroll
-      for (int v = 0; v < SORT_THREADS / 64; v++) { tot += wcnt[v][b2]; wcnt[v][b2] = 0; }
-      base[b2] += tot;
-    }
+    for (int v = 0; v < SORT_THREADS / 64; v++) { tot += wcnt[v][tid]; wcnt[v][tid] = 0; }
+    base[tid] += tot;
     __syncthreads();
   }
 }
@@ -250,14 +230,6 @@ __global__ void window_zero_count_kernel(const u64 *pairs, u32 *zstart, u32 n, u
 }
 
 static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
-
-// |digit| <= 2^(c-1) takes c bits: ceil(c / 8) passes of 8 bits - or of 10 bits where that is a pass less (c = 17 ... 20)
-static void set_sort_passes(MsmPlan &p) {
-  static const bool wide_on = [] { const char *e = getenv("BELLMAN_HIP_SORT_10BIT"); return !(e && *e == '0'); }();
-  const u32 p8 = (p.c + 7) / 8, p10 = (p.c + 9) / 10;
-  p.sort_bits = (wide_on && p10 < p8) ? 10 : 8;
-  p.sort_passes = p.sort_bits == 10 ? p10 : p8;
-}
 
 MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   MsmPlan p;
@@ -295,7 +267,7 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   // are 6.8 M buckets to merge into; 2^24: reduce 8.4 -> 6.1 ms)
   if (!forced_chunk) p.chunk = (u32)std::max<u64>(p.chunk, (n >> (p.c - 1)) << (p.c >= 20 ? 1 : 0));
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
-  set_sort_passes(p);
+  p.sort_passes = (p.c + 7) / 8;
   p.nd = p.n; p.Wd = p.W; p.base_stride = 0;
   return p;
 }
@@ -356,7 +328,7 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_min));
   p.chunk = forced_chunk ? forced_chunk : (u32)k;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
-  set_sort_passes(p);
+  p.sort_passes = (p.c + 7) / 8;
   return p;
 }
 
@@ -364,7 +336,7 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
 int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_dev, int fmt, const u64 *density_dev,
                    u64 skip, u64 n_bases, hipStream_t st, const u64 **sorted_out) {
   const u64 n = p.nd;   // scalars (the density bitmap is indexed by scalar)
-  const u64 ncounts = p.ncounts();
+  const u64 ncounts = (u64)p.W * 256 * p.num_tiles;
   const u64 nwords = (n + 63) / 64;
   if (density_dev) {
     hipLaunchKernelGGL(density_popc_kernel, dim3((u32)((nwords + 255) / 256)), dim3(256), 0, st, density_dev,
@@ -380,18 +352,14 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
   // 2. sort by digit, 8 bits per pass
   u64 *src = b.pairs_a, *dst = b.pairs_b;
   for (u32 pass = 0; pass < p.sort_passes; pass++) {
-    const u32 shift = 32 + p.sort_bits * pass;
-    if (p.sort_bits == 10)
-      hipLaunchKernelGGL(sort_hist_kernel<10>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, b.counts, p.n, shift, p.num_tiles);
-    else
-      hipLaunchKernelGGL(sort_hist_kernel<8>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, b.counts, p.n, shift, p.num_tiles);
+    const u32 shift = 32 + 8 * pass;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, b.counts, p.n,
+                       shift, p.num_tiles);
     BH_HIP_CHECK(hipGetLastError());
     int rc = exclusive_scan_u32(b.counts, ncounts, b.scan_tmp, st);
     if (rc) return rc;
-    if (p.sort_bits == 10)
-      hipLaunchKernelGGL(sort_scatter_kernel<10>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts, p.n, shift, p.num_tiles);
-    else
-      hipLaunchKernelGGL(sort_scatter_kernel<8>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts, p.n, shift, p.num_tiles);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
+                       p.n, shift, p.num_tiles);
     BH_HIP_CHECK(hipGetLastError());
     std::swap(src, dst);
   }

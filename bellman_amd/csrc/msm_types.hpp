@@ -47,8 +47,6 @@ struct MsmOpts {
 
 struct MsmPlan {
   u32 n, c, W, nb, NB, lo_bits, hi_bits, num_tiles, sort_passes;
-  u32 sort_bits = 8;   // key bits per radix pass: 8, or 10 where that saves a pass (c = 17 ... 20: two passes instead of three)
-  u64 ncounts() const { return ((u64)W << sort_bits) * num_tiles; }   // histogram entries of one pass
   u32 chunk;             // K: sorted entries per accumulation lane
   u32 chunks_per_window; // ceil(n / K)
   // digit stage: nd scalars x Wd digits.  Classic plan: nd == n, Wd == W, base_stride == 0.

@@ -29,7 +29,7 @@ static int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt,
                     u32 *zstart_out) {
   const MsmPlan p = make_plan(n, cbits, 0, false);
   hipStream_t st = c.stream;
-  const u64 npairs = (u64)p.W * n, ncounts = p.ncounts();
+  const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
   MsmBuffers b;
   std::vector<void *> owned;
   auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); owned.push_back(q); return q; };
