@@ -308,9 +308,10 @@ def test_h_poly_pipeline(worker, n_evals):
 
 
 # ------------------------------------------------------------------------------ MSM stages
-@pytest.mark.parametrize("n,c", [(1, 4), (100, 4), (5000, 7), (70000, 11), (1 << 17, 16)])
+@pytest.mark.parametrize("n,c", [(1, 4), (100, 4), (5000, 7), (70000, 11), (1 << 17, 16), (4097, 17), (50000, 19), (1 << 17, 20), (9000, 21)])
 def test_msm_sort_stages(worker, n, c):
-    """signed digits + stable radix sort + zero-digit count against numpy."""
+    """signed digits + stable radix sort + zero-digit count against numpy ([r5]: also the window sizes that take three
+    passes, c = 17 ... 21 - written for the 10-bit passes of round 5, which sorted correctly and slower)."""
     from bellman_amd import _lib
 
     lib = _lib.load()
