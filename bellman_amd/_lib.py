@@ -40,7 +40,7 @@ EXPORTS = [
 TEST_EXPORTS = [
     "bh_groth16_prove_demo", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs", "bh_groth16_prove_demo_async", "bh_groth16_prove_demo_r1cs_part",
     "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev", "bh_test_msm_stages",
-    "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host", "bh_test_fr_ops_host", "bh_test_glv_decompose_host",
+    "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host", "bh_test_fr_ops_host",
     "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
 

@@ -8,7 +8,6 @@
 
 #include "../../include/bellman_hip.h"
 #include "common.hpp"
-#include "glv.cuh"
 #include "msm_types.hpp"
 #include "shard_cuts.hpp"
 
@@ -162,9 +161,6 @@ struct bh_bases {
   // Infinity Cache either way), -3 % at 2^22 (it does not).  Dense `dev` stays what every other path and the API see.
   // BELLMAN_HIP_BASE_PAD=0 switches it off; vectors whose copy would exceed 1/16 of the device memory are not padded.
   void *padded = nullptr;
-  // [r5] ... followed by a second half of n records phi(P_i) = (beta x_i, y_i), the images under G1's endomorphism
-  // (glv.cuh): base phi_off + k of a GLV-form job.  `glv` says the half exists (2 n records in `padded`).
-  bool glv = false;
   // [r4] ... and the window table of a G1 vector too large for the Infinity Cache (>= 2^19 points: 16 rows of 2^19
   // records are 0.8 GB) is KEPT at that stride only: `table` then holds W * n records of 128 bytes, read by the bucket
   // accumulation alone (MsmOpts::padded_table); everything else of such a job reads the dense `dev`.
@@ -246,22 +242,6 @@ static size_t table_bytes_for(const bh_bases *b, unsigned c) {
   const u32 W = (256 + c - 1) / c;
   return (size_t)W * b->n * (b->group == BH_G1 ? (table_will_pad(b) ? 128 : 96) : 192);
 }
-// records [n, 2 n) of a G1 vector's 128-byte-stride copy: phi(P_i) = (beta x_i, y_i) (glv.cuh; the identity - an all-zero
-// record - maps to itself)
-__global__ void glv_phi_kernel(char *padded, u64 n) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32 *src = reinterpret_cast<const u32 *>(padded + i * 128);
-  u32 *dst = reinterpret_cast<u32 *>(padded + (n + i) * 128);
-  fp_t x, beta, bx;
-#pragma unroll
-  for (int k = 0; k < 12; k++) { x.l[k] = src[k]; beta.l[k] = glv::beta_mont(k); }
-  fe_mul(bx, x, beta);   // canonical
-#pragma unroll
-  for (int k = 0; k < 12; k++) { dst[k] = bx.l[k]; dst[12 + k] = src[12 + k]; }
-#pragma unroll
-  for (int k = 24; k < 32; k++) dst[k] = 0;
-}
 static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh_bases **out) {
   bh_bases *b = new bh_bases{group, dev, n, owned};
   b->ctx = ctx;
@@ -284,20 +264,11 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
   const bool table_size = lg_table && n > TINY_MSM_MAX && n <= (size_t(1) << lg_table);   // (takes a window table instead)
   if (pad_on && group == BH_G1 && !table_size && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
       (ctx->c.hbm_total == 0 || n * 128 <= ctx->c.hbm_total / 16)) {
-    // (with the endomorphism images behind it where 2 n records still fit the same bound: BELLMAN_HIP_GLV=0 leaves them out)
-    static const bool glv_on = [] { const char *e = getenv("BELLMAN_HIP_GLV"); return !(e && *e == '0'); }();
-    const bool with_phi = glv_on && n < ((size_t)1 << 30) && (ctx->c.hbm_total == 0 || n * 256 <= ctx->c.hbm_total / 16);
-    if (hipMalloc(&b->padded, n * (with_phi ? 256 : 128)) == hipSuccess) {
-      bool ok = hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) == hipSuccess;
-      if (ok && with_phi) {
-        hipLaunchKernelGGL(glv_phi_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->c.stream, (char *)b->padded, (u64)n);
-        ok = hipGetLastError() == hipSuccess;
-      }
-      if (!ok || hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+    if (hipMalloc(&b->padded, n * 128) == hipSuccess) {
+      if (hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
         (void)hipFree(b->padded);
         b->padded = nullptr;
-      } else {
-        b->glv = with_phi;
       }
     } else {
       (void)hipGetLastError();
@@ -1060,7 +1031,6 @@ static int msm_common(bh_ctx *ctx, const bh_bases *bases, size_t skip, const voi
     ptab = tab_ptr && bases->table_padded;
     tab_info = bases->tab;
     opts.padded_bases = bases->padded;   // (read by the classic plan only)
-    opts.glv_phi_off = (bases->padded && bases->glv) ? bases->n : 0;
   }
   opts.padded_table = ptab ? tab_ptr : nullptr;
   MsmJobImpl *impl = msm_job_new(&ctx->c, bases->group);

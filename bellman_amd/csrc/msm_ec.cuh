@@ -910,17 +910,10 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const bool use_table = table && !(opts.flags & BH_MSM_NO_TABLE) && (opts.c == 0 || opts.c == table->c) &&
                          (u64)table->W * table->stride < ((u64)1 << 31) && (u64)table->W * n < ((u64)1 << 32);
   if (opts.padded_table && G2) return BH_ERR_INVALID_ARG;   // only G1 tables are laid out at a 128-byte stride
+  const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, G2, c.num_cus)
+                              : make_plan(n, opts.c, opts.chunk, G2);
   // running bucket sum in LDS: only meaningful for the single-lane G2 kernel (its default), or when forced
   const bool lds_acc = F::LANES == 1 && ((opts.flags & BH_MSM_ACC_LDS) ? true : (opts.flags & BH_MSM_ACC_REGISTERS) ? false : G2);
-  // [r5] GLV form of the classic G1 plan (glv.cuh): needs the padded copy with its phi half (built at registration for the
-  // vectors that run this plan), the default window size, and index room for 2 n entries / 2 n_bases records
-  static const bool glv_on = [] { const char *e = getenv("BELLMAN_HIP_GLV"); return !(e && *e == '0'); }();
-  const bool use_glv = glv_on && !use_table && !G2 && F::LANES == 1 && !lds_acc && opts.padded_bases && opts.glv_phi_off &&
-                       opts.glv_phi_off == n_bases && opts.c == 0 && !(opts.flags & BH_MSM_NO_GLV) && n >= ((u64)1 << 17) &&
-                       2 * n < ((u64)1 << 32) && 2 * n_bases < ((u64)1 << 31);
-  const MsmPlan p = use_table ? make_table_plan(n, *table, opts.chunk, G2, c.num_cus)
-                    : use_glv ? make_glv_plan(n, opts.glv_phi_off, opts.chunk)
-                              : make_plan(n, opts.c, opts.chunk, G2);
   job.plan = p;
   if ((u64)p.Wd * n >= ((u64)1 << 32)) return BH_ERR_INVALID_ARG;  // pair positions are 32-bit
   if (n_bases >= ((u64)1 << 31)) return BH_ERR_INVALID_ARG;        // base index shares its word with the sign bit

@@ -29,7 +29,6 @@
 #include <algorithm>
 #include <cmath>
 
-#include "glv.cuh"
 #include "msm_scalar.cuh"
 #include "msm_types.hpp"
 
@@ -139,53 +138,6 @@ __global__ void msm_digits_kernel(const void *scalars, int fmt, u32 n, const u64
     if (v > half) { v = (1u << c) - v; neg = (v != 0); carry = 1; }
     // with a window table digit w of base k adds row w of the table: 2^(c*w) P_k
     pairs[(u64)w * n + i] = ((u64)v << 32) | ((u64)neg << 31) | ((u32)(k + w * base_stride) & 0x7fffffffu);
-  }
-}
-
-// [r5] GLV form (glv.cuh): s = k1 + k2 lambda with signed 127-bit halves; each half is recoded into eight signed 16-bit
-// digits (its top digit is below 2^15, so no carry leaves window 7) and a negative half flips the sign of its digits.
-// Window w holds 2 n entries: entry 2 i + h is half h of scalar i, its base the point itself (h = 0) or its image under
-// the endomorphism, record phi_off + k of the padded copy (h = 1).
-__global__ void msm_digits_glv_kernel(const void *scalars, int fmt, u32 n, const u64 *density, const u32 *word_prefix, u64 skip,
-                                      u64 n_bases, u64 phi_off, u64 *pairs, ErrFlags *err) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool dense = true;
-  u64 k = skip + i;
-  if (density) {
-    const u64 word = density[i >> 6];
-    dense = (word >> (i & 63)) & 1;
-    k = skip + word_prefix[i >> 6] + __popcll(word & (((u64)1 << (i & 63)) - 1));
-  }
-  bool live = dense;
-  if (dense && k >= n_bases) {   // every dense entry checks EOF first, whatever its scalar
-    atomicOr(&err->eof, 1u);
-    live = false;
-  }
-  GlvHalf half[2];
-  half[0].lo = half[0].hi = half[1].lo = half[1].hi = 0;
-  half[0].neg = half[1].neg = false;
-  if (live) {
-    fr_t s;
-    load_scalar(scalars, i, fmt, s);
-    glv_decompose(s, half[0], half[1]);
-  }
-  const u64 n2 = (u64)n * 2;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    u32 carry = 0;
-    const u64 base = (u64)((u32)(k + (h ? phi_off : 0)) & 0x7fffffffu);
-#pragma unroll
-    for (u32 w = 0; w < 8; w++) {
-      const u64 limb = w < 4 ? half[h].lo : half[h].hi;
-      u32 v = (u32)((limb >> (16 * (w & 3))) & 0xffffu) + carry;
-      u32 neg = 0;
-      carry = 0;
-      if (v > 0x8000u) { v = 0x10000u - v; neg = 1; carry = 1; }
-      if (half[h].neg) neg ^= 1u;
-      if (v == 0) neg = 0;
-      pairs[(u64)w * n2 + 2 * (u64)i + h] = ((u64)v << 32) | ((u64)neg << 31) | base;
-    }
   }
 }
 
@@ -309,7 +261,10 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   // per lane shrinks instead of leaving SIMDs idle (same sweep)
   p.chunk = forced_chunk ? forced_chunk
                          : g2 ? (lg <= 11 ? 8 : lg <= 15 ? 16 : lg <= 17 ? 32 : 64)   // G2: fewer, costlier partials
-                              : (lg <= 11 ? 8 : lg <= 17 ? 16 : 32);
+                              : (lg <= 11 ? 8 : lg <= 17 ? 16 : lg <= 19 ? 32 : 64);   // [r5] 2^20: 64 (below)
+  // [r5] G1 at 2^20 terms: K = 64 instead of 32 - 2^18 chunks instead of 2^19, i.e. half the head / tail partials the merge
+  // launch folds (merge + reduce 0.86 -> 0.69 ms) for the same accumulation (2.51 vs 2.56 ms): 3.72 -> 3.62 ms of device time,
+  // same process, alternating (profiles/r5_call4_glv_and_chunk_ab.txt); the launch is exactly two wavefronts per SIMD
   // never let a typical bucket span many chunks: the chunk merge is serial per bucket
   // (c = 20: twice the average run - every chunk partial is a 192-byte record written, read and merged, and there
   // are 6.8 M buckets to merge into; 2^24: reduce 8.4 -> 6.1 ms)
@@ -317,30 +272,6 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;
   p.nd = p.n; p.Wd = p.W; p.base_stride = 0;
-  return p;
-}
-
-// [r5] The GLV form of the classic G1 plan: c = 16 over 127-bit halves = 8 windows of 2 n entries - the same number of sorted
-// entries and bucket additions as 16 windows of n, half the bucket sets to reduce and half the host tail.
-MsmPlan make_glv_plan(u64 n, u64 phi_off, unsigned forced_chunk) {
-  MsmPlan p;
-  p.c = 16;
-  p.W = 8;
-  p.nd = (u32)n;
-  p.Wd = 16;                         // digit columns per scalar (8 windows x 2 halves): sizes the pair buffers
-  p.n = (u32)(2 * n);                // entries per window
-  p.nb = 1u << (p.c - 1);
-  p.NB = p.W * p.nb;
-  p.lo_bits = (p.c - 1) / 2;
-  p.hi_bits = (p.c - 1) - p.lo_bits;
-  p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
-  // K as in make_plan: at least the average run (2 n / 2^15 entries per bucket), so that a typical run touches two chunks
-  p.chunk = forced_chunk ? forced_chunk : (u32)std::max<u64>(32, (u64)p.n >> (p.c - 1));
-  p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
-  p.sort_passes = (p.c + 7) / 8;
-  p.base_stride = 0;
-  p.glv = true;
-  p.phi_off = phi_off;
   return p;
 }
 
@@ -418,10 +349,6 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
     if (rc) return rc;
   }
   // 1. digits
-  if (p.glv)
-    hipLaunchKernelGGL(msm_digits_glv_kernel, dim3((p.nd + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.nd, density_dev,
-                       b.word_prefix, skip, n_bases, p.phi_off, b.pairs_a, b.err);
-  else
   hipLaunchKernelGGL(msm_digits_kernel, dim3((p.nd + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.nd,
                      density_dev, b.word_prefix, skip, n_bases, p.c, p.Wd, p.base_stride, b.pairs_a, b.err);
   BH_HIP_CHECK(hipGetLastError());

@@ -43,9 +43,6 @@ struct MsmOpts {
   // a G1 window table whose records sit at a 128-byte stride (api.hip bh_bases::table_padded): only the bucket
   // accumulation of the table plan reads it; `bases_dev` of such a job is the dense base vector itself
   const void *padded_table = nullptr;
-  // [r5] the 128-byte-stride copy has a second half phi(P_i) = (beta x_i, y_i) at records [phi_off, 2 phi_off): the
-  // classic G1 plan then runs its GLV form (glv.cuh; api.hip bh_bases::glv)
-  u64 glv_phi_off = 0;
 };
 
 struct MsmPlan {
@@ -58,11 +55,6 @@ struct MsmPlan {
   // and a pair's base field addresses table row j: j*base_stride + base index.
   u32 nd, Wd;
   u64 base_stride;
-  // [r5] GLV form of the classic G1 plan (glv.cuh): every scalar is two signed 127-bit halves k1, k2 (s = k1 + k2 lambda), the
-  // digit stage writes 2 entries per scalar and window - base k for k1's digit, base phi_off + k for k2's - so the later
-  // stages see W = 8 windows of n = 2 nd entries (Wd = 16 digit columns per scalar in all)
-  bool glv = false;
-  u64 phi_off = 0;
 };
 // multiples 2^(c*j) P_i, j < W, stored row-major [j][i] (row 0 = the bases themselves)
 struct WindowTable {
@@ -120,7 +112,6 @@ struct MsmBuffers {
 };
 MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2);
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus);
-MsmPlan make_glv_plan(u64 n, u64 phi_off, unsigned forced_chunk);
 unsigned table_window_bits(u64 n_bases, bool g2);   // the c a window table is built for by default
 size_t scan_tmp_elems(u64 n);
 // runs stages 1-2 (+ per-window first non-zero position) on `st`; *sorted_out = sorted pairs

@@ -4,7 +4,6 @@
 #include <string.h>
 
 #include "../../include/bellman_hip_test.h"
-#include "glv.cuh"
 #include "msm_ec.cuh"
 #include "shard_cuts.hpp"
 
@@ -172,15 +171,6 @@ void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n) 
 }
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
-}
-void bh_test_glv_decompose_host(const void *scalars, size_t n, uint64_t *mags4, unsigned char *negs2) {
-  const fr_t *s = (const fr_t *)scalars;
-  for (size_t i = 0; i < n; i++) {
-    GlvHalf k1, k2;
-    glv_decompose(s[i], k1, k2);
-    mags4[4 * i] = k1.lo; mags4[4 * i + 1] = k1.hi; mags4[4 * i + 2] = k2.lo; mags4[4 * i + 3] = k2.hi;
-    negs2[2 * i] = k1.neg; negs2[2 * i + 1] = k2.neg;
-  }
 }
 int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9) {
   // host only: the plan make_plan picks - out9 = c, W, buckets per window, K, chunks per window, sort passes,

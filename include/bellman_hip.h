@@ -260,8 +260,6 @@ typedef struct {
 #define BH_MSM_G2_SINGLE_LANE 16u /* G2: force the one-lane-per-point kernels (default: merge + reduction above 2^17 buckets) */
 #define BH_MSM_G2_LANE_TRIPLES 32u /* G2: force the lane-triple (Karatsuba) kernels (default below 2^15 terms) */
 #define BH_MSM_G2_LANE_PAIRS 256u /* G2: force the lane-pair kernel for the bucket accumulation (default from 2^15 terms) */
-#define BH_MSM_NO_GLV 512u /* G1: the classic 16-window plan even where the vector carries its endomorphism images (default: the
-                              GLV form - 8 windows over scalar halves - for registered vectors of more than 2^18 points) */
 int bh_msm_async_opts(bh_ctx *ctx, const bh_bases *bases, size_t skip, const void *scalars_host,
                       size_t n_scalars, int scalar_fmt, const uint64_t *density_words,
                       size_t density_len, const bh_msm_opts *opts, bh_msm_job **job);

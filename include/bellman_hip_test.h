@@ -95,9 +95,6 @@ void bh_test_fr_ops_host(int op, void *r, const void *a, const void *b, size_t n
 int bh_test_shard_cuts(const size_t *lens, size_t n_shards, size_t skip, const uint64_t *density_words, size_t n_scalars,
                        size_t *cuts_out);
 size_t bh_test_pool_size_class(size_t bytes);
-/* host only: the GLV decomposition the G1 multiexp's digit stage applies (csrc/glv.cuh): n canonical scalars (32 bytes each,
- * < r) -> per scalar mags4 = |k1| (2 x u64), |k2| (2 x u64) and negs2 = (k1 < 0, k2 < 0) with s = k1 + k2 lambda mod r */
-void bh_test_glv_decompose_host(const void *scalars, size_t n, uint64_t *mags4, unsigned char *negs2);
 /* create_proof's h block + eight multiexps issued as the reference's call sites would issue them through the Rust shim
  * (shim/patches/bellman-hip.patch), transcribed in C++ (csrc/groth16_callsites.cpp):
  *   mode 1  groth16/src/prover.rs patched: bh_scalars_register x2, bh_msm_async_scalars x8, bh_h_poly_fr_scalars

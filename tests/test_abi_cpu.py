@@ -444,48 +444,3 @@ def test_montgomery_reduction_whole_columns_with_maximal_limbs(lib):
         want = a * b * pow(Rq, -1, q) % q
         assert val(r) == want and val(r2) == want, (hex(a), hex(b))
 
-
-def test_glv_decomposition_host():
-    """[r5] csrc/glv.cuh (the G1 multiexp's digit stage): s = k1 + k2 * lambda (mod r) with |k1|, |k2| < 2^127 and the top
-    16-bit digit of either magnitude below 2^15 - against Python integers, on random scalars and on the values where the
-    quotient estimate, the two corrections and the two balancing steps switch (0, 1, r - 1, multiples of lambda and of
-    lambda / 2 and their neighbours).  phi(P) = (beta x, y) = [lambda] P for the same lambda: checked here on the generator
-    with the affine formulas of oracle/pyref (integers only)."""
-    import ctypes
-    import random
-
-    import numpy as np
-
-    from bellman_amd import _lib
-    from oracle.pyref import bls12_381 as bls
-
-    lib = _lib.load()
-    q = bls.Q
-    lam = 0xac45a4010001a40200000000ffffffff
-    assert lam * lam + lam + 1 == q
-    beta = 0x1a0111ea397fe699ec02408663d4de85aa0d857d89759ad4897d29650fb85f9b409427eb4f49fffd8bfd00000000aaac
-    assert pow(beta, 3, bls.P) == 1 and beta != 1
-    g = bls.G1.gen
-    assert bls.G1.mul(g, lam) == (beta * g[0] % bls.P, g[1])
-    rnd = random.Random(2718)
-    half, half_b = lam >> 1, (lam + 1) >> 1
-    edge = [0, 1, 2, q - 1, q - 2, lam, lam - 1, lam + 1, 2 * lam, lam * lam, lam * (lam + 1), half, half + 1, half * lam,
-            half_b * lam, (half_b + 1) * lam, (half_b + 1) * lam + half + 1, half_b * lam + half, (1 << 255) % q, (1 << 128) - 1]
-    vals = [v % q for v in edge] + [rnd.randrange(q) for _ in range(20000)] + [rnd.randrange(1 << k) for k in range(1, 255, 3)]
-    arr = np.zeros((len(vals), 4), dtype=np.uint64)
-    for i, v in enumerate(vals):
-        arr[i] = [(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
-    mags = np.zeros((len(vals), 4), dtype=np.uint64)
-    negs = np.zeros((len(vals), 2), dtype=np.uint8)
-    lib.bh_test_glv_decompose_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
-    lib.bh_test_glv_decompose_host.restype = None
-    lib.bh_test_glv_decompose_host(arr.ctypes.data_as(ctypes.c_void_p), len(vals), mags.ctypes.data_as(ctypes.c_void_p),
-                                   negs.ctypes.data_as(ctypes.c_void_p))
-    for i, v in enumerate(vals):
-        m1 = int(mags[i, 0]) | (int(mags[i, 1]) << 64)
-        m2 = int(mags[i, 2]) | (int(mags[i, 3]) << 64)
-        k1 = -m1 if negs[i, 0] else m1
-        k2 = -m2 if negs[i, 1] else m2
-        assert (k1 + k2 * lam - v) % q == 0, hex(v)
-        assert m1 < (1 << 127) and m2 < (1 << 127) and (m1 >> 112) < (1 << 15) and (m2 >> 112) < (1 << 15), hex(v)
-        assert not (negs[i, 0] and m1 == 0) and not (negs[i, 1] and m2 == 0)
