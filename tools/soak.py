@@ -43,7 +43,43 @@ def main():
     print("free MiB over time:", marks, "elapsed %.1fs" % (time.time() - t0))
     assert marks[-1] >= marks[1] - 64, "device memory keeps shrinking"
     print("soak ok (multiexp / fft)")
+    soak_fft_cache(w)
     soak_proofs(w)
+
+
+def soak_fft_cache(w):
+    """[r5] the FFT table cache under pressure and from four host threads at once: a 96 MiB budget (the one-level set of
+    2^19 points is 64 MiB, of 2^20 points 128 MiB: two-level), random sizes 2^12 ... 2^21 - every table request may have to
+    evict another size's tables while other threads are between their table lookup and their launches (fft.hip fft_evict:
+    exclusive lock + device synchronise).  Every transform is checked by its round trip; the cache never exceeds its budget."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    budget = 96 << 20
+    w.set_limits(fft_table_budget_bytes=budget)
+    w.trim() if hasattr(w, "trim") else None
+    t0 = time.time()
+    peak = [0]
+
+    def worker_thread(tid):
+        rnd = np.random.default_rng(900 + tid)
+        for it in range(40):
+            lg = int(rnd.integers(12, 22))
+            data = splitmix_scalars(1 << lg, 1000 * tid + it)
+            d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
+            if it & 1:
+                d.coset_fft(); d.icoset_fft()
+            else:
+                d.fft(); d.ifft()
+            assert np.array_equal(d.into_coeffs(), data), (tid, it, lg)
+            peak[0] = max(peak[0], w.info()["fft_table_bytes"])
+        return tid
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        assert sorted(ex.map(worker_thread, range(4))) == [0, 1, 2, 3]
+    assert peak[0] <= budget, (peak[0], budget)
+    print("soak ok (fft table cache: 160 transforms from 4 threads under a %d MiB budget, peak %d MiB, %.1fs)" %
+          (budget >> 20, peak[0] >> 20, time.time() - t0))
+    w.set_limits(fft_table_budget_bytes=w.info()["hbm_bytes"] // 8)
 
 
 def soak_proofs(w):
