@@ -415,14 +415,14 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
 // Queued runs: tail[l0] + sum of head[l0+1 .. l1] by G workers per run (G a power of two chosen by the host,
 // PW / G runs per wavefront): every worker folds every G-th partial, then a shuffle tree.  The medium case this is
 // for: the top window of the 13-bit plans and the buckets of window-table plans, a few times fuller than a
-// chunk (8-16 chunks).  Runs longer than BIG_RUN_CHUNKS are passed on to the workgroup kernel below - boolean-
-// heavy witnesses put half the scalars of window 0 into ONE bucket.
-constexpr u32 BIG_RUN_CHUNKS = 128;
+// chunk (8-16 chunks).  Runs of more than `big_chunks` chunks (more than four serial additions per worker here) are
+// passed on to msm_merge_long_kernel, cut into pieces of `piece` partials - boolean-heavy witnesses put a quarter of the
+// scalars of window 0 into ONE bucket.
 template <class F>
 __global__ __launch_bounds__(64, merge_waves_per_simd<F>()) void msm_merge_runs_kernel(XYZZ<typename F::Mem> *pts, const XYZZ<typename F::Mem> *head,
                                                             const XYZZ<typename F::Mem> *tail, u32 c, u32 chunks_per_window,
-                                                            const LongRun *runs, u32 max_runs, LongRun *big_runs,
-                                                            u32 max_big, ErrFlags *err, u32 G) {
+                                                            const LongRun *runs, u32 max_runs, BigRun *big_runs,
+                                                            u32 max_big, ErrFlags *err, u32 G, u32 big_chunks, u32 piece) {
   constexpr u32 PW = tree_per_wave<F>();
   u32 nruns = err->nlong;
   if (nruns > max_runs) nruns = max_runs;
@@ -434,10 +434,12 @@ __global__ __launch_bounds__(64, merge_waves_per_simd<F>()) void msm_merge_runs_
     bool valid = live && e < nruns;
     LongRun lr = {0, 0, 0, 0};
     if (valid) lr = runs[e];
-    if (valid && lr.last - lr.lane > BIG_RUN_CHUNKS) {
+    if (valid && lr.last - lr.lane > big_chunks) {
       if (k == 0 && worker_role<F>() == 0) {
         const u32 slot = atomicAdd(&err->nbig, 1u);
-        if (slot < max_big) big_runs[slot] = lr;
+        const u32 np = (lr.last - lr.lane + piece) / piece;   // ceil(partials / piece), partials = last - lane + 1
+        const u32 p0 = atomicAdd(&err->npieces, np);
+        if (slot < max_big) { BigRun br = {lr.w, lr.lane, lr.d, lr.last, p0, np, 0u, 0u}; big_runs[slot] = br; }
       }
       valid = false;
     }
@@ -455,48 +457,6 @@ __global__ __launch_bounds__(64, merge_waves_per_simd<F>()) void msm_merge_runs_
     }
     group_reduce_points<F>(acc, G, k);
     if (valid && k == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
-  }
-}
-
-// One 512-thread workgroup per very long run.
-constexpr u32 LONG_THREADS = 512;
-template <class F>
-__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typename F::Mem> *pts,
-                                                                      const XYZZ<typename F::Mem> *head,
-                                                                      const XYZZ<typename F::Mem> *tail, u32 c,
-                                                                      u32 chunks_per_window, const LongRun *runs,
-                                                                      u32 max_runs, const ErrFlags *err) {
-  constexpr u32 PW = tree_per_wave<F>(), NWAVES = LONG_THREADS / 64, NWORK = workers_per_block<F>(LONG_THREADS, PW);
-  __shared__ XYZZ<F> wave_part[NWAVES][F::LANES];
-  u32 nruns = err->nbig;
-  if (nruns > max_runs) nruns = max_runs;
-  u32 wid, gid;
-  const bool live = worker_index<F>(PW, wid, gid);   // idle lanes stay for the barriers
-  const u32 wave = threadIdx.x >> 6, t_in_wave = wid - wave * PW;
-  const u32 role = worker_role<F>();
-  for (u32 e = blockIdx.x; e < nruns; e += gridDim.x) {
-    const LongRun lr = runs[e];
-    const u64 slot0 = (u64)lr.w * chunks_per_window;
-    XYZZ<F> acc;
-    xyzz_set_identity(acc);
-    if (live) {
-      if (wid == 0) load_xyzz<F>(acc, tail + slot0 + lr.lane);
-      for (u32 j = lr.lane + 1 + wid; j <= lr.last; j += NWORK) {
-        XYZZ<F> o, r;
-        load_xyzz<F>(o, head + slot0 + j);
-        xyzz_add(r, acc, o);
-        acc = r;
-      }
-      group_reduce_points<F>(acc, PW, t_in_wave);
-      if (t_in_wave == 0) wave_part[wave][role] = acc;
-    }
-    __syncthreads();
-    if (wave == 0 && live) {
-      if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else xyzz_set_identity(acc);
-      group_reduce_points<F>(acc, NWAVES, t_in_wave);
-      if (t_in_wave == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
-    }
-    __syncthreads();
   }
 }
 
@@ -741,6 +701,127 @@ __global__ __launch_bounds__(64) void msm_sum_k2_kernel(SumJobs<FK> jobs) {
   if (sub == 0 && g < d.groups) k2_store(&out[g], acc);
 }
 
+// ============================================================================================
+// 4''. very long bucket runs: workgroup-sized pieces, the last workgroup to finish folds the piece results
+// ============================================================================================
+// What a run of L partials costs is the DEPTH of its addition tree times the latency of a point addition (~19 us on a
+// wavefront that has its SIMD to itself, ~10 us on lane pairs), not the number of additions: round 5 gave every such run
+// ONE workgroup of 512 workers - ceil(L / 512) serial additions + 9 tree levels at two wavefronts per SIMD (37 us a level):
+// 0.59 ms for the 5 461 partials of bucket 1 of a 50 %-boolean 2^20-term multiexp, 7.5 ms for an all-ones vector over a
+// window table, 4.2 ms for a 90 %-boolean G2 query of 2^19 points (profiles/r6_call2_boolean_kernels.txt).  Now a run is cut
+// into pieces of 2 x (workers of a 256-thread workgroup) partials - one serial addition, then the tree, four wavefronts on
+// four SIMDs - spread over the chip, and the workgroup that finishes a run's last piece (a counter in the run's record)
+// folds the piece results the same way: depth ~ log2 L + 2.
+// A worker is a lane / lane triple of bundle F holding an XYZZ point, or - G1 - a lane PAIR holding half a point (K2 above).
+template <class F>
+struct XyzzWorker {
+  typedef XYZZ<F> Pt;
+  typedef typename F::Mem Mem;
+  static constexpr u32 PER_WAVE = tree_per_wave<F>(), LANES = F::LANES;
+  __device__ __forceinline__ static bool index(u32 &in_block) { u32 g; return worker_index<F>(PER_WAVE, in_block, g); }
+  __device__ __forceinline__ static u32 role() { return worker_role<F>(); }
+  __device__ __forceinline__ static void identity(Pt &p) { xyzz_set_identity(p); }
+  __device__ __forceinline__ static void load(Pt &p, const XYZZ<Mem> *m) { load_xyzz<F>(p, m); }
+  __device__ __forceinline__ static void store(XYZZ<Mem> *m, const Pt &p) { store_xyzz<F>(m, p); }
+  __device__ __forceinline__ static void add(Pt &acc, const Pt &o) { Pt r; xyzz_add(r, acc, o); acc = r; }
+  __device__ __forceinline__ static void tree(Pt &acc, u32 G, u32 sub) { group_reduce_points<F>(acc, G, sub); }
+};
+struct K2Worker {
+  typedef HalfPt Pt;
+  typedef FpOps Mem;
+  static constexpr u32 PER_WAVE = 32, LANES = 2;
+  __device__ __forceinline__ static bool index(u32 &in_block) { in_block = threadIdx.x >> 1; return true; }
+  __device__ __forceinline__ static u32 role() { return k2_role(); }
+  __device__ __forceinline__ static void identity(Pt &p) { k2_set_identity(p); }
+  __device__ __forceinline__ static void load(Pt &p, const XYZZ<FpOps> *m) { k2_load(p, m); }
+  __device__ __forceinline__ static void store(XYZZ<FpOps> *m, const Pt &p) { k2_store(m, p); }
+  __device__ __forceinline__ static void add(Pt &acc, const Pt &o) { k2_add(acc, acc, o); }
+  __device__ __forceinline__ static void tree(Pt &acc, u32 G, u32 sub) { k2_group_reduce(acc, G, sub); }
+};
+constexpr u32 LONG_THREADS = 256;
+template <class WK>
+constexpr u32 long_workers() { return (LONG_THREADS / 64) * WK::PER_WAVE; }
+template <class WK>
+constexpr u32 long_piece() { return 2 * long_workers<WK>(); }   // partials per piece
+// sum over the workgroup's workers -> worker 0 (every thread of the workgroup calls it)
+template <class WK>
+__device__ __forceinline__ void long_block_sum(typename WK::Pt &acc, bool live, u32 wid, typename WK::Pt (*wave_part)[WK::LANES]) {
+  constexpr u32 PW = WK::PER_WAVE, NWAVES = LONG_THREADS / 64;
+  const u32 wave = threadIdx.x >> 6, t_in_wave = wid - wave * PW, role = WK::role();
+  if (live) {
+    WK::tree(acc, PW, t_in_wave);
+    if (t_in_wave == 0) wave_part[wave][role] = acc;
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+    if (t_in_wave < NWAVES) acc = wave_part[t_in_wave][role]; else WK::identity(acc);
+    WK::tree(acc, NWAVES, t_in_wave);
+  }
+  __syncthreads();
+}
+template <class WK>
+__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typename WK::Mem> *pts,
+                                                                      const XYZZ<typename WK::Mem> *head,
+                                                                      const XYZZ<typename WK::Mem> *tail, u32 c,
+                                                                      u32 chunks_per_window, BigRun *runs, u32 max_runs,
+                                                                      XYZZ<typename WK::Mem> *piece_out, u32 max_pieces,
+                                                                      const ErrFlags *err) {
+  typedef typename WK::Pt Pt;
+  constexpr u32 NWORK = long_workers<WK>(), PIECE = long_piece<WK>();
+  __shared__ Pt wave_part[LONG_THREADS / 64][WK::LANES];
+  __shared__ u32 sh_run, sh_last;
+  u32 nruns = err->nbig, total = err->npieces;
+  if (nruns > max_runs) nruns = max_runs;   // (cannot happen: max_big / max_pieces are upper bounds, msm_enqueue)
+  if (total > max_pieces) total = max_pieces;
+  u32 wid;
+  const bool live = WK::index(wid);   // idle lanes stay for the barriers
+  for (u32 piece = blockIdx.x; piece < total; piece += gridDim.x) {
+    if (threadIdx.x == 0) sh_run = 0xffffffffu;
+    __syncthreads();
+    for (u32 e = threadIdx.x; e < nruns; e += LONG_THREADS)
+      if (piece - runs[e].piece0 < runs[e].npieces) sh_run = e;   // exactly one run owns the piece
+    __syncthreads();
+    const u32 e = sh_run;
+    if (e == 0xffffffffu) continue;   // (uniform over the workgroup)
+    const u32 rw = runs[e].w, rlane = runs[e].lane, rd = runs[e].d, rlast = runs[e].last, p0 = runs[e].piece0, np = runs[e].npieces;
+    const u64 slot0 = (u64)rw * chunks_per_window;
+    XYZZ<typename WK::Mem> *out = &pts[((u64)rw << (c - 1)) + rd - 1];
+    // partial t of the run: t == 0 the tail partial of its first chunk, then the head partials of the chunks that follow
+    const u32 t0 = (piece - p0) * PIECE, nparts = rlast - rlane + 1;
+    const u32 t1 = t0 + PIECE < nparts ? t0 + PIECE : nparts;
+    Pt acc;
+    WK::identity(acc);
+    if (live)
+      for (u32 t = t0 + wid; t < t1; t += NWORK) {
+        Pt o;
+        WK::load(o, t == 0 ? tail + slot0 + rlane : head + slot0 + rlane + t);
+        WK::add(acc, o);
+      }
+    long_block_sum<WK>(acc, live, wid, wave_part);
+    if (np == 1) {
+      if (live && wid == 0) WK::store(out, acc);
+      continue;
+    }
+    if (live && wid == 0) WK::store(&piece_out[piece], acc);
+    __threadfence();   // the piece result is visible device-wide before the counter moves
+    __syncthreads();
+    if (threadIdx.x == 0) sh_last = atomicAdd(&runs[e].done, 1u) == np - 1 ? 1u : 0u;
+    __syncthreads();
+    if (sh_last) {   // every other piece of the run has been published: fold them
+      __threadfence();
+      WK::identity(acc);
+      if (live)
+        for (u32 q = wid; q < np; q += NWORK) {
+          Pt o;
+          WK::load(o, &piece_out[p0 + q]);
+          WK::add(acc, o);
+        }
+      long_block_sum<WK>(acc, live, wid, wave_part);
+      if (live && wid == 0) WK::store(out, acc);
+    }
+  }
+}
+
 // Resident wavefronts per SIMD the lane cost model assumes for the reduction kernels: [0] G1, [1] G2 one lane per
 // point, [2] G2 lane triples.  One each: a second resident wavefront does NOT interleave for free in these mad-bound
 // chains (profiles/r2_call8_slots.txt: G1 2^17-2^20 reduce 0.73-0.99 ms with 1, 0.92-1.19 ms with 2; G2 within noise).
@@ -940,7 +1021,17 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     }
   }
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
-  const u32 max_big = (u32)(nslots / (BIG_RUN_CHUNKS + 1) + 1);
+  // runs of more than big_chunks chunks - more than four serial additions per worker of msm_merge_runs_kernel - are cut
+  // into workgroup-sized pieces (msm_merge_long_kernel); G1 pieces run on lane pairs.  BELLMAN_HIP_LONG_K2=0: one lane
+  // per point there too (A/B)
+  static const bool long_k2 = [] { const char *e = getenv("BELLMAN_HIP_LONG_K2"); return !(e && *e == '0'); }();
+  constexpr bool LONG_ON_PAIRS = std::is_same<FR, FpOps>::value;
+  const bool long_pairs = LONG_ON_PAIRS && long_k2;
+  const u32 big_chunks = std::max(32u, 4u * run_lanes);
+  const u32 piece = long_pairs ? long_piece<K2Worker>() : long_piece<XyzzWorker<FR>>();
+  const u32 max_big = (u32)(nslots / (big_chunks + 1) + 1);
+  // sum of ceil(L_r / piece) over the big runs: consecutive runs share one chunk, so sum L_r <= nslots + max_big
+  const u32 max_pieces = (u32)((nslots + max_big) / piece + max_big + 1);
   const u32 H = 1u << p.hi_bits, Lw = 1u << p.lo_bits;
   const u64 nwords = (n + 63) / 64;
   size_t off = 0;
@@ -955,7 +1046,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_pairs_a = carve(npairs * 8), o_pairs_b = carve(npairs * 8);
   const size_t o_counts = carve(ncounts * 4), o_scan = carve(scan_tmp_elems(ncounts) * 4), o_zstart = carve((u64)p.W * 4);
   const size_t o_head = carve(nslots * sizeof(Pt)), o_tail = carve(nslots * sizeof(Pt));
-  const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(LongRun));
+  const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(BigRun));
+  const size_t o_pieces = carve((u64)max_pieces * sizeof(Pt));
   const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
   const size_t o_prefix = density_dev ? carve((nwords + 1) * 4) : 0;
   char *ws = (char *)c.pool.acquire(off);
@@ -967,7 +1059,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   b.counts = (u32 *)(ws + o_counts); b.scan_tmp = (u32 *)(ws + o_scan); b.zstart = (u32 *)(ws + o_zstart);
   b.word_prefix = density_dev ? (u32 *)(ws + o_prefix) : nullptr;
   Pt *pts = (Pt *)(ws + o_pts), *head = (Pt *)(ws + o_head), *tail = (Pt *)(ws + o_tail);
-  LongRun *long_runs = (LongRun *)(ws + o_long), *big_runs = (LongRun *)(ws + o_big);
+  LongRun *long_runs = (LongRun *)(ws + o_long);
+  BigRun *big_runs = (BigRun *)(ws + o_big);
+  Pt *piece_out = (Pt *)(ws + o_pieces);
   Pt *rowcol = (Pt *)(ws + o_rowcol), *bits = (Pt *)(ws + o_bits);
   ErrFlags *err = b.err;
   job.err_dev = err;
@@ -1071,10 +1165,21 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
                        p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
     BH_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(msm_merge_runs_kernel<FR>, dim3((u32)c.num_cus * 4), dim3(64), 0, st, pts, head, tail, p.c,
-                       p.chunks_per_window, long_runs, max_long, big_runs, max_big, err, run_lanes);
+                       p.chunks_per_window, long_runs, max_long, big_runs, max_big, err, run_lanes, big_chunks, piece);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_merge_long_kernel<FR>, dim3(256), dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
-                       p.chunks_per_window, big_runs, max_big, err);
+    // (one workgroup per piece at a time; a launch with nothing to do costs ~5 us)
+    const dim3 lgrid(std::min<u32>(max_pieces, (u32)c.num_cus * 8));
+    if constexpr (LONG_ON_PAIRS) {
+      if (long_pairs)
+        hipLaunchKernelGGL(msm_merge_long_kernel<K2Worker>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
+                           p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
+      else
+        hipLaunchKernelGGL(msm_merge_long_kernel<XyzzWorker<FR>>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
+                           p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
+    } else {
+      hipLaunchKernelGGL(msm_merge_long_kernel<XyzzWorker<FR>>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
+                         p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
+    }
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.

@@ -10,7 +10,8 @@ struct ErrFlags {       // device-side status word block
   u32 ident_top;        // ... in the reference's top window, before the first EOF entry
   u32 nlong;            // number of bucket runs queued for the wavefront-parallel merge
   u32 nbig;             // ... of those, runs long enough to be passed on to the workgroup-parallel merge
-  u32 pad[3];
+  u32 npieces;          // ... and the workgroup-sized pieces they were cut into (msm_merge_long_kernel)
+  u32 pad[2];
 };
 
 enum { SUM_STRIDED = 1, SUM_BITS = 2 };
@@ -27,6 +28,14 @@ struct SumDesc {
 struct LongRun {   // a bucket run that spans more chunks than its owner lane folds itself
   u32 w, lane, d;  // window, first chunk (holds the run's tail partial), digit
   u32 last;        // last chunk with a head partial of the run
+};
+// A run too long for a handful of lanes (boolean-heavy witnesses put a quarter of the scalars into bucket 1 of window 0 -
+// the reason the reference has Exponent::One, multiexp.rs:172-182,245-252): its partials are cut into pieces of one
+// workgroup's worth, pieces [piece0, piece0 + npieces) of the job; the workgroup that finishes the run's last piece folds
+// the piece results (`done` counts finished pieces).
+struct BigRun {
+  u32 w, lane, d, last;
+  u32 piece0, npieces, done, pad;
 };
 
 // per-job plan overrides (bh_msm_opts): zero = tuned default
