@@ -94,6 +94,83 @@ class ChainCircuit : public Circuit {
   }
 };
 
+// A boolean-heavy circuit in the shape of the reference's bit-level gadgets (src/gadgets/boolean.rs: AllocatedBit::alloc
+// enforces (1 - b) * b = 0, `and` enforces a * b = c, `xor` enforces (a + a) * b = a + b - c; src/gadgets/sha256.rs:307-331
+// builds its rounds from exactly these): 64 state bits taken from the witness, then `rounds` steps
+//   i % 3 == 0:  u = s[a] AND s[b]                 (kept aside)
+//   i % 3 == 1:  s[c] = s[c] XOR u
+//   i % 3 == 2:  s[a] = s[a] XOR s[b]
+// with a, b, c walking over the state, and every 64th step the state packed into ONE field element
+// (sum_j 2^j s[j]) * 1 = num (as the gadgets' `pack_into_inputs` / UInt32 arithmetic do); the last packed value is the
+// public input.  More than 98 % of the aux assignment is 0 or 1 - the vectors Exponent::Zero / One exist for
+// (src/multiexp.rs:172-182,245-252).  tests/circuits.py::boolmix_circuit is the same circuit.
+class BoolMixCircuit : public Circuit {
+ public:
+  uint64_t seed;
+  size_t rounds;
+  Fr x0;
+  void synthesize(ConstraintSystem &cs) override {
+    uint64_t canon[4];
+    x0.to_canonical(canon);
+    uint64_t st = seed;
+    const uint64_t init = canon[0] ^ ChainCircuit::splitmix(st);
+    const Variable one = ConstraintSystem::one();
+    Variable s[64];
+    bool v[64];
+    for (int j = 0; j < 64; j++) {
+      v[j] = (init >> j) & 1;
+      const Fr bv = v[j] ? Fr::one() : Fr::zero();
+      s[j] = cs.alloc([&] { return bv; });
+      const Variable b = s[j];
+      cs.enforce([&](LinearCombination lc) { return lc + one - b; }, [&](LinearCombination lc) { return lc + b; },
+                 [&](LinearCombination lc) { return lc; });
+    }
+    Fr pow2[64];
+    pow2[0] = Fr::one();
+    for (int j = 1; j < 64; j++) pow2[j] = pow2[j - 1] + pow2[j - 1];
+    auto pack_value = [&] { uint64_t w = 0; for (int j = 0; j < 64; j++) w |= (uint64_t)v[j] << j; return Fr::from_u64(w); };
+    auto pack_lc = [&](LinearCombination lc) { for (int j = 0; j < 64; j++) lc = std::move(lc) + std::make_pair(pow2[j], s[j]); return lc; };
+    auto xor_into = [&](int dst, Variable other, bool other_v) {
+      const bool tv = v[dst] ^ other_v;
+      const Fr tf = tv ? Fr::one() : Fr::zero();
+      const Variable x = s[dst];
+      Variable t = cs.alloc([&] { return tf; });
+      cs.enforce([&](LinearCombination lc) { return lc + x + x; }, [&](LinearCombination lc) { return lc + other; },
+                 [&](LinearCombination lc) { return lc + x + other - t; });
+      s[dst] = t; v[dst] = tv;
+    };
+    Variable pending = s[0];
+    bool pending_v = v[0];
+    for (size_t i = 0; i < rounds; i++) {
+      const int a = (int)((7 * i + 1) % 64), c = (int)((29 * i + 11) % 64);
+      int b = (int)((13 * i + 5) % 64);
+      if (a == b) b = (b + 1) % 64;
+      switch (i % 3) {
+        case 0: {
+          const bool uv = v[a] && v[b];
+          const Fr uf = uv ? Fr::one() : Fr::zero();
+          const Variable xa = s[a], xb = s[b];
+          Variable u = cs.alloc([&] { return uf; });
+          cs.enforce([&](LinearCombination lc) { return lc + xa; }, [&](LinearCombination lc) { return lc + xb; },
+                     [&](LinearCombination lc) { return lc + u; });
+          pending = u; pending_v = uv;
+          break;
+        }
+        case 1: xor_into(c, pending, pending_v); break;
+        default: xor_into(a, s[b], v[b]); break;
+      }
+      if (i % 64 == 63) {
+        const Fr nv = pack_value();
+        Variable num = cs.alloc([&] { return nv; });
+        cs.enforce(pack_lc, [&](LinearCombination lc) { return lc + one; }, [&](LinearCombination lc) { return lc + num; });
+      }
+    }
+    const Fr outv = pack_value();
+    Variable out = cs.alloc_input([&] { return outv; });
+    cs.enforce(pack_lc, [&](LinearCombination lc) { return lc + one; }, [&](LinearCombination lc) { return lc + out; });
+  }
+};
+
 // Every way a linear combination can reach `enforce` through the mirror (test fixture: tests/circuits.py::forms_circuit is
 // the same circuit against the oracle's ConstraintSystem).  Per round i, on variables v (aux), w (aux), p (a public input
 // every third round) and constants k, k2 from SplitMix64(seed):
@@ -272,6 +349,13 @@ static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const
   }
   if (circuit_kind == 2) {   // every form of linear combination (test fixture): witness = x0, `size` rounds
     FormsCircuit c;
+    c.seed = seed; c.rounds = size;
+    c.x0 = Fr::zero();
+    if (witness) memcpy(&c.x0, witness, 32);
+    return f(c);
+  }
+  if (circuit_kind == 5) {   // boolean-heavy bit-mixing circuit: witness = x0 (its low 64 bits seed the state), `size` steps
+    BoolMixCircuit c;
     c.seed = seed; c.rounds = size;
     c.x0 = Fr::zero();
     if (witness) memcpy(&c.x0, witness, 32);
@@ -492,6 +576,11 @@ int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint
     rc = run_guarded([&] { return create_proof(c, *params->p, rr, ss, &tm); }, proof_out);
   } else if (circuit_kind == 1) {   // chain: witness = x0, `size` rounds
     ChainCircuit c;
+    c.seed = seed; c.rounds = size;
+    memcpy(&c.x0, witness, 32);
+    rc = run_guarded([&] { return create_proof(c, *params->p, rr, ss, &tm); }, proof_out);
+  } else if (circuit_kind == 5) {   // boolean-heavy bit mixing: witness = x0, `size` steps
+    BoolMixCircuit c;
     c.seed = seed; c.rounds = size;
     memcpy(&c.x0, witness, 32);
     rc = run_guarded([&] { return create_proof(c, *params->p, rr, ss, &tm); }, proof_out);

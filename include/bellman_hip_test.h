@@ -17,7 +17,10 @@ extern "C" {
  * kind 1 = synthetic multiplicative chain of `size` rounds (witness = x0),
  * kind 2 = every form of linear combination (`size` rounds, witness = x0; not satisfiable: a fixture for the host-side
  *          hooks bh_test_demo_assignment / bh_test_capture_check, bh_groth16_prove_demo rejects it),
- * kind 3 = a circuit whose structure is drawn from `seed` (`size` rounds, witness = x0; same use as kind 2). */
+ * kind 3 = a circuit whose structure is drawn from `seed` (`size` rounds, witness = x0; same use as kind 2),
+ * kind 5 = boolean-heavy bit mixing in the shape of src/gadgets/boolean.rs (64 state bits from the low word of the witness
+ *          x0, `size` AND / XOR steps, the state packed into a field element every 64 steps: > 98 % of the aux assignment
+ *          is 0 or 1). */
 int bh_groth16_prove_demo(bh_params *params, int circuit_kind, size_t size, uint64_t seed,
                           const void *witness, const void *constants, const void *r, const void *s,
                           void *proof_out, float *timings4);

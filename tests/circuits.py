@@ -213,3 +213,135 @@ def random_circuit(rounds, seed, x0):
             cs.enforce(closure(sides[0]), closure(sides[1]), closure(sides[2]))
 
     return synth
+
+
+def _boolmix_indices(i):
+    a, c = (7 * i + 1) % 64, (29 * i + 11) % 64
+    b = (13 * i + 5) % 64
+    if a == b:
+        b = (b + 1) % 64
+    return a, b, c
+
+
+def _boolmix_init(seed, x0):
+    _, z = _splitmix(seed & MASK64)
+    return ((x0 % Q) & MASK64) ^ z
+
+
+def boolmix_rounds(log_m):
+    """steps of the boolean circuit whose constraint count (64 bit checks + steps + one pack per 64 steps + the final pack +
+    create_proof's 2 input constraints) fills a domain of 2^log_m without exceeding it"""
+    return ((1 << log_m) - 67) * 64 // 65
+
+
+def boolmix_circuit(rounds, seed, x0):
+    """BoolMixCircuit::synthesize of csrc/demo_circuits.cpp: a boolean-heavy circuit in the shape of the reference's
+    bit-level gadgets (src/gadgets/boolean.rs: AllocatedBit::alloc, and, xor), the state packed into a field element every
+    64 steps.  Written against the ConstraintSystem interface of oracle/pyref/core.py."""
+
+    def synth(cs):
+        init = _boolmix_init(seed, x0)
+        one = cs.one()
+        s, v = [], []
+        for j in range(64):
+            bit = (init >> j) & 1
+            var = cs.alloc(lambda: bit)
+            cs.enforce(lambda lc: lc + one - var, lambda lc: lc + var, lambda lc: lc)
+            s.append(var)
+            v.append(bit)
+
+        def pack_value():
+            return sum(b << j for j, b in enumerate(v))
+
+        def pack_lc(lc):
+            for j in range(64):
+                lc = lc + (1 << j, s[j])
+            return lc
+
+        def xor_into(dst, other, other_v):
+            tv = v[dst] ^ other_v
+            x = s[dst]
+            t = cs.alloc(lambda: tv)
+            cs.enforce(lambda lc: lc + x + x, lambda lc: lc + other, lambda lc: lc + x + other - t)
+            s[dst], v[dst] = t, tv
+
+        pending, pending_v = s[0], v[0]
+        for i in range(rounds):
+            a, b, c = _boolmix_indices(i)
+            if i % 3 == 0:
+                uv = v[a] & v[b]
+                xa, xb = s[a], s[b]
+                u = cs.alloc(lambda: uv)
+                cs.enforce(lambda lc: lc + xa, lambda lc: lc + xb, lambda lc: lc + u)
+                pending, pending_v = u, uv
+            elif i % 3 == 1:
+                xor_into(c, pending, pending_v)
+            else:
+                xor_into(a, s[b], v[b])
+            if i % 64 == 63:
+                nv = pack_value()
+                num = cs.alloc(lambda: nv)
+                cs.enforce(pack_lc, lambda lc: lc + one, lambda lc: lc + num)
+        outv = pack_value()
+        out = cs.alloc_input(lambda: outv)
+        cs.enforce(pack_lc, lambda lc: lc + one, lambda lc: lc + out)
+
+    return synth
+
+
+def boolmix_assignment_fast(rounds, seed, x0):
+    """The ProvingAssignment of boolmix_circuit (after create_proof's input constraints) computed directly - evaluations,
+    assignments and density maps as prover.rs:19-55 would leave them - for sizes where the generic synthesis is too slow.
+    Checked against the generic synthesis in tests/test_boolean_circuit_cpu.py."""
+    init = _boolmix_init(seed, x0)
+    aux, a_ev, b_ev, c_ev = [], [], [], []
+    a_den, b_den = [], []          # density of the aux variables in the A and B queries
+    s, v = [], []
+
+    def alloc(val):
+        aux.append(val)
+        a_den.append(False)
+        b_den.append(False)
+        return len(aux) - 1
+
+    for j in range(64):
+        bit = (init >> j) & 1
+        var = alloc(bit)
+        a_ev.append((1 - bit) % Q); b_ev.append(bit); c_ev.append(0)
+        a_den[var] = True; b_den[var] = True
+        s.append(var); v.append(bit)
+
+    def pack():
+        val = 0
+        for j in range(64):
+            val |= v[j] << j
+            a_den[s[j]] = True
+        return val
+
+    pending, pending_v = s[0], v[0]
+    for i in range(rounds):
+        a, b, c = _boolmix_indices(i)
+        k = i % 3
+        if k == 0:
+            uv = v[a] & v[b]
+            a_den[s[a]] = True; b_den[s[b]] = True
+            u = alloc(uv)
+            a_ev.append(v[a]); b_ev.append(v[b]); c_ev.append(uv)
+            pending, pending_v = u, uv
+        else:
+            dst, other, other_v = (c, pending, pending_v) if k == 1 else (a, s[b], v[b])
+            xv = v[dst]
+            tv = xv ^ other_v
+            a_den[s[dst]] = True; b_den[other] = True
+            t = alloc(tv)
+            a_ev.append(2 * xv); b_ev.append(other_v); c_ev.append((xv + other_v - tv) % Q)
+            s[dst], v[dst] = t, tv
+        if i % 64 == 63:
+            nv = pack()
+            alloc(nv)
+            a_ev.append(nv); b_ev.append(1); c_ev.append(nv)
+    outv = pack()
+    a_ev.append(outv); b_ev.append(1); c_ev.append(outv)
+    a_ev += [1, outv]; b_ev += [0, 0]; c_ev += [0, 0]    # input_i * 0 = 0 (prover.rs:208-215)
+    return dict(a=a_ev, b=b_ev, c=c_ev, input_assignment=[1, outv], aux_assignment=aux,
+                a_aux_density=a_den, b_input_density=[True, False], b_aux_density=b_den)

@@ -1,0 +1,174 @@
+"""GPU parity on the scalar vectors REAL witnesses produce (run with `pytest -m gpu` on a MI355X).
+
+The reference special-cases Exponent::Zero / One (src/multiexp.rs:172-182,245-252) because witnesses of bit-level circuits
+(src/gadgets/boolean.rs, sha256.rs:307-331) are almost only zeros and ones; SURVEY.md 8(d) lists "boolean-heavy vectors
+(~50 % zeros/ones)" in the input suite.  On the device such a vector puts a quarter (or all) of its entries into ONE bucket
+of window 0 - a run of thousands of chunks through msm_merge_chunks -> merge_runs -> merge_long (csrc/msm_ec.cuh) that the
+uniform scalars of every other large test never produce.  Here, at BASELINE sizes:
+
+  * G1 at 2^20 and 2^22 terms, G2 at 2^20: mixes {50 % 0/1, 90 % 0/1, all ones, 90 % below 2^8} x {classic plan, window-table
+    plan} x {FullDensity, a 0.5 density map with a base offset} against the restated multiexp (src/multiexp.rs:210-332) on
+    all host cores, and against the size-independent identity sum_i s_i [t_i]G = [sum_i s_i t_i]G;
+  * create_proof on the boolean-heavy demo circuit (csrc/demo_circuits.cpp BoolMixCircuit: > 98 % of the aux assignment is
+    0 or 1) with 2^20 constraints - host synthesis and R1CS-resident - against the restated prover (prover.rs:217-360).
+Integer work: exact equality of every limb."""
+
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import cprover, cref  # noqa: E402
+from tests import golden_cache, scalar_mixes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def worker():
+    import bellman_amd
+
+    w = bellman_amd.Worker(0)
+    yield w
+    w.close()
+
+
+_BASES = {}
+
+
+@pytest.fixture(scope="module")
+def base_sets(worker):
+    """(group, log_n) -> (t, classic handle, table handle, host records, generator); P_i = [t_i]G made on the device"""
+    import bellman_amd
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+
+    def get(group, log_n):
+        key = (group, log_n)
+        if key not in _BASES:
+            for k in list(_BASES):   # one size at a time in HBM
+                for h in _BASES.pop(k)[1:3]:
+                    h.release()
+            n = 1 << log_n
+            words = 12 if group == 1 else 24
+            gen = cref.g1_generator() if group == 1 else cref.g2_generator()
+            t = scalar_mixes.scalars("uniform", n, 0xB00 + 16 * group + log_n)
+            dt, dout = worker.alloc(n * 32), worker.alloc(n * 8 * words)
+            worker.upload(dt, t)
+            assert lib.bh_fixed_base_mul_dev(worker.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+            worker.synchronize()
+            worker.free(dt)
+            plain = bellman_amd.Bases.wrap_device(worker, group, dout, n)        # no window table: the classic plan
+            table = bellman_amd.Bases.copy_device(worker, group, dout, n)
+            if table.table_info()[1] == 0:
+                table.precompute()
+            assert plain.table_info()[1] == 0 and table.table_info()[1] > 0
+            host = plain.download()
+            for i in (0, n // 3, n - 1):   # the generator kernel against the oracle
+                assert np.array_equal(host[i], cref.point_mul(group, gen, cref.limbs_to_int(t[i])))
+            _BASES[key] = (t, plain, table, host, gen, dout)
+        return _BASES[key][:5]
+
+    yield get
+    for k in list(_BASES):
+        rec = _BASES.pop(k)
+        rec[1].release()
+        rec[2].release()
+        worker.free(rec[5])
+    worker.trim()
+
+
+@pytest.mark.parametrize("mix", ["bool50", "bool90", "ones", "small90"])
+@pytest.mark.parametrize("group,log_n", [(1, 20), (2, 20), (1, 22)])
+def test_boolean_heavy_multiexp_matches_oracle(worker, base_sets, group, log_n, mix):
+    import bellman_amd
+
+    n = 1 << log_n
+    t, plain, table, host_bases, gen = base_sets(group, log_n)
+    sc = scalar_mixes.scalars(mix, n, 0x5EED + 64 * group + log_n)
+    bits = np.random.default_rng(log_n + group).random(n) < 0.5
+    skip = 3
+    for dense in (False, True):
+        if dense:
+            dmap = bellman_amd.DensityTracker()
+            dmap.bv = bits
+            k = cref.fr_dot(sc[bits], t[skip:skip + int(bits.sum())])
+            key = "msm_boolean:g%d:2^%d:%s:density0.5:skip3" % (group, log_n, mix)
+            inputs = [host_bases, sc, bits.astype(np.uint8)]
+            compute = lambda: _oracle_msm(group, host_bases, skip, cref.density_bitmap(bits), sc)   # noqa: E731
+        else:
+            dmap = bellman_amd.FullDensity()
+            k = cref.fr_dot(sc, t)
+            key = "msm_boolean:g%d:2^%d:%s:full" % (group, log_n, mix)
+            inputs = [host_bases, sc]
+            compute = lambda: _oracle_msm(group, host_bases, 0, None, sc)   # noqa: E731
+        (want,), src = golden_cache.oracle_answer(key, inputs, compute)
+        assert np.array_equal(want, cref.point_mul(group, gen, k)), "oracle != [sum s_i t_i]G"
+        for name, bases in (("classic", plain), ("table", table)):
+            got, ms = bellman_amd.multiexp(worker, bases, dmap, sc, skip=skip if dense else 0, timed=True).wait()
+            assert np.array_equal(got, want), (group, log_n, mix, dense, name)
+            print("G%d 2^%d %-8s %-7s %-7s device %.3f ms [sort %.3f, accumulate %.3f, reduce %.3f] (oracle: %s)"
+                  % (group, log_n, mix, "density" if dense else "full", name, ms[0], ms[1], ms[2], ms[3], src))
+
+
+def _oracle_msm(group, bases, skip, density, sc):
+    rc, want = cref.multiexp(group, bases, skip, density, sc, threads=cref.lib().orc_max_threads())
+    assert rc == 0
+    return [want]
+
+
+def test_boolean_circuit_proof_2_20_matches_oracle(worker):
+    """create_proof on BoolMixCircuit with 2^20 constraints (aux assignment > 98 % zeros and ones) == the restated
+    prover (prover.rs:217-360) on all host cores, proof A, B, C bit-identical - through host synthesis (ProvingAssignment) and
+    with the constraint matrices resident in HBM."""
+    from bellman_amd import groth16 as pg
+    from tests import circuits
+
+    log_n = 20
+    rounds = circuits.boolmix_rounds(log_n)
+    seed, x0, r, s = 777, 0x0123456789ABCDEF, 0xABCDEF0123456789, 0x1234567890ABCDEF
+    f = circuits.boolmix_assignment_fast(rounds, seed, x0)
+    n_cons, n_aux = len(f["a"]), len(f["aux_assignment"])
+    m = 1 << log_n
+    assert m - 70 < n_cons <= m
+    aux = f["aux_assignment"]
+    assert sum(1 for v in aux if v in (0, 1)) >= 0.98 * n_aux
+    na = 2 + sum(f["a_aux_density"])
+    nb = sum(f["b_input_density"]) + sum(f["b_aux_density"])
+    h, l = cref.gen_bases(1, m - 1, a=11, b=3), cref.gen_bases(1, n_aux, a=5, b=7)
+    a, b1, b2 = cref.gen_bases(1, na, a=2, b=9), cref.gen_bases(1, nb, a=13, b=4), cref.gen_bases(2, nb, a=17, b=6)
+    g1, g2 = cref.g1_generator(), cref.g2_generator()
+    vk = dict(alpha_g1=cref.point_mul(1, g1, 101), beta_g1=cref.point_mul(1, g1, 102), beta_g2=cref.point_mul(2, g2, 102),
+              delta_g1=cref.point_mul(1, g1, 103), delta_g2=cref.point_mul(2, g2, 103))
+    pp = pg.Parameters(worker, vk["alpha_g1"], vk["beta_g1"], vk["beta_g2"], vk["delta_g1"], vk["delta_g2"], h, l, a, b1, b2)
+    tm = [0, 0, 0, 0]
+    got = pg.create_proof_demo(pp, 5, rounds, seed, [x0], None, r, s, tm)
+    r1cs = pg.R1CS.from_demo(worker, 5, rounds, seed)
+    tm_r = [0, 0, 0, 0]
+    got_r = pg.create_proof_demo_r1cs(pp, r1cs, 5, rounds, seed, [x0], None, r, s, tm_r)
+
+    def compute():
+        tc = {}
+        want = cprover.prove_assignment(f["a"], f["b"], f["c"], f["input_assignment"], f["aux_assignment"], f["a_aux_density"],
+                                        f["b_input_density"], f["b_aux_density"], vk, h, l, a, b1, b2, r, s,
+                                        threads=cref.lib().orc_max_threads(), concurrent=True, timing=tc)
+        print("oracle proof %.1f s" % tc["total_s"])
+        return list(want)
+
+    aux_arr = cref.ints_to_arr(aux, 4)
+    want, src = golden_cache.oracle_answer("proof_boolmix:2^20:seed777", [aux_arr, h, l, a, b1, b2, np.array([r, s], dtype=np.uint64)], compute)
+    print("2^20 boolean proof: host-synthesis ms [synthesis, h, msm, total] = %s; R1CS resident %s (oracle: %s)"
+          % ([round(x, 1) for x in tm], [round(x, 1) for x in tm_r], src))
+    for g in (got, got_r):
+        assert np.array_equal(g.a.reshape(-1), want[0]) and np.array_equal(g.b.reshape(-1), want[1]) and \
+            np.array_equal(g.c.reshape(-1), want[2])
+    r1cs.release()
+    pp.release()
