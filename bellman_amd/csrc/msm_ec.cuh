@@ -348,8 +348,9 @@ __device__ __forceinline__ u32 run_last_chunk(const u64 *src, u32 n, u32 z, u32 
 
 // Folds the partial sums of buckets that straddle chunk boundaries.  The lane whose chunk holds the run's first
 // entry owns it: it finds the run's last chunk, folds tail[l0] + head[l0+1 .. l1] itself when that is at most
-// `walk` additions, and queues longer runs for msm_merge_runs_kernel so that no lane ever executes a long serial
-// chain of point additions (~20 us per link).
+// `walk` additions, and queues longer runs - medium ones for the G-workers-per-run part of msm_merge_tail_kernel, runs of
+// more than `big_chunks` chunks cut into workgroup-sized pieces for its long part - so that no lane ever executes a long
+// serial chain of point additions (~20 us per link).
 // wavefronts per SIMD the register allocation aims at (hipcc reads the second launch bound that way): two for every
 // bundle whose lane state allows it - the lane-triple instantiation sat at 256 VGPRs + 2 AGPRs, one wavefront per SIMD
 // for two registers (profiles/r4_call8.txt: G2 reduce 1.0 -> 0.91-0.94 ms)
@@ -361,7 +362,8 @@ __global__ __launch_bounds__(128, merge_waves_per_simd<F>()) void msm_merge_chun
                                                                const XYZZ<typename F::Mem> *head,
                                                                const XYZZ<typename F::Mem> *tail, u32 n, u32 c, u32 K,
                                                                u32 chunks_per_window, u32 walk, LongRun *long_runs,
-                                                               u32 max_long, ErrFlags *err) {
+                                                               u32 max_long, BigRun *big_runs, u32 max_big, u32 big_chunks,
+                                                               u32 piece, ErrFlags *err) {
   const u32 w = blockIdx.y;
   u32 in_block, lane;
   if (!worker_index<F>(default_per_wave<F>(), in_block, lane)) return;
@@ -376,8 +378,15 @@ __global__ __launch_bounds__(128, merge_waves_per_simd<F>()) void msm_merge_chun
   const u32 last = run_last_chunk(src, n, z, K, lane, d);
   if (last - lane > walk) {
     if (worker_role<F>() == 0) {   // one entry per worker
-      const u32 slot = atomicAdd(&err->nlong, 1u);
-      if (slot < max_long) { LongRun lr = {w, lane, d, last}; long_runs[slot] = lr; }
+      if (last - lane > big_chunks) {   // cut into workgroup-sized pieces (msm_merge_tail_kernel, long part)
+        const u32 slot = atomicAdd(&err->nbig, 1u);
+        const u32 np = (last - lane + piece) / piece;   // ceil(partials / piece), partials = last - lane + 1
+        const u32 p0 = atomicAdd(&err->npieces, np);
+        if (slot < max_big) { BigRun br = {w, lane, d, last, p0, np, 0u, 0u}; big_runs[slot] = br; }
+      } else {
+        const u32 slot = atomicAdd(&err->nlong, 1u);
+        if (slot < max_long) { LongRun lr = {w, lane, d, last}; long_runs[slot] = lr; }
+      }
     }
     return;
   }
@@ -409,54 +418,6 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
       xyzz_add(r, acc, o);
       acc = r;
     }
-  }
-}
-
-// Queued runs: tail[l0] + sum of head[l0+1 .. l1] by G workers per run (G a power of two chosen by the host,
-// PW / G runs per wavefront): every worker folds every G-th partial, then a shuffle tree.  The medium case this is
-// for: the top window of the 13-bit plans and the buckets of window-table plans, a few times fuller than a
-// chunk (8-16 chunks).  Runs of more than `big_chunks` chunks (more than four serial additions per worker here) are
-// passed on to msm_merge_long_kernel, cut into pieces of `piece` partials - boolean-heavy witnesses put a quarter of the
-// scalars of window 0 into ONE bucket.
-template <class F>
-__global__ __launch_bounds__(64, merge_waves_per_simd<F>()) void msm_merge_runs_kernel(XYZZ<typename F::Mem> *pts, const XYZZ<typename F::Mem> *head,
-                                                            const XYZZ<typename F::Mem> *tail, u32 c, u32 chunks_per_window,
-                                                            const LongRun *runs, u32 max_runs, BigRun *big_runs,
-                                                            u32 max_big, ErrFlags *err, u32 G, u32 big_chunks, u32 piece) {
-  constexpr u32 PW = tree_per_wave<F>();
-  u32 nruns = err->nlong;
-  if (nruns > max_runs) nruns = max_runs;
-  u32 t, gid;
-  const bool live = worker_index<F>(PW, t, gid);   // one wavefront per block
-  const u32 per_wave = PW / G, r = t / G, k = t & (G - 1);
-  for (u32 base = blockIdx.x * per_wave; base < nruns; base += gridDim.x * per_wave) {
-    const u32 e = base + r;
-    bool valid = live && e < nruns;
-    LongRun lr = {0, 0, 0, 0};
-    if (valid) lr = runs[e];
-    if (valid && lr.last - lr.lane > big_chunks) {
-      if (k == 0 && worker_role<F>() == 0) {
-        const u32 slot = atomicAdd(&err->nbig, 1u);
-        const u32 np = (lr.last - lr.lane + piece) / piece;   // ceil(partials / piece), partials = last - lane + 1
-        const u32 p0 = atomicAdd(&err->npieces, np);
-        if (slot < max_big) { BigRun br = {lr.w, lr.lane, lr.d, lr.last, p0, np, 0u, 0u}; big_runs[slot] = br; }
-      }
-      valid = false;
-    }
-    const u64 slot0 = (u64)lr.w * chunks_per_window;
-    XYZZ<F> acc;
-    xyzz_set_identity(acc);
-    if (valid) {
-      if (k == 0) load_xyzz<F>(acc, tail + slot0 + lr.lane);
-      for (u32 j = lr.lane + 1 + k; j <= lr.last; j += G) {
-        XYZZ<F> o, s2;
-        load_xyzz<F>(o, head + slot0 + j);
-        xyzz_add(s2, acc, o);
-        acc = s2;
-      }
-    }
-    group_reduce_points<F>(acc, G, k);
-    if (valid && k == 0) store_xyzz<F>(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
   }
 }
 
@@ -759,29 +720,58 @@ __device__ __forceinline__ void long_block_sum(typename WK::Pt &acc, bool live, 
   }
   __syncthreads();
 }
+// Medium runs: tail[l0] + sum of head[l0+1 .. l1] by G workers per run (G a power of two chosen by the host, PER_WAVE / G
+// runs per wavefront): every worker folds every G-th partial, then a shuffle tree.  The case this is for: the top window
+// of the 13-bit plans and the buckets of window-table plans, a few times fuller than a chunk (8-32 chunks).  Wavefront
+// `wave` of `nwaves` (no barrier in here: the wavefronts of a workgroup proceed independently).
 template <class WK>
-__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typename WK::Mem> *pts,
-                                                                      const XYZZ<typename WK::Mem> *head,
-                                                                      const XYZZ<typename WK::Mem> *tail, u32 c,
-                                                                      u32 chunks_per_window, BigRun *runs, u32 max_runs,
-                                                                      XYZZ<typename WK::Mem> *piece_out, u32 max_pieces,
-                                                                      const ErrFlags *err) {
+__device__ __forceinline__ void merge_medium_runs(XYZZ<typename WK::Mem> *pts, const XYZZ<typename WK::Mem> *head,
+                                                  const XYZZ<typename WK::Mem> *tail, u32 c, u32 chunks_per_window,
+                                                  const LongRun *runs, u32 nruns, u32 G, u32 wave, u32 nwaves) {
+  typedef typename WK::Pt Pt;
+  constexpr u32 PW = WK::PER_WAVE;
+  u32 wid;
+  const bool live = WK::index(wid);
+  const u32 t = wid - (threadIdx.x >> 6) * PW;   // worker inside the wavefront
+  const u32 per_wave = PW / G, r = t / G, k = t & (G - 1);
+  for (u32 base = wave * per_wave; base < nruns; base += nwaves * per_wave) {
+    const u32 e = base + r;
+    const bool valid = live && e < nruns;
+    LongRun lr = {0, 0, 0, 0};
+    if (valid) lr = runs[e];
+    const u64 slot0 = (u64)lr.w * chunks_per_window;
+    Pt acc;
+    WK::identity(acc);
+    if (valid) {
+      if (k == 0) WK::load(acc, tail + slot0 + lr.lane);
+      for (u32 j = lr.lane + 1 + k; j <= lr.last; j += G) {
+        Pt o;
+        WK::load(o, head + slot0 + j);
+        WK::add(acc, o);
+      }
+    }
+    WK::tree(acc, G, k);   // (every lane of the wavefront takes part in the shuffles)
+    if (valid && k == 0) WK::store(&pts[((u64)lr.w << (c - 1)) + lr.d - 1], acc);
+  }
+}
+// Big runs, piece by piece: workgroup `blk` of `nblk`.
+template <class WK>
+__device__ __forceinline__ void merge_big_runs(XYZZ<typename WK::Mem> *pts, const XYZZ<typename WK::Mem> *head,
+                                               const XYZZ<typename WK::Mem> *tail, u32 c, u32 chunks_per_window,
+                                               BigRun *runs, u32 nruns, XYZZ<typename WK::Mem> *piece_out, u32 total,
+                                               u32 blk, u32 nblk, void *lds_part, u32 *sh_run, u32 *sh_last) {
   typedef typename WK::Pt Pt;
   constexpr u32 NWORK = long_workers<WK>(), PIECE = long_piece<WK>();
-  __shared__ Pt wave_part[LONG_THREADS / 64][WK::LANES];
-  __shared__ u32 sh_run, sh_last;
-  u32 nruns = err->nbig, total = err->npieces;
-  if (nruns > max_runs) nruns = max_runs;   // (cannot happen: max_big / max_pieces are upper bounds, msm_enqueue)
-  if (total > max_pieces) total = max_pieces;
+  Pt(*wave_part)[WK::LANES] = reinterpret_cast<Pt(*)[WK::LANES]>(lds_part);
   u32 wid;
   const bool live = WK::index(wid);   // idle lanes stay for the barriers
-  for (u32 piece = blockIdx.x; piece < total; piece += gridDim.x) {
-    if (threadIdx.x == 0) sh_run = 0xffffffffu;
+  for (u32 piece = blk; piece < total; piece += nblk) {
+    if (threadIdx.x == 0) *sh_run = 0xffffffffu;
     __syncthreads();
     for (u32 e = threadIdx.x; e < nruns; e += LONG_THREADS)
-      if (piece - runs[e].piece0 < runs[e].npieces) sh_run = e;   // exactly one run owns the piece
+      if (piece - runs[e].piece0 < runs[e].npieces) *sh_run = e;   // exactly one run owns the piece
     __syncthreads();
-    const u32 e = sh_run;
+    const u32 e = *sh_run;
     if (e == 0xffffffffu) continue;   // (uniform over the workgroup)
     const u32 rw = runs[e].w, rlane = runs[e].lane, rd = runs[e].d, rlast = runs[e].last, p0 = runs[e].piece0, np = runs[e].npieces;
     const u64 slot0 = (u64)rw * chunks_per_window;
@@ -805,9 +795,9 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typen
     if (live && wid == 0) WK::store(&piece_out[piece], acc);
     __threadfence();   // the piece result is visible device-wide before the counter moves
     __syncthreads();
-    if (threadIdx.x == 0) sh_last = atomicAdd(&runs[e].done, 1u) == np - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) *sh_last = atomicAdd(&runs[e].done, 1u) == np - 1 ? 1u : 0u;
     __syncthreads();
-    if (sh_last) {   // every other piece of the run has been published: fold them
+    if (*sh_last) {   // every other piece of the run has been published: fold them
       __threadfence();
       WK::identity(acc);
       if (live)
@@ -819,6 +809,34 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typen
       long_block_sum<WK>(acc, live, wid, wave_part);
       if (live && wid == 0) WK::store(out, acc);
     }
+  }
+}
+// ONE launch for both: workgroups [0, run_blocks) fold the medium runs (a wavefront each at a time, worker policy WKR),
+// the rest the pieces of the big runs (policy WKL) - side by side, not one after the other: a window table over 2^16
+// points has 4 096 medium runs AND ~115 big ones (the top row's 8-bit digits), 130 us + 170 us as two launches
+// (profiles/r6_call7_k2_ab.txt).
+template <class WKR, class WKL>
+__global__ __launch_bounds__(LONG_THREADS) void msm_merge_tail_kernel(XYZZ<typename WKL::Mem> *pts,
+                                                                      const XYZZ<typename WKL::Mem> *head,
+                                                                      const XYZZ<typename WKL::Mem> *tail, u32 c,
+                                                                      u32 chunks_per_window, const LongRun *runs, u32 max_runs,
+                                                                      u32 G, u32 run_blocks, BigRun *big_runs, u32 max_big,
+                                                                      XYZZ<typename WKL::Mem> *piece_out, u32 max_pieces,
+                                                                      const ErrFlags *err) {
+  static_assert(std::is_same<typename WKR::Mem, typename WKL::Mem>::value, "both parts work on the same records");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_part[sizeof(typename WKL::Pt) * (LONG_THREADS / 64) * WKL::LANES];
+  __shared__ u32 sh_run, sh_last;
+  if (blockIdx.x < run_blocks) {
+    u32 nruns = err->nlong;
+    if (nruns > max_runs) nruns = max_runs;   // (cannot happen: max_long is an upper bound, msm_enqueue)
+    merge_medium_runs<WKR>(pts, head, tail, c, chunks_per_window, runs, nruns, G,
+                           blockIdx.x * (LONG_THREADS / 64) + (threadIdx.x >> 6), run_blocks * (LONG_THREADS / 64));
+  } else {
+    u32 nbig = err->nbig, total = err->npieces;
+    if (nbig > max_big) nbig = max_big;
+    if (total > max_pieces) total = max_pieces;
+    merge_big_runs<WKL>(pts, head, tail, c, chunks_per_window, big_runs, nbig, piece_out, total, blockIdx.x - run_blocks,
+                        gridDim.x - run_blocks, lds_part, &sh_run, &sh_last);
   }
 }
 
@@ -1009,23 +1027,35 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // G workers per queued run: 8-16 chunk runs become 1-2 serial additions + 3 tree levels; when the AVERAGE run is
   // much longer than that (window tables over tiny vectors: 32 n entries in 128 buckets, chunks of 8) more workers
   // shorten the chain as long as the launch still fits the chip
+  // [r6] G1: the same on lane PAIRS (K2: half the latency of an addition for twice the lanes) when that is cheaper by
+  // the same model - levels x latency of a level x how far the launch overfills the chip.  BELLMAN_HIP_LONG_K2=0: one lane
+  // per point everywhere (A/B)
+  static const bool long_k2 = [] { const char *e = getenv("BELLMAN_HIP_LONG_K2"); return !(e && *e == '0'); }();
+  constexpr bool PAIRS_POSSIBLE = std::is_same<FR, FpOps>::value;
   u32 run_lanes = 8;
+  bool runs_on_pairs = false;
   {
     const double avg_chunks = (double)p.n / (double)p.nb / (double)p.chunk;   // per window: n sorted entries, nb buckets
     double best_cost = 1e30;
-    for (u32 g = 8, lg = 3; g <= tree_per_wave<FR>(); g <<= 1, lg++) {
-      const double steps = std::ceil(std::max(1.0, avg_chunks) / g) + lg;
-      const double waves = (double)p.NB * g / (double)tree_per_wave<FR>();
-      const double cost = steps * std::max(1.0, waves / ((double)c.num_cus * 4));
-      if (cost < best_cost) { best_cost = cost; run_lanes = g; }
-    }
+    auto sweep = [&](u32 per_wave, double level_us, bool pairs) {
+      for (u32 g = 8, lg = 3; g <= per_wave; g <<= 1, lg++) {
+        const double steps = std::ceil(std::max(1.0, avg_chunks) / g) + lg;
+        const double waves = (double)p.NB * g / (double)per_wave;
+        const double cost = steps * level_us * std::max(1.0, waves / ((double)c.num_cus * 4));
+        if (cost < best_cost) { best_cost = cost; run_lanes = g; runs_on_pairs = pairs; }
+      }
+    };
+    sweep(tree_per_wave<FR>(), 19.0, false);
+    if (PAIRS_POSSIBLE && long_k2) sweep(K2Worker::PER_WAVE, 10.5, true);
+    // (the model takes every bucket for a queued run - true of window-table plans; where a typical bucket fits a chunk only
+    // the few outliers are queued and the chip has the lanes)
+    if (PAIRS_POSSIBLE && long_k2 && avg_chunks <= 1.0) { run_lanes = 8; runs_on_pairs = true; }
   }
   const u32 max_long = (u32)(nslots / (walk + 1) + 1);
   // runs of more than big_chunks chunks - more than four serial additions per worker of msm_merge_runs_kernel - are cut
   // into workgroup-sized pieces (msm_merge_long_kernel); G1 pieces run on lane pairs.  BELLMAN_HIP_LONG_K2=0: one lane
   // per point there too (A/B)
-  static const bool long_k2 = [] { const char *e = getenv("BELLMAN_HIP_LONG_K2"); return !(e && *e == '0'); }();
-  constexpr bool LONG_ON_PAIRS = std::is_same<FR, FpOps>::value;
+  constexpr bool LONG_ON_PAIRS = PAIRS_POSSIBLE;
   const bool long_pairs = LONG_ON_PAIRS && long_k2;
   const u32 big_chunks = std::max(32u, 4u * run_lanes);
   const u32 piece = long_pairs ? long_piece<K2Worker>() : long_piece<XyzzWorker<FR>>();
@@ -1162,24 +1192,24 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     const u32 rwpb = workers_per_block<FR>(128, default_per_wave<FR>());
     const dim3 rgrid((p.chunks_per_window + rwpb - 1) / rwpb, p.W);
     hipLaunchKernelGGL(msm_merge_chunks_kernel<FR>, rgrid, dim3(128), 0, st, sorted, b.zstart, pts, head, tail, p.n,
-                       p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, err);
+                       p.c, p.chunk, p.chunks_per_window, walk, long_runs, max_long, big_runs, max_big, big_chunks, piece, err);
     BH_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_merge_runs_kernel<FR>, dim3((u32)c.num_cus * 4), dim3(64), 0, st, pts, head, tail, p.c,
-                       p.chunks_per_window, long_runs, max_long, big_runs, max_big, err, run_lanes, big_chunks, piece);
-    BH_HIP_CHECK(hipGetLastError());
-    // (one workgroup per piece at a time; a launch with nothing to do costs ~5 us)
-    const dim3 lgrid(std::min<u32>(max_pieces, (u32)c.num_cus * 8));
-    if constexpr (LONG_ON_PAIRS) {
-      if (long_pairs)
-        hipLaunchKernelGGL(msm_merge_long_kernel<K2Worker>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
-                           p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
-      else
-        hipLaunchKernelGGL(msm_merge_long_kernel<XyzzWorker<FR>>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
-                           p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
+    // medium runs and the pieces of the big runs in ONE launch (a launch with nothing to do costs ~5 us): a wavefront per
+    // SIMD for the medium runs, one workgroup per piece at a time for the big ones
+    const u32 run_blocks = (u32)c.num_cus, long_blocks = std::min<u32>(max_pieces, (u32)c.num_cus * 8);
+    const dim3 tgrid(run_blocks + long_blocks);
+#define BH_TAIL(WKR, WKL)                                                                                                   \
+    hipLaunchKernelGGL((msm_merge_tail_kernel<WKR, WKL>), tgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,              \
+                       p.chunks_per_window, long_runs, max_long, run_lanes, run_blocks, big_runs, max_big, piece_out,           \
+                       max_pieces, err)
+    if constexpr (PAIRS_POSSIBLE) {
+      if (runs_on_pairs && long_pairs) BH_TAIL(K2Worker, K2Worker);
+      else if (long_pairs) BH_TAIL(XyzzWorker<FR>, K2Worker);
+      else BH_TAIL(XyzzWorker<FR>, XyzzWorker<FR>);
     } else {
-      hipLaunchKernelGGL(msm_merge_long_kernel<XyzzWorker<FR>>, lgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,
-                         p.chunks_per_window, big_runs, max_big, piece_out, max_pieces, err);
+      BH_TAIL(XyzzWorker<FR>, XyzzWorker<FR>);
     }
+#undef BH_TAIL
     BH_HIP_CHECK(hipGetLastError());
   }
   // 5. reduce: rows (sum over lo, contiguous), columns (sum over hi, stride Lw), then bits.
