@@ -18,6 +18,10 @@ _OVERRIDE = os.environ.get("BELLMAN_HIP_LIB") if os.environ.get("BELLMAN_HIP_ALL
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, "lib", "libbellman_hip.so")
 
 TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libbellman_hip_test.so")
+# the demo circuits once more, compiled WITHOUT the closure checks of the test library (csrc/Makefile): what bench.py times
+DEMO_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libbellman_hip_demo.so")
+DEMO_EXPORTS = ["bh_groth16_prove_demo", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs", "bh_groth16_prove_demo_async",
+                "bh_groth16_prove_demo_r1cs_part", "bh_test_synthesis_ms"]
 
 # every symbol include/bellman_hip.h declares (libbellman_hip.so exports exactly these) ...
 EXPORTS = [
@@ -27,7 +31,7 @@ EXPORTS = [
     "bh_fft_fr", "bh_fft_fr_dev", "bh_fr_mul_assign_dev", "bh_fr_sub_assign_dev",
     "bh_fr_divide_by_z_on_coset_dev", "bh_fr_distribute_powers_dev", "bh_h_poly_fr", "bh_h_poly_fr_dev", "bh_h_poly_fr_dev_on",
     "bh_bases_register", "bh_bases_register_uncompressed", "bh_bases_read_uncompressed", "bh_bases_download", "bh_bases_write_uncompressed", "bh_bases_copy_dev", "bh_bases_precompute", "bh_bases_table_info", "bh_bases_wrap_dev", "bh_bases_release", "bh_bases_len",
-    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
+    "bh_msm_async", "bh_msm_async_dev", "bh_msm_wait", "bh_msm_wait_timed", "bh_msm_wait_profile", "bh_msm_wait_stats", "bh_msm_plan_info", "bh_msm_debug_stages", "bh_point_add", "bh_point_mul", "bh_point_lincomb", "bh_msm_async_opts", "bh_msm_async_dev_opts",
     "bh_scalars_register", "bh_scalars_adopt_dev", "bh_scalars_release", "bh_scalars_len", "bh_scalars_dev_ptr", "bh_msm_async_scalars", "bh_h_poly_fr_scalars", "bh_msm_async_dev_after", "bh_msm_start",
     "bh_msm_sharded_async", "bh_msm_sharded_wait",
     "bh_fixed_base_mul_dev",
@@ -39,8 +43,8 @@ EXPORTS = [
 # ... and what include/bellman_hip_test.h declares: test hooks and the built-in demo circuits, in libbellman_hip_test.so
 TEST_EXPORTS = [
     "bh_groth16_prove_demo", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs", "bh_groth16_prove_demo_async", "bh_groth16_prove_demo_r1cs_part",
-    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev", "bh_test_msm_stages",
-    "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_msm_plan", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host", "bh_test_fr_ops_host",
+    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev",
+    "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host", "bh_test_fr_ops_host",
     "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
 
@@ -70,6 +74,22 @@ class _Libs:
 
     def __init__(self, product, test):
         self.product, self.test = product, test
+        self.demo_unchecked = None
+
+    def use_unchecked_demo_circuits(self):
+        """bench.py: the demo-circuit entry points (DEMO_EXPORTS) from libbellman_hip_demo.so - the same circuits whose
+        closures do not count their terms (the checking build costs 1.5-2 % of a synthesis, VERDICT r5 weak #8)."""
+        if self.demo_unchecked is None:
+            if not os.path.exists(DEMO_LIB_PATH):
+                raise RuntimeError("libbellman_hip_demo.so not built (run `make -C bellman_amd/csrc`)")
+            d = ctypes.CDLL(DEMO_LIB_PATH)
+            for name in DEMO_EXPORTS:
+                f = getattr(d, name)
+                t = getattr(self.test, name)
+                f.argtypes, f.restype = t.argtypes, t.restype
+                self.__dict__[name] = f
+            self.demo_unchecked = d
+        return self
 
     def __getattr__(self, name):
         try:
@@ -123,7 +143,7 @@ def load():
     lib.bh_test_pool_size_class.argtypes = [sz]
     lib.bh_test_pool_size_class.restype = sz
     lib.bh_test_fp_lazy_host.argtypes = [i32, vp, vp, vp]
-    lib.bh_test_msm_plan.argtypes = [sz, i32, c.c_uint, vp]
+    lib.bh_msm_plan_info.argtypes = [sz, i32, c.c_uint, vp]
     lib.bh_test_proof_slice.argtypes = [sz, sz, sz, c.POINTER(sz), c.POINTER(sz)]
     lib.bh_test_proof_slice.restype = None
     lib.bh_test_synthesis_ms.argtypes = [i32, sz, c.c_uint64, i32]
@@ -220,7 +240,8 @@ def load():
     lib.bh_test_fr_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_fp_mul_dev.argtypes = [vp, vp, vp, vp, sz]
     lib.bh_test_point_add_dev.argtypes = [vp, i32, vp, vp, vp, sz]
-    lib.bh_test_msm_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp]
+    lib.bh_msm_debug_stages.argtypes = [vp, vp, sz, i32, c.c_uint, vp, vp]
+    lib.bh_msm_wait_stats.argtypes = [vp, vp, c.POINTER(c.c_float), c.POINTER(c.c_uint64)]
     lib.bh_test_g2_k3_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     lib.bh_test_g2_pairs_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_fr_mul_bform_host"):

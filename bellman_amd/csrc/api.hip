@@ -26,7 +26,8 @@ MsmJobImpl *msm_job_new(Context *ctx, int group);
 void msm_job_delete(MsmJobImpl *j);
 int msm_job_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev, u64 n,
                     int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table);
-int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms);
+int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms, u64 *stats8 = nullptr);
+int msm_debug_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out, u32 *zstart_out);
 void msm_job_track(MsmJobImpl &job);
 int msm_job_start(MsmJobImpl &job);
 bool msm_slot_try_reserve(Context &c);
@@ -1245,6 +1246,30 @@ int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4) {
   msm_job_delete(job->impl);
   delete job;
   return rc;
+}
+int bh_msm_wait_stats(bh_msm_job *job, void *out_affine, float *stage_ms4, uint64_t *stats8) {
+  if (!job) return BH_ERR_INVALID_ARG;
+  float ms[4] = {0, 0, 0, 0};
+  u64 st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int rc = msm_job_finish(*job->impl, out_affine, ms, st);
+  if (stage_ms4) memcpy(stage_ms4, ms, sizeof ms);
+  if (stats8) memcpy(stats8, st, sizeof st);
+  msm_job_delete(job->impl);
+  delete job;
+  return rc;
+}
+int bh_msm_plan_info(size_t n, int group, unsigned forced_c, unsigned *out9) {
+  if (!out9 || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
+  const MsmPlan p = make_plan(n, forced_c, 0, group == BH_G2);
+  out9[0] = p.c; out9[1] = p.W; out9[2] = p.nb; out9[3] = p.chunk; out9[4] = p.chunks_per_window; out9[5] = p.sort_passes;
+  out9[6] = p.lo_bits; out9[7] = p.hi_bits; out9[8] = (unsigned)((u64)p.W * p.n);
+  return BH_OK;
+}
+int bh_msm_debug_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
+                        uint64_t *pairs_out_host, uint32_t *zstart_out_host) {
+  if (!ctx || !scalars_host || !n || !pairs_out_host || !zstart_out_host) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return msm_debug_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, zstart_out_host);
 }
 int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms) {
   float ms[4];

@@ -373,9 +373,11 @@ static int with_demo_circuit(int circuit_kind, size_t size, uint64_t seed, const
 
 extern "C" {
 
+#ifndef BH_DEMO_TIMED_BUILD
 void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi) {
   groth16::proof_slice_for_tests(n, part, parts, lo, hi);
 }
+#endif
 double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mode) {
   // host-only timing of circuit synthesis (no device involved): mode 0 = ProvingAssignment (the
   // reference's structure: every linear combination evaluated on the host), 1 = WitnessAssignment
@@ -414,6 +416,7 @@ double bh_test_synthesis_ms(int circuit_kind, size_t size, uint64_t seed, int mo
   });
   return ms;
 }
+#ifndef BH_DEMO_TIMED_BUILD   // (fixtures and host-side hooks: the checked test library only)
 double bh_test_capture_check(int circuit_kind, size_t size, uint64_t seed, size_t out4[4]) {
   // host only: the structure capture (R1cs's constructor without the upload) of a demo circuit, checked against the
   // ProvingAssignment of the same circuit - captured A, B, C times the assignment == its a, b, c rows
@@ -485,6 +488,7 @@ void bh_test_fr_ops_host(int op, void *r, const void *a, const void *b, size_t n
     memcpy((char *)r + 32 * i, &z, 32);
   }
 }
+#endif
 int bh_groth16_demo_r1cs(bh_ctx *ctx, int circuit_kind, size_t size, uint64_t seed, const void *constants, bh_r1cs **out) {
   if (!ctx || !out) return BH_ERR_INVALID_ARG;
   return with_demo_circuit(circuit_kind, size, seed, nullptr, constants, [&](bellman::Circuit &c) -> int {

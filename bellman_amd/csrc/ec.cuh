@@ -143,8 +143,9 @@ BH_HD void order_after(T &v) {
   (void)v;
 #endif
 }
+// Returns false when acc was the identity (the "addition" is a copy), true when a group addition was executed.
 template <class F, class PF>
-BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
+BH_HD bool xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   typedef typename F::T T;
   if (xyzz_is_identity(acc)) {
     acc.x = q.x;
@@ -152,7 +153,7 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
     F::one(acc.zz);
     F::one(acc.zzz);
     prefetch();
-    return;
+    return false;
   }
   T p, r, pp, ppp, qq, t;
   F::mul(p, q.x, acc.zz);
@@ -166,7 +167,7 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
       xyzz_set_identity(acc);   // opposite points
     }
     prefetch();
-    return;
+    return true;
   }
   // ordered so that at most four temporaries are live at once (PP and PPP die early): the G2
   // instantiation is register-bound
@@ -196,16 +197,17 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
     F::mul_tail(qq, r, qq);             // R*(Q - X3)            (r dead); inline, see above
     F::sub(acc.y, qq, ppp);
   }
+  return true;
 }
 template <class F>
-BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
+BH_HD bool xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
   typedef typename F::T T;
   if (xyzz_is_identity(acc)) {
     acc.x = q.x;
     acc.y = q.y;
     F::one(acc.zz);
     F::one(acc.zzz);
-    return;
+    return false;
   }
   T p, r, pp, ppp, qq, t;
   F::mul(p, q.x, acc.zz);
@@ -218,7 +220,7 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
     } else {
       xyzz_set_identity(acc);   // opposite points
     }
-    return;
+    return true;
   }
   F::sqr(pp, p);
   F::mul(ppp, p, pp);                 // p dead
@@ -239,6 +241,7 @@ BH_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q) {
     F::sub(acc.y, qq, ppp);
   }
   acc.x = t;
+  return true;
 }
 
 // add-2008-s: r = a + b (general)

@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <thread>
+#include <vector>
 
 #include "msm_types.hpp"
 
@@ -168,11 +169,12 @@ bool msm_complete_oldest(Context &c) {
   pick->mu.unlock();
   return true;
 }
-int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
+int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms, u64 *stats8) {
   if (job.trivial) {
     const size_t rec = job.group == BH_G1 ? 96 : 192;
     if (job.has_result) memcpy(out_affine, job.result, rec); else memset(out_affine, 0, rec);
     if (ms) ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+    if (stats8) memset(stats8, 0, 8 * sizeof(u64));
     return job.early_rc;
   }
   msm_job_untrack(job);   // first: a back-pressure scan that has not picked the job yet will never see it
@@ -180,7 +182,37 @@ int msm_job_finish(MsmJobImpl &job, void *out_affine, float *ms) {
   msm_job_complete_locked(job);
   memcpy(out_affine, job.done_out, job.group == BH_G1 ? 96 : 192);
   if (ms) memcpy(ms, job.done_ms, sizeof job.done_ms);
+  if (stats8) memcpy(stats8, job.done_stats, sizeof job.done_stats);
   return job.done_rc;
+}
+// bring-up / verification aid (bh_msm_debug_stages): stages 1-3 only - signed digits, radix sort, zero-digit count -
+// with the sorted (digit, base) pairs and the per-window zero counts copied to the host
+int msm_debug_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out, u32 *zstart_out) {
+  const MsmPlan p = make_plan(n, cbits, 0, false);
+  hipStream_t st = c.stream;
+  const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
+  MsmBuffers b;
+  std::vector<void *> owned;
+  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); owned.push_back(q); return q; };
+  void *sc = alloc(n * 32);
+  b.pairs_a = (u64 *)alloc(npairs * 8);
+  b.pairs_b = (u64 *)alloc(npairs * 8);
+  b.counts = (u32 *)alloc(ncounts * 4);
+  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
+  b.zstart = (u32 *)alloc((u64)p.W * 4);
+  b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
+  b.word_prefix = nullptr;
+  int rc = BH_OK;
+  for (void *q : owned) if (!q) rc = BH_ERR_HIP;
+  const u64 *sorted = nullptr;
+  if (rc == BH_OK && hipMemcpyAsync(sc, scalars_host, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemsetAsync(b.err, 0, sizeof(ErrFlags), st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK) rc = msm_run_stages(p, b, sc, fmt, nullptr, 0, n, st, &sorted);
+  if (rc == BH_OK && hipMemcpyAsync(pairs_out, sorted, npairs * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (rc == BH_OK && hipMemcpyAsync(zstart_out, b.zstart, (u64)p.W * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  for (void *q : owned) if (q) c.pool.release(q);
+  return rc;
 }
 int fixed_base_mul(int group, const void *base_host, const void *scalars_dev, u64 n, int fmt, void *out_dev,
                    hipStream_t st, void *table_dev) {

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   xyzz_set_identity(acc);
   u32 cur = v.d_first;
   bool saw_identity = false;
+  u32 adds = 0;   // additions into a non-empty accumulator (the rest of the chunk's entries are copies): bh_msm_wait_stats
   // Software pipeline (one lane per G2 point only: the kernels that fit two wavefronts per SIMD would lose the second
   // one to the extra live registers, and the second wavefront already covers their loads): the entry two steps
   // ahead and the base point one step ahead are loaded by `prefetch`, which xyzz_madd calls right before its last
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
         prefetch();
       } else {
         if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
-        xyzz_madd(acc, q, prefetch);
+        adds += xyzz_madd(acc, q, prefetch) ? 1u : 0u;
       }
       q = qn;
       e = e1;
@@ -197,11 +198,16 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
       load_affine<F>(q, base_at((u32)e & 0x7fffffffu));
       if (aff_is_identity(q)) { saw_identity = true; continue; }
       if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
-      xyzz_madd(acc, q);
+      adds += xyzz_madd(acc, q) ? 1u : 0u;
     }
   }
   store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : v.tail_partial ? &tail[slot] : &bucket[cur], acc);
   if (saw_identity) atomicOr(&err->ident, 1u);
+  // (one address for the whole launch: the compiler's atomic optimizer folds a wavefront's adds into one atomic)
+  if (worker_role<F>() == 0) {
+    atomicAdd(&err->madds, (unsigned long long)adds);
+    if (lane == 0) atomicAdd(&err->zeros, (unsigned long long)z);
+  }
 }
 
 // ============================================================================================
@@ -1391,6 +1397,11 @@ static int msm_finish(MsmJobImpl &job, void *out_affine, float *ms) {
     }
     job.saw_eof = ef.eof != 0;
     job.saw_ident = ef.ident != 0;
+    // [0] sorted entries  [1] zero digits among them  [2] mixed additions of the accumulate launch  [3] chunk lanes
+    // [4] window bits c  [5] chunk length K  [6] windows W (1: window-table plan)  [7] digit columns per scalar
+    job.done_stats[0] = (u64)p.W * p.n; job.done_stats[1] = ef.zeros; job.done_stats[2] = ef.madds;
+    job.done_stats[3] = (u64)p.W * p.chunks_per_window; job.done_stats[4] = p.c; job.done_stats[5] = p.chunk;
+    job.done_stats[6] = p.W; job.done_stats[7] = p.Wd;
     if (ef.ident && (ef.eof || job.always_resolve_ident)) {
       // both kinds of failure exist (or the caller folds shards): the reference reports the top window's first failure
       const u64 nref = job.ref_n ? job.ref_n : p.nd;

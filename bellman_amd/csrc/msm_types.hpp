@@ -10,8 +10,10 @@ struct ErrFlags {       // device-side status word block
   u32 ident_top;        // ... in the reference's top window, before the first EOF entry
   u32 nlong;            // number of bucket runs queued for the wavefront-parallel merge
   u32 nbig;             // ... of those, runs long enough to be passed on to the workgroup-parallel merge
-  u32 npieces;          // ... and the workgroup-sized pieces they were cut into (msm_merge_long_kernel)
-  u32 pad[2];
+  u32 npieces;          // ... and the workgroup-sized pieces they were cut into (msm_merge_tail_kernel)
+  // what the job executed (bh_msm_wait_stats): mixed additions into a non-empty accumulator by the accumulate launch
+  // (entries that OPEN a bucket or a chunk partial are copies, ec.cuh xyzz_madd), zero digits the sort moved to the front
+  unsigned long long madds, zeros;
 };
 
 enum { SUM_STRIDED = 1, SUM_BITS = 2 };
@@ -109,6 +111,7 @@ struct MsmJobImpl {
   bool done = false;
   int done_rc = BH_OK;
   float done_ms[4] = {0, 0, 0, 0};
+  u64 done_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bh_msm_wait_stats
   alignas(16) unsigned char done_out[192];
 };
 

@@ -24,36 +24,6 @@ static int test_fe_mul(void *r, const void *a, const void *b, u64 n, hipStream_t
   BH_HIP_CHECK(hipGetLastError());
   return BH_OK;
 }
-// bring-up aid: MSM stages 1-3 only (digits, radix sort, zero-digit count), results copied to the host
-static int test_msm_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsigned cbits, u64 *pairs_out,
-                    u32 *zstart_out) {
-  const MsmPlan p = make_plan(n, cbits, 0, false);
-  hipStream_t st = c.stream;
-  const u64 npairs = (u64)p.W * n, ncounts = (u64)p.W * 256 * p.num_tiles;
-  MsmBuffers b;
-  std::vector<void *> owned;
-  auto alloc = [&](size_t bytes) { void *q = c.pool.acquire(bytes); owned.push_back(q); return q; };
-  void *sc = alloc(n * 32);
-  b.pairs_a = (u64 *)alloc(npairs * 8);
-  b.pairs_b = (u64 *)alloc(npairs * 8);
-  b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
-  b.zstart = (u32 *)alloc((u64)p.W * 4);
-  b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
-  b.word_prefix = nullptr;
-  int rc = BH_OK;
-  for (void *q : owned) if (!q) rc = BH_ERR_HIP;
-  const u64 *sorted = nullptr;
-  if (rc == BH_OK && hipMemcpyAsync(sc, scalars_host, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemsetAsync(b.err, 0, sizeof(ErrFlags), st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK) rc = msm_run_stages(p, b, sc, fmt, nullptr, 0, n, st, &sorted);
-  if (rc == BH_OK && hipMemcpyAsync(pairs_out, sorted, npairs * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (rc == BH_OK && hipMemcpyAsync(zstart_out, b.zstart, (u64)p.W * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BH_ERR_HIP;
-  if (hipStreamSynchronize(st) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
-  for (void *q : owned) c.pool.release(q);
-  return rc;
-}
-
 }  // namespace bh
 
 // ---- test hook: the group law in the multi-lane forms on its own (tests/test_gpu_parity.py::test_g2_k3_group_law,
@@ -154,10 +124,6 @@ int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, v
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   return test_g2_pairs(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
 }
-int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *zstart_out_host) {
-  return test_msm_stages(ctx->c, scalars_host, n, scalar_fmt, c, (u64 *)pairs_out_host, zstart_out_host);
-}
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fr_t *)r)[i], ((const fr_t *)a)[i], ((const fr_t *)b)[i]);
 }
@@ -171,15 +137,6 @@ void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n) 
 }
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n) {
   for (size_t i = 0; i < n; i++) fe_mul(((fp_t *)r)[i], ((const fp_t *)a)[i], ((const fp_t *)b)[i]);
-}
-int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9) {
-  // host only: the plan make_plan picks - out9 = c, W, buckets per window, K, chunks per window, sort passes,
-  // lo_bits, hi_bits, pairs (W*n) low 32 bits
-  if (!out9 || (group != BH_G1 && group != BH_G2)) return BH_ERR_INVALID_ARG;
-  const MsmPlan p = make_plan(n, forced_c, 0, group == BH_G2);
-  out9[0] = p.c; out9[1] = p.W; out9[2] = p.nb; out9[3] = p.chunk; out9[4] = p.chunks_per_window; out9[5] = p.sort_passes;
-  out9[6] = p.lo_bits; out9[7] = p.hi_bits; out9[8] = (unsigned)((u64)p.W * p.n);
-  return BH_OK;
 }
 int bh_test_fp_lazy_host(int op, void *r, const void *a, const void *b) {
   // the lazily reduced Fp helpers of the curve code (ff.cuh), compiled for the host; operands in [0, 2p)

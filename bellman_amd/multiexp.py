@@ -187,14 +187,19 @@ class MsmOpts(ctypes.Structure):
 ACC_REGISTERS, ACC_LDS, NO_TABLE, NO_SMALL_PATH, G2_SINGLE_LANE, G2_LANE_TRIPLES, STAGE_TIMES, HOLD, G2_LANE_PAIRS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
+STATS_FIELDS = ("sorted_entries", "zero_digits", "mixed_additions", "chunk_lanes", "window_bits", "chunk", "bucket_sets", "digit_columns")
+
+
 def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=False, scalars_dev=None, n=None,
-             density_dev=None, window_bits=0, chunk=0, flags=0):
+             density_dev=None, window_bits=0, chunk=0, flags=0, stats=False):
     """multiexp(pool, (bases, skip), density_map, exponents) -> Waiter (src/multiexp.rs:305-332).
 
     exponents: [n,4] uint64 scalars on the host; or pass scalars_dev (device pointer) + n.
     The Waiter's wait() returns the affine result record (numpy uint64[12|24]) or raises the
-    SynthesisError the reference would return.  With timed=True it returns (record, [total, sort, accumulate, reduce] device ms).
-    window_bits / chunk / flags override the plan of THIS job only (tests, tuning sweeps)."""
+    SynthesisError the reference would return.  With timed=True it returns (record, [total, sort, accumulate, reduce] device ms);
+    with stats=True (implies timed) a third element: what the job executed, counted on the device (bh_msm_wait_stats,
+    a dict over STATS_FIELDS).  window_bits / chunk / flags override the plan of THIS job only (tests, tuning sweeps)."""
+    timed = timed or stats
     lib = _lib.load()
     words = None
     dlen = 0
@@ -220,6 +225,10 @@ def multiexp(pool, bases, density_map, exponents, skip=0, mont=False, timed=Fals
     def finish():
         out = np.zeros(w, dtype=np.uint64)
         ms = (ctypes.c_float * 4)()
+        if stats:
+            st = (ctypes.c_uint64 * 8)()
+            check(lib.bh_msm_wait_stats(job, out.ctypes.data_as(ctypes.c_void_p), ms, st), "multiexp.wait")
+            return out, list(ms), dict(zip(STATS_FIELDS, (int(x) for x in st)))
         check(lib.bh_msm_wait_profile(job, out.ctypes.data_as(ctypes.c_void_p), ms), "multiexp.wait")
         return (out, list(ms)) if timed else out
 

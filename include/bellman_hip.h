@@ -233,6 +233,22 @@ int bh_msm_wait_timed(bh_msm_job *job, void *out_affine, float *device_ms);
  * [0] whole pipeline  [1] digits + radix sort + task list  [2] bucket accumulation  [3] reductions;
  * zeros unless the job was issued with BH_MSM_STAGE_TIMES in bh_msm_opts.flags */
 int bh_msm_wait_profile(bh_msm_job *job, void *out_affine, float *stage_ms4);
+/* ... and with what the job EXECUTED, counted on the device (every job; no flag needed):
+ * [0] sorted (digit, base) entries = windows x terms   [1] zero digits among them (skipped after the sort)
+ * [2] mixed additions the accumulate launch performed into a non-empty accumulator - the entries that open a bucket or a
+ *     chunk partial are copies (src/multiexp.rs:256-258 adds into an identity bucket likewise)
+ * [3] chunk lanes of the accumulate launch   [4] window bits c   [5] chunk length K   [6] bucket sets W (1 = window-table
+ * plan)   [7] digit columns per scalar.  What bench.py's roofline.alu and its check of the PMC files are computed from. */
+int bh_msm_wait_stats(bh_msm_job *job, void *out_affine, float *stage_ms4, uint64_t *stats8);
+/* The plan a multiexp of n terms over unregistered bases would run (host only, no context): out9 = c, windows, buckets
+ * per window, K, chunks per window, sort passes, lo bits, hi bits of the two-dimensional bucket reduction, low 32 bits of
+ * windows x n.  forced_c = 0: the tuned window size. */
+int bh_msm_plan_info(size_t n, int group, unsigned forced_c, unsigned *out9);
+/* Verification aid: runs the digit and sort stages of a G1 multiexp for window size c on n host scalars (src/multiexp.rs:
+ * 159-208, 281-286: Exponent, chunks) and copies the sorted (|digit| << 32 | sign << 31 | index) pairs [windows * n] and
+ * the per-window number of zero digits [windows] to the host. */
+int bh_msm_debug_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
+                        uint64_t *pairs_out_host, uint32_t *zstart_out_host);
 /* r[i] = a[i] + b[i] for affine records on the HOST - used to fold the per-GPU partial results of
  * a base-sharded MSM after the all-gather, and g_a/g_b/g_c in create_proof. */
 void bh_point_add(int group, void *r, const void *a, const void *b, size_t n);

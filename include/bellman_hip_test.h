@@ -53,10 +53,6 @@ int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void
 /* the same in the lane-pair form (csrc/fp2pair.cuh: schoolbook Fp2 products, one reduction per lane) */
 int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
                          const void *b_dev, size_t n);
-/* runs MSM stages 1-3 (digits, radix sort, zero-digit count) for window size c and copies the
- * sorted (digit<<32|base) pairs [W*n] and the per-window count of zero digits [W] back (bring-up aid) */
-int bh_test_msm_stages(bh_ctx *ctx, const void *scalars_host, size_t n, int scalar_fmt, unsigned c,
-                       uint64_t *pairs_out_host, uint32_t *zstart_out_host);
 /* host-side (CPU) versions of the same arithmetic headers, for toolchain-only unit tests */
 void bh_test_fr_mul_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_fp_mul_host(void *r, const void *a, const void *b, size_t n);
@@ -64,10 +60,7 @@ void bh_test_fr_mul_bform_host(void *r, const void *a, const void *b, size_t n);
 void bh_test_point_add_host(int group, void *r, const void *a, const void *b, size_t n);
 void bh_test_point_mul_host(int group, void *r, const void *a, const void *k_canonical);
 void bh_test_fr_inv_host(void *r, const void *a, size_t n); /* Montgomery in/out */
-/* host only: the MSM plan for n terms (out9 = c, W, buckets per window, K, chunks per window, sort passes,
- * lo_bits, hi_bits, low 32 bits of W*n) and the scalar-index slice [lo, hi) that part `part` of `parts`
- * of a sharded proof computes */
-int bh_test_msm_plan(size_t n, int group, unsigned forced_c, unsigned *out9);
+/* host only: the scalar-index slice [lo, hi) that part `part` of `parts` of a sharded proof computes */
 void bh_test_proof_slice(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi);
 /* lazily reduced Fp helpers of the curve kernels, host build: op 0 add, 1 sub, 2 neg, 3 canonicalise,
  * 4 is_zero (returned), 5 product, 6 square, 7 eq (returned); operands are 48-byte values in [0, 2p) */

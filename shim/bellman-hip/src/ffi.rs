@@ -148,6 +148,9 @@ extern "C" {
     pub fn bh_msm_wait(job: *mut BhMsmJob, out_affine: *mut c_void) -> c_int;
     pub fn bh_msm_wait_timed(job: *mut BhMsmJob, out_affine: *mut c_void, device_ms: *mut f32) -> c_int;
     pub fn bh_msm_wait_profile(job: *mut BhMsmJob, out_affine: *mut c_void, stage_ms4: *mut f32) -> c_int;
+    pub fn bh_msm_wait_stats(job: *mut BhMsmJob, out_affine: *mut c_void, stage_ms4: *mut f32, stats8: *mut u64) -> c_int;
+    pub fn bh_msm_plan_info(n: usize, group: c_int, forced_c: c_uint, out9: *mut c_uint) -> c_int;
+    pub fn bh_msm_debug_stages(ctx: *mut BhCtx, scalars_host: *const c_void, n: usize, scalar_fmt: c_int, c: c_uint, pairs_out_host: *mut u64, zstart_out_host: *mut u32) -> c_int;
     pub fn bh_point_add(group: c_int, r: *mut c_void, a: *const c_void, b: *const c_void, n: usize);
     pub fn bh_point_mul(group: c_int, r: *mut c_void, a: *const c_void, k_canonical: *const c_void);
     pub fn bh_point_lincomb(group: c_int, r: *mut c_void, points: *const c_void, scalars_canonical: *const c_void, n: usize);

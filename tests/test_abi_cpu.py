@@ -36,9 +36,19 @@ def _exported_c_symbols(path):
     return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and not ln.split()[2].startswith("_")}
 
 
+def _all_dynamic_symbols(path):
+    """every symbol a shared library DEFINES in its dynamic symbol table, whatever its type (functions, objects, weak C++)"""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+
+
 def test_header_symbols_all_exported(lib):
     """[r4] libbellman_hip.so exports EXACTLY the C symbols include/bellman_hip.h declares; the test hooks and the
-    built-in demo circuits (include/bellman_hip_test.h) live in libbellman_hip_test.so, which links against it."""
+    built-in demo circuits (include/bellman_hip_test.h) live in libbellman_hip_test.so, which links against it.
+    [r6] ... and NOTHING else: no mangled C++ internal is in any library's dynamic symbol table (csrc/libbellman_hip.map);
+    the test library gets the C++ host API from the static archive libbellman_groth16.a and everything else through the C ABI."""
     hdr = open(os.path.join(ROOT, "include", "bellman_hip.h")).read()
     declared = set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
@@ -50,6 +60,15 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.EXPORTS) and hooks == set(_lib.TEST_EXPORTS)
     assert _exported_c_symbols(_lib.LIB_PATH) == declared
     assert _exported_c_symbols(_lib.TEST_LIB_PATH) == hooks
+    assert _all_dynamic_symbols(_lib.LIB_PATH) == declared, sorted(_all_dynamic_symbols(_lib.LIB_PATH) - declared)[:10]
+    assert _all_dynamic_symbols(_lib.TEST_LIB_PATH) == hooks
+    assert _all_dynamic_symbols(_lib.DEMO_LIB_PATH) == set(_lib.DEMO_EXPORTS)
+    # the test and demo libraries import nothing from the product but its C ABI
+    import subprocess
+    for path in (_lib.TEST_LIB_PATH, _lib.DEMO_LIB_PATH):
+        und = subprocess.run(["nm", "-D", "--undefined-only", "-C", path], capture_output=True, text=True, check=True).stdout
+        internals = [ln for ln in und.splitlines() if " bh::" in ln or " groth16::" in ln or " bellman::" in ln]
+        assert not internals, internals[:5]
     for sym in declared:
         assert hasattr(lib.product, sym), sym
     for sym in hooks:
@@ -363,7 +382,7 @@ def test_msm_plan_invariants_host():
         for lg in range(0, 27):
             for n in {1 << lg, (1 << lg) + 1, max(1, (1 << lg) - 1)}:
                 for forced in (0, 2, 7, 13, 16, 24):
-                    assert lib.bh_test_msm_plan(n, group, forced, out.ctypes.data_as(ctypes.c_void_p)) == 0
+                    assert lib.bh_msm_plan_info(n, group, forced, out.ctypes.data_as(ctypes.c_void_p)) == 0
                     c_, W, nb, K, cpw, passes, lo, hi, pairs = (int(x) for x in out)
                     assert 2 <= c_ <= 24 and (forced == 0 or c_ == forced)
                     assert W == -(-256 // c_) and W * c_ >= 256 and nb == 1 << (c_ - 1)
@@ -444,3 +463,18 @@ def test_montgomery_reduction_whole_columns_with_maximal_limbs(lib):
         want = a * b * pow(Rq, -1, q) % q
         assert val(r) == want and val(r2) == want, (hex(a), hex(b))
 
+
+
+def test_plain_c_caller_builds_and_passes_host_checks(tmp_path):
+    """tests/c/abi_smoke.c: a C11 translation unit (gcc, no C++) against include/bellman_hip.h and libbellman_hip.so -
+    the version string, the plan query, the host-side group operations and BH_ERR_NO_DEVICE without a GPU
+    (its `gpu` mode runs in tests/test_gpu_c_abi.py)."""
+    import subprocess
+
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lbellman_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "host checks passed" in r.stdout, r.stdout + r.stderr

@@ -323,7 +323,7 @@ def test_msm_sort_stages(worker, n, c):
     half = 1 << (c - 1)
     pairs = np.zeros(W * n, dtype=np.uint64)
     zstart = np.zeros(W, dtype=np.uint32)
-    assert lib.bh_test_msm_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(zstart)) == 0
+    assert lib.bh_msm_debug_stages(worker.ctx, _p(sc), n, 0, c, _p(pairs), _p(zstart)) == 0
     ints = cref.arr_to_ints(sc)
     # signed-digit recoding: d in [-(2^(c-1)-1), 2^(c-1)], sum d_w 2^(c w) == scalar
     mags = np.zeros((W, n), dtype=np.uint64)

@@ -139,7 +139,7 @@ def test_mirror_under_sanitizers(tmp_path):
     exe = str(tmp_path / "mirror_sanitized.bin")
     cmd = [cxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-mbmi2", "-madx", "-std=c++17",
            os.path.join(ROOT, "tests", "cpp", "mirror_sanitized.cpp")] + \
-          [os.path.join(csrc, f) for f in ("demo_circuits.cpp", "groth16_prover.cpp", "groth16_fr.cpp")] + \
+          [os.path.join(csrc, f) for f in ("demo_circuits.cpp", "groth16_prover.cpp", "groth16_fr.cpp", "groth16_params.cpp")] + \
           ["-o", exe, "-L" + libdir, "-lbellman_hip", "-Wl,-rpath," + libdir]
     build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if build.returncode != 0 and "sanitizer" in (build.stderr + build.stdout).lower():
