@@ -47,6 +47,11 @@ BYTES_PER_TERM_G1 = 128  # 96 B affine base + 32 B scalar, each read once (SURVE
 # (91 + 182).  Since round 4 the last line Y3 = R*(Q - X3) - Y1*PPP is two products under ONE reduction (ff.cuh fe_mul2):
 # one reduction (169 + 13) fewer per addition - the numerator of roofline.alu shrinks with it.
 MADS_PER_MIXED_ADD = 8 * 351 + 2 * 273 - 182
+# Algorithmic figures of the other kernels, for the roofline objects of the fft and create_proof blocks:
+MADS_PER_FR_BUTTERFLY = 153          # one Fr product with a pre-sliced twiddle (ff.cuh: 81 + 72 mads), one per butterfly
+MADS_PER_MIXED_ADD_G2 = 3 * MADS_PER_MIXED_ADD   # an Fp2 product is three Fp products by Karatsuba: the algorithmic count
+MAD_PEAK_T = 26.2                    # v_mad_u64_u32 ceiling of the chip, T/s (profiles/r1_microbench_int.txt)
+BYTES_PER_TERM_G2 = 224
 
 
 def splitmix_scalars(n, seed):
@@ -78,13 +83,32 @@ G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1
 )
 
 
-def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
+def proof_roofline(log_n, n_aux, a_dense, b_dense, device_ms):
+    """Algorithmic work of ONE create_proof (prover.rs:217-318) against the span of its device part: the five large
+    multiexps (h: m - 1 terms, l: n_aux, a_aux / b_g1 / b_g2: the dense entries of their queries) as 16 windows x terms
+    mixed additions, the 7 FFTs as (m / 2) log m butterflies, bytes per SURVEY.md 8(d)."""
+    m = 1 << log_n
+    g1_terms = (m - 1) + n_aux + a_dense + b_dense
+    mads = 16 * g1_terms * MADS_PER_MIXED_ADD + 16 * b_dense * MADS_PER_MIXED_ADD_G2 + 7 * (m // 2) * log_n * MADS_PER_FR_BUTTERFLY
+    nbytes = g1_terms * BYTES_PER_TERM_G1 + b_dense * BYTES_PER_TERM_G2 + 7 * 64 * m + 128 * m
+    t = device_ms * 1e-3
+    return {"bound": "alu", "unit": "Tmad/s", "peak": MAD_PEAK_T, "achieved": round(mads / t / 1e12, 2), "frac": round(mads / t / 1e12 / MAD_PEAK_T, 4),
+            "device_ms": round(device_ms, 2),
+            "work": "16 windows x (h %d + l %d + a_aux %d + b_g1 %d) G1 mixed additions x %d mads + 16 x %d G2 mixed additions x %d "
+                    "(three Fp products per Fp2 product) + 7 FFTs x (m/2) log m butterflies x %d; the input multiexps, the fused "
+                    "quotient and the constraint evaluation not counted" % (m - 1, n_aux, a_dense, b_dense, MADS_PER_MIXED_ADD, b_dense,
+                                                                            MADS_PER_MIXED_ADD_G2, MADS_PER_FR_BUTTERFLY),
+            "hbm": {"algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / t / 1e9, 1), "frac_of_8TBps": round(nbytes / t / 8e12, 5)}}
+
+
+def bench_create_proof(worker, lib, log_n, proofs=10, cpu_baseline=True):
     """BASELINE config C4: groth16::create_proof on a synthetic 2^log_n-constraint R1CS (the C++
     chain circuit of groth16_capi.cpp).  The CRS is a real one for this circuit, made by the product's
     device generator (generate_parameters, generator.rs:163-510) from fixed toxic waste - as the
     reference's own tests do (groth16/src/tests/mod.rs:93-99); not a secure setup."""
     from bellman_amd import groth16 as pg
 
+    lib.use_unchecked_demo_circuits()   # the timed legs run the demo circuits built WITHOUT closure checks (csrc/Makefile)
     rounds = (1 << log_n) - 3
     CIRCUIT_SEED = 2020
     t0 = time.perf_counter()
@@ -193,15 +217,15 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
     for name, patched in (("create_proof_via_patched_call_sites", True), ("create_proof_via_multiexp_and_fft_call_sites_only", "resident"),
                           ("create_proof_via_multiexp_and_fft_call_sites_only_round4_patch", False)):
         ws = []
-        for i in range(proofs + 1):
+        for i in range((proofs if patched else min(proofs, 3)) + 1):
             t0 = time.perf_counter()
             got = pg.prove_via_call_sites(params, asg, 0xABCDEF0123 + proofs, 0x123456789AB, patched)
             if i:
                 ws.append((time.perf_counter() - t0) * 1e3)
         assert got.a.tobytes() == last.a.tobytes() and got.b.tobytes() == last.b.tobytes() and got.c.tobytes() == last.c.tobytes(), \
             name + ": proof differs from bh_groth16_prove_assignment"
-        call_sites[name] = {"ms_after_synthesis": round(float(np.mean(ws)), 2), "proofs_per_s_after_synthesis": round(1e3 / float(np.mean(ws)), 3),
-                            "samples": proofs}
+        call_sites[name] = {"ms_after_synthesis": round(float(np.median(ws)), 2), "proofs_per_s_after_synthesis": round(1e3 / float(np.median(ws)), 3),
+                            "samples": len(ws)}
     call_sites["create_proof_via_patched_call_sites"]["calls"] = (
         "groth16/src/prover.rs patched: bh_scalars_register x2 (Montgomery, shared by the multiexps that use them), "
         "bh_msm_async_scalars x8, bh_h_poly_fr_scalars x1 (h coefficients stay in HBM), bh_msm_wait x8; host tail prover.rs:320-360")
@@ -214,7 +238,7 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "the round-4 form of that patch level: 7 x bh_fft_fr on host vectors (upload + download each), mul/sub/divide_by_z "
         "on the host (one chunk per host thread), serial Fr -> Exponent passes (prover.rs:241-261), 8 x bh_msm_async with "
         "canonical host scalars (each uploads its vector again)")
-    call_sites["bh_groth16_prove_assignment_same_inputs"] = {"ms_after_synthesis": round(float(np.mean(ref_tm)), 2)}
+    call_sites["bh_groth16_prove_assignment_same_inputs"] = {"ms_after_synthesis": round(float(np.median(ref_tm)), 2)}
     call_sites["note"] = ("all four proofs asserted bit-identical; host synthesis (ms_host_synthesis above) precedes each of them "
                           "in a real create_proof")
     cpu = None
@@ -246,8 +270,11 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         }
     r1cs.release()
     params.release()
-    m = np.mean(np.array(tms), axis=0)
-    mr = np.mean(np.array(tms_r), axis=0)
+    m = np.median(np.array(tms), axis=0)
+    mr = np.median(np.array(tms_r), axis=0)
+    pop = lambda words: int(np.unpackbits(words.view(np.uint8)).sum())  # noqa: E731
+    n_aux = asg["aux_assignment"].shape[0]
+    roof = proof_roofline(log_n, n_aux, pop(asg["a_aux_density"]), pop(asg["b_aux_density"]), float(mr[4]) - float(mr[0]))
     return {
         "workload": "groth16::create_proof, synthetic multiplicative-chain R1CS, 2^%d constraints, 1 public input "
                     "(BASELINE.json configs[3]): 7 FFTs + fused quotient, 4 large G1 + 1 large G2 multiexp (+3 small)" % log_n,
@@ -261,6 +288,9 @@ def bench_create_proof(worker, lib, log_n, proofs=3, cpu_baseline=True):
         "proofs_per_s_concurrent": round(conc, 3),
         "concurrent_host_threads": threads,
         "samples": proofs,
+        "statistic": "median of %d proofs after one warm-up (round 5: mean of 3); demo circuits from libbellman_hip_demo.so, "
+                     "built without BELLMAN_HIP_CHECK_CLOSURES" % proofs,
+        "roofline": roof,
         "cpu_baseline": cpu,
         "drop_in_call_sites": call_sites,
         "crs": "generate_parameters on the device from fixed toxic waste: %.0f ms (h, l, a, b_g1, b_g2 = %d G1 + %d G2 "
@@ -404,8 +434,19 @@ def bench_fft(worker, lib, log_n=22, iters=10):
         worker.synchronize()
         dt = (time.perf_counter() - t0) / iters
         out[name] = {"ms": round(dt * 1e3, 4), "algorithmic_GBps": round(64.0 * n / dt / 1e9, 1),
-                     "frac_of_8TBps": round(64.0 * n / dt / 8e12, 4), "Gbutterflies_per_s": round(n / 2 * log_n / dt / 1e9, 1)}
+                     "frac_of_8TBps": round(64.0 * n / dt / 8e12, 4), "Gbutterflies_per_s": round(n / 2 * log_n / dt / 1e9, 1),
+                     "Tmad_per_s": round(n / 2 * log_n * MADS_PER_FR_BUTTERFLY / dt / 1e12, 2),
+                     "frac_of_mad_ceiling": round(n / 2 * log_n * MADS_PER_FR_BUTTERFLY / dt / 1e12 / MAD_PEAK_T, 4)}
     worker.free(d)
+    worst = max(out[k]["ms"] for k in ("fft", "ifft", "coset_fft", "icoset_fft"))
+    out["roofline"] = {
+        "kernel": "ntt_pass_kernel (two launches per transform at 2^22)", "statistic": "the slowest of the four modes",
+        "hbm": {"bound": "hbm", "achieved": round(64.0 * n / (worst * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(64.0 * n / (worst * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes": "64 B per element: one read + one write (SURVEY.md 8d)"},
+        "alu": {"bound": "alu", "achieved": round(n / 2 * log_n * MADS_PER_FR_BUTTERFLY / (worst * 1e-3) / 1e12, 2), "peak": MAD_PEAK_T, "unit": "Tmad/s",
+                "frac": round(n / 2 * log_n * MADS_PER_FR_BUTTERFLY / (worst * 1e-3) / 1e12 / MAD_PEAK_T, 4),
+                "work": "(n / 2) log2 n butterflies x one Fr product of %d v_mad_u64_u32 (pre-sliced twiddle); the inter-pass twiddle, "
+                        "coset and 1/n products the passes also execute are not counted: the algorithmic minimum" % MADS_PER_FR_BUTTERFLY}}
     return out
 
 
@@ -580,6 +621,165 @@ def bench_one_process_sharded(lib, n_ctx, n_devices, log_n):
             "contexts": n_ctx, "devices": min(n_ctx, n_devices), "scaling": "strong"}
 
 
+def bench_msm_boolean(worker, lib, bases, t_host, n, uniform_ms, iters=10, check=True):
+    """The C2 multiexp on the scalar vectors REAL witnesses produce (SURVEY.md 8d: "boolean-heavy vectors (~50 % zeros/ones)";
+    the reason Exponent::Zero / One exist, src/multiexp.rs:172-182,245-252): same registered bases P_i = [t_i]G, scalars
+    resident in HBM, median wall of `iters` calls per mix (tests/scalar_mixes.py), device stages, and what the job executed.
+    Outside the timed calls every result is checked against [sum_i s_i t_i]G (the dot product by the oracle's field
+    arithmetic); bit-exactness against the restated multiexp is tests/test_gpu_boolean.py."""
+    import bellman_amd
+    from tests import scalar_mixes
+
+    ds = worker.alloc(n * 32)
+    out = {"workload": "G1 multiexp, 2^%d terms, the bases of the headline workload, scalar mixes of tests/scalar_mixes.py "
+                       "(bool50: 25 %% zeros + 25 %% ones; bool90: 45 %% + 45 %%; ones; small90: 90 %% below 2^8)" % int(np.log2(n)),
+           "uniform_ms_per_step": round(uniform_ms, 4), "mixes": {}}
+    for mix in ("bool50", "bool90", "ones", "small90"):
+        sc = scalar_mixes.scalars(mix, n, 0xB001EA)
+        worker.upload(ds, sc)
+        walls, stages, st = [], [], None
+        for it in range(iters + 2):
+            t0 = time.perf_counter()
+            got, ms, st = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, stats=True).wait()
+            if it >= 2:
+                walls.append((time.perf_counter() - t0) * 1e3)
+                stages.append(ms)
+        if check:
+            from oracle import cref
+
+            k = np.array(cref.int_to_limbs(cref.fr_dot(sc, t_host), 4), dtype=np.uint64)
+            want = np.zeros(12, dtype=np.uint64)
+            lib.bh_point_mul(1, want.ctypes.data_as(ctypes.c_void_p), G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p))
+            assert np.array_equal(got, want), "boolean-heavy multiexp (%s) != [sum s_i t_i]G" % mix
+        med = float(np.median(walls))
+        sg = np.median(np.array(stages), axis=0)
+        live = st["sorted_entries"] - st["zero_digits"]
+        out["mixes"][mix] = {
+            "ms_median": round(med, 4), "Mscalar_mul_per_s": round(n / med / 1e3, 2), "x_uniform_rate": round(uniform_ms / med, 3),
+            "device_ms": {"pipeline": round(float(sg[0]), 4), "digits_sort": round(float(sg[1]), 4),
+                          "bucket_accumulate": round(float(sg[2]), 4), "merge_reduce": round(float(sg[3]), 4)},
+            "merge_reduce_share_of_step": round(float(sg[3]) / med, 3),
+            "live_entries": live, "mixed_additions": st["mixed_additions"],
+            "accumulate_Tmad_per_s": round(st["mixed_additions"] * MADS_PER_MIXED_ADD / (float(sg[2]) * 1e-3) / 1e12, 2) if sg[2] > 0 else None}
+    worker.free(ds)
+    return out
+
+
+def bench_create_proof_boolean(worker, lib, log_n=20, proofs=10):
+    """create_proof on the boolean-heavy demo circuit (csrc/demo_circuits.cpp BoolMixCircuit: the AND / XOR / packing
+    constraints of src/gadgets/boolean.rs; > 98 % of the aux assignment is 0 or 1) filling a 2^log_n domain: CRS from the
+    device generator, host synthesis and R1CS-resident, medians.  The R1CS-resident proof must equal the host-synthesis one;
+    equality with the restated prover is tests/test_gpu_boolean.py::test_boolean_circuit_proof_2_20_matches_oracle."""
+    from bellman_amd import groth16 as pg
+    from tests import circuits
+
+    lib.use_unchecked_demo_circuits()
+    rounds = circuits.boolmix_rounds(log_n)
+    seed = 777
+    r1cs = pg.R1CS.from_demo(worker, 5, rounds, seed)
+    params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+    tms, tms_r = [], []
+    for i in range(proofs + 1):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        last = pg.create_proof_demo(params, 5, rounds, seed, [0x0123456789ABCDEF + i], None, 0xB001 + i, 0xEA, tm)
+        if i:
+            tms.append(tm + [(time.perf_counter() - t0) * 1e3])
+    for i in range(proofs + 1):
+        tm = [0, 0, 0, 0]
+        t0 = time.perf_counter()
+        last_r = pg.create_proof_demo_r1cs(params, r1cs, 5, rounds, seed, [0x0123456789ABCDEF + i], None, 0xB001 + i, 0xEA, tm)
+        if i:
+            tms_r.append(tm + [(time.perf_counter() - t0) * 1e3])
+    assert last_r.a.tobytes() == last.a.tobytes() and last_r.b.tobytes() == last.b.tobytes() and last_r.c.tobytes() == last.c.tobytes(), \
+        "boolean circuit: device-evaluated constraints gave a different proof"
+    asg = pg.demo_assignment(5, rounds, seed, [0x0123456789ABCDEF + proofs])
+    aux = asg["aux_assignment"]
+    one = pg.fr_to_mont_array([1])[0]
+    zeros = int((aux == 0).all(axis=1).sum())
+    ones = int((aux == one).all(axis=1).sum())
+    pop = lambda words: int(np.unpackbits(words.view(np.uint8)).sum())  # noqa: E731
+    m, mr = np.median(np.array(tms), axis=0), np.median(np.array(tms_r), axis=0)
+    r1cs.release()
+    params.release()
+    worker.trim()
+    return {"workload": "groth16::create_proof, boolean-heavy bit-mixing circuit (src/gadgets/boolean.rs shapes), %d constraints "
+                        "in a 2^%d domain, 1 public input" % (asg["a"].shape[0], log_n),
+            "aux_assignment": {"variables": int(aux.shape[0]), "zeros": zeros, "ones": ones,
+                               "boolean_fraction": round((zeros + ones) / aux.shape[0], 4),
+                               "a_query_dense": pop(asg["a_aux_density"]), "b_query_dense": pop(asg["b_aux_density"])},
+            "proofs_per_s": round(1e3 / float(m[4]), 3), "ms_total": round(float(m[4]), 2), "ms_host_synthesis": round(float(m[0]), 2),
+            "with_r1cs_resident_in_hbm": {"proofs_per_s": round(1e3 / float(mr[4]), 3), "ms_total": round(float(mr[4]), 2),
+                                          "ms_host_witness": round(float(mr[0]), 2), "ms_device_part": round(float(mr[4]) - float(mr[0]), 2)},
+            "samples": proofs, "statistic": "median"}
+
+
+def bench_scaling_model(worker, lib, log_n_total=26, proof_log_n=24, reps=3):
+    """What ONE rank of an N-rank run does, measured here on one GPU, so that the first real SCALE record judges itself:
+      (i) MSM leg of BASELINE configs[4]: the 2^26-term G1 multiexp sharded by bases - a rank runs the whole single-GPU
+          pipeline on 2^26 / N terms, then one all-gather of N x 96 bytes and N - 1 point additions (assumed 0.1 ms: RCCL's
+          small-message latency, never measured here at N > 1).  T(N) = t_msm(2^26 / N) + 0.1 ms.
+      (ii) proof leg: every rank builds the whole witness and runs the h block (replicated), and computes 1 / N of every
+          multiexp (prove_witness_part).  T(N) = t_part(N) measured as part 0 of N + 0.1 ms: Amdahl-bound by the replicated
+          host witness - stated, not hidden."""
+    import bellman_amd
+    from bellman_amd import groth16 as pg
+
+    out = {"assumed_all_gather_and_fold_ms": 0.1, "msm_2p%d_strong" % log_n_total: {}, "note":
+           "predictions for N ranks from single-GPU measurements of one rank's share; N > 1 has never run on hardware here"}
+    nmax = 1 << log_n_total
+    t = splitmix_scalars(nmax, 0xC5)
+    dt, dout = worker.alloc(nmax * 32), worker.alloc(nmax * 96)
+    worker.upload(dt, t)
+    assert lib.bh_fixed_base_mul_dev(worker.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), dt, nmax, 0, dout, None) == 0
+    worker.synchronize()
+    worker.upload(dt, splitmix_scalars(nmax, 0x5CA1A25))
+    base_ms = None
+    for ranks in (1, 2, 4, 8):
+        n = nmax // ranks
+        bases = bellman_amd.Bases.wrap_device(worker, 1, dout, n)
+        walls = []
+        for it in range(reps + 1):
+            t0 = time.perf_counter()
+            bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=dt, n=n).wait()
+            if it:
+                walls.append((time.perf_counter() - t0) * 1e3)
+        bases.release()
+        ms = float(np.median(walls)) + (0.1 if ranks > 1 else 0.0)
+        base_ms = ms if ranks == 1 else base_ms
+        out["msm_2p%d_strong" % log_n_total][str(ranks)] = {"terms_per_rank": n, "predicted_ms": round(ms, 2),
+                                                               "predicted_speedup": round(base_ms / ms, 2),
+                                                               "predicted_Mscalar_mul_per_s": round(nmax / ms / 1e3, 1)}
+    worker.free(dt)
+    worker.free(dout)
+    worker.trim()
+    if proof_log_n:
+        rounds = (1 << proof_log_n) - 3
+        seed = 2024
+        r1cs = pg.R1CS.from_demo(worker, 1, rounds, seed)
+        params = pg.Parameters.generate(worker, r1cs, G1_GEN_MONT, G2_GEN_MONT, alpha=48577, beta=22580, gamma=53332, delta=5481, tau=3673)
+        leg = {}
+        base = None
+        for ranks in (1, 2, 4, 8):
+            best = None
+            for it in range(2):
+                tm = [0, 0, 0, 0]
+                t0 = time.perf_counter()
+                pg.prove_demo_part(params, r1cs, 1, rounds, seed, [55555], None, 0, ranks, tm)
+                wall = (time.perf_counter() - t0) * 1e3
+                if it and (best is None or wall < best[0]):
+                    best = (wall, tm)
+            ms = best[0] + (0.1 if ranks > 1 else 0.0)
+            base = ms if ranks == 1 else base
+            leg[str(ranks)] = {"predicted_ms": round(ms, 1), "predicted_speedup": round(base / ms, 2),
+                               "replicated_host_witness_ms": round(float(best[1][0]), 1)}
+        out["proof_2p%d_strong" % proof_log_n] = leg
+        r1cs.release()
+        params.release()
+        worker.trim()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -664,10 +864,13 @@ def main():
 
     ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (tools/r5/*.sh, tools/history/)
 
+    job_stats = {}
+
     def step():
         w = bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s_dev.data_ptr()),
-                                 n=n, timed=True, flags=ab_flags)
-        part, ms = w.wait()
+                                 n=n, stats=True, flags=ab_flags)
+        part, ms, st = w.wait()
+        job_stats.update(st)   # what the job executed, counted on the device (bh_msm_wait_stats)
         if collective:   # one 96-byte all-gather over RCCL + local fold (bellman_amd/sharding.py)
             return sharding.fold_partials(part, 1, device=coll_dev if coll_dev == "cuda" else None), ms
         return part, ms
@@ -765,10 +968,23 @@ def main():
         tt = torch.tensor([time.perf_counter() - t0], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         e5 = float(tt.item())
+        # the model of DESIGN.md 7, on this run's own numbers: T(N) = the slowest rank's shard alone + 0.1 ms for the all-gather and fold
+        barrier()
+        alone = []
+        for _ in range(steps5):
+            ta = time.perf_counter()
+            bellman_amd.multiexp(worker, bases5, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s5.data_ptr()), n=n5).wait()
+            alone.append((time.perf_counter() - ta) * 1e3)
+        ta = torch.tensor([float(np.median(alone))], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         c5 = {"workload": "one G1 MSM of 2^%d terms sharded by bases over %d ranks (%d terms per rank) + all-gather + fold"
                           % (args.c5_log_n, world, n5),
               "value": round(world * n5 * steps5 / e5 / 1e6, 3), "unit": "Mscalar-mul/s", "ms_per_msm": round(e5 * 1e3 / steps5, 2),
-              "scaling": "strong", "steps": steps5}
+              "scaling": "strong", "steps": steps5,
+              "model": {"predicted_ms": round(float(ta.item()) + 0.1, 2), "measured_ms": round(e5 * 1e3 / steps5, 2),
+                        "terms": "slowest rank's shard alone (median of %d, ranks running side by side) + 0.1 ms assumed for the "
+                                 "all-gather of %d x 96 B and the fold; the N = 1 line's scaling_model holds the single-GPU "
+                                 "prediction for every N" % (steps5, world)}}
         del bases5, b5, t5, s5
         worker.trim()
     # one PROCESS driving every GPU of the node (bh_msm_sharded_async: one context per device, the reference's single
@@ -820,6 +1036,9 @@ def main():
                 "value_at_median_step": round(world * n / float(np.median(step_ms)) / 1e3, 3),
                 "value_with_2_jobs_in_flight": round(pipelined_value, 3) if pipelined_value else None,
                 "value_per_gpu_with_host_scalars_pcie_inclusive": round(pcie_value, 3) if pcie_value else None,
+                # SURVEY.md 8(d) defines the metric "excl. one-time base upload; incl. scalar upload": THIS is that figure; `value` is
+                # the resident-scalar rate (the state multiexp is called in inside create_proof)
+                "value_incl_scalar_upload_survey_8d": round(world * pcie_value, 3) if pcie_value else None,
             },
             "roofline": {
                 "bound": "hbm",
@@ -833,11 +1052,17 @@ def main():
                 # the roofline that actually bounds this kernel: the v_mad_u64_u32 pipe.  Work per launch =
                 # W*n mixed additions x 10 field products x 351 mads (ff.cuh); peak = 26.2 T mad/s measured
                 # on this chip (profiles/r1_microbench_int.txt).
-                "alu": {"unit": "Tmad/s", "peak": 26.2,
-                        "achieved": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
-                        "frac": round(16 * n * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12 / 26.2, 4) if acc_ms > 0 else 0.0,
-                        "work": "16 windows x n mixed additions x (8 Fp products x 351 + 2 squarings x 273 - 182: the last two "
-                                "products share one reduction) = %d v_mad_u64_u32 / v_mul_lo_u32 per addition" % MADS_PER_MIXED_ADD,
+                "alu": {"unit": "Tmad/s", "peak": MAD_PEAK_T,
+                        "achieved": round(job_stats["mixed_additions"] * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12, 2) if acc_ms > 0 else 0.0,
+                        "frac": round(job_stats["mixed_additions"] * MADS_PER_MIXED_ADD / (acc_ms * 1e-3) / 1e12 / MAD_PEAK_T, 4) if acc_ms > 0 else 0.0,
+                        "mixed_additions_per_launch": job_stats["mixed_additions"],
+                        "sorted_entries": job_stats["sorted_entries"], "zero_digits": job_stats["zero_digits"],
+                        "bucket_and_chunk_openers": job_stats["sorted_entries"] - job_stats["zero_digits"] - job_stats["mixed_additions"],
+                        "plan": {"window_bits": job_stats["window_bits"], "chunk": job_stats["chunk"], "bucket_sets": job_stats["bucket_sets"]},
+                        "work": "mixed additions the launch EXECUTED into a non-empty accumulator, counted on the device "
+                                "(bh_msm_wait_stats; the entries that open a bucket or a chunk partial are copies) x (8 Fp products x 351 "
+                                "+ 2 squarings x 273 - 182: the last two products share one reduction) = %d v_mad_u64_u32 / "
+                                "v_mul_lo_u32 per addition" % MADS_PER_MIXED_ADD,
                         "peak_provenance": "v_mad_u64_u32 microbenchmark on this chip (tools/microbench_int.hip, "
                                            "profiles/r1_microbench_int.txt) at its sustained clock; under the accumulate kernel the "
                                            "SQ counters put the clock near 2.0 GHz (profiles/r1_pmc_valu.json), so the fraction is "
@@ -876,31 +1101,42 @@ def main():
         if one_process is not None:
             out["msm_one_process_sharded"] = one_process
         if not args.no_proof and not distributed:
+            out["msm_boolean_heavy"] = bench_msm_boolean(worker, lib, bases, t_host, n, ms_per_step, check=not args.no_cpu_baseline)
             out["msm_other_shapes"] = [bench_msm_shape(worker, lib, 2, 19), bench_msm_shape(worker, lib, 2, 20),
-                                       bench_msm_shape(worker, lib, 1, 16)]
+                                       bench_msm_shape(worker, lib, 1, 16), bench_msm_shape(worker, lib, 1, 18)]
             out["create_proof_mimc"] = bench_mimc(worker, cpu_baseline=not args.no_cpu_baseline)
             out["fft"] = bench_fft(worker, lib)
             out["create_proof"] = bench_create_proof(worker, lib, args.proof_log_n, cpu_baseline=not args.no_cpu_baseline)
             out["setup"] = out["create_proof"]["setup"]   # (also at the top level: the set-up path of the config C4 proof)
+            out["create_proof_boolean"] = bench_create_proof_boolean(worker, lib, args.proof_log_n)
             if args.c5_proof_log_n:
                 out["create_proof_c5"] = bench_create_proof_c5(worker, args.c5_proof_log_n)
+            # what one rank of an N-rank run would do, measured on this GPU: the model the first SCALE record is read against
+            out["scaling_model"] = bench_scaling_model(worker, lib, 26, args.c5_proof_log_n)
         # measured HBM traffic of the dominant kernel, recorded from the rocprofv3 --pmc passes of this same command
-        # (tools/r5/gpu_final.sh -> profiles/r5_final_pmc_accumulate.json), if it matches this workload.  The guide's x2
-        # read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte
-        # pieces, so `traffic` carries the read-corrected (doubled FETCH_SIZE) figure and the note the raw one.
-        for name in ("r5_final_pmc_accumulate.json", "r4_final_pmc_accumulate.json", "r3_final_pmc_accumulate.json", "r2_final_pmc_accumulate.json", "r1_pmc_accumulate.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            except Exception:
-                continue
-            if pmc.get("log_n") == args.log_n:
+        # (tools/r6/gpu_final.sh -> profiles/r6_final_pmc_accumulate.json).  Used ONLY if the file was taken at the plan this
+        # run executed (log_n, window bits, chunk length - bh_msm_wait_stats): a stale file leaves `traffic` null.  The guide's
+        # x2 read correction is calibrated for wide coalesced reads; this kernel gathers 96-byte records in 16-byte pieces, so
+        # `traffic` carries the read-corrected (doubled FETCH_SIZE) figure and the note the raw one.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r6_final_pmc_accumulate.json")))
+        except Exception:
+            pmc = None
+        if pmc is not None:
+            same = (pmc.get("log_n") == args.log_n and pmc.get("window_bits") == job_stats.get("window_bits") and
+                    pmc.get("chunk") == job_stats.get("chunk"))
+            if same:
                 fetch, write = pmc["FETCH_SIZE"]["per_launch_kb_mean"] * 1024, pmc["WRITE_SIZE"]["per_launch_kb_mean"] * 1024
                 out["roofline"]["traffic"] = int(2 * fetch + write)
                 out["roofline"]["traffic_note"] = (
-                    "bytes per launch from profiles/%s: 2 x FETCH_SIZE (gfx950 read correction of MI355X_MICROARCH.md, calibrated "
-                    "on wide coalesced reads; this kernel's reads are 16-byte pieces of gathered 96-byte records, so it is an upper "
-                    "bound - uncorrected: %d) + WRITE_SIZE %d; algorithmic 128 B x 2^20 = %d" % (name, int(fetch + write), int(write), 128 << 20))
-            break
+                    "bytes per launch from profiles/r6_final_pmc_accumulate.json (same plan: c = %d, K = %d): 2 x FETCH_SIZE (gfx950 read "
+                    "correction of MI355X_MICROARCH.md, calibrated on wide coalesced reads; this kernel's reads are 16-byte pieces of "
+                    "gathered 96-byte records, so it is an upper bound - uncorrected: %d) + WRITE_SIZE %d; algorithmic 128 B x 2^%d = %d"
+                    % (job_stats["window_bits"], job_stats["chunk"], int(fetch + write), int(write), args.log_n, 128 << args.log_n))
+            else:
+                out["roofline"]["traffic_note"] = ("profiles/r6_final_pmc_accumulate.json was taken at log_n %s, c %s, K %s - not the plan "
+                                                   "of this run (c %s, K %s): ignored" % (pmc.get("log_n"), pmc.get("window_bits"), pmc.get("chunk"),
+                                                                                        job_stats.get("window_bits"), job_stats.get("chunk")))
         print(json.dumps(out), flush=True)
     if collective:
         dist.barrier()

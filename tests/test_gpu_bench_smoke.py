@@ -36,6 +36,27 @@ def test_bench_single_gpu_contract_small():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"])
     assert "workload" in out["config"] and "model" not in out["config"]
+    # [r6] what the launch executed is reported, not assumed: additions counted on the device, the plan they ran under
+    alu = out["roofline"]["alu"]
+    assert 0 < alu["mixed_additions_per_launch"] <= alu["sorted_entries"] - alu["zero_digits"]
+    assert alu["plan"]["window_bits"] > 0 and alu["plan"]["chunk"] > 0
+
+
+def test_bench_scaling_model_is_emitted():
+    """[r6] the N = 1 line carries the predicted 1 / 2 / 4 / 8-rank table of DESIGN.md 7 (one rank's share measured on this
+    GPU), at reduced sizes here"""
+    sys.path.insert(0, ROOT)
+    import bellman_amd
+    import bench
+    from bellman_amd import _lib
+
+    w = bellman_amd.Worker(0)
+    m = bench.bench_scaling_model(w, _lib.load(), log_n_total=16, proof_log_n=12, reps=2)
+    w.close()
+    for leg in ("msm_2p16_strong", "proof_2p12_strong"):
+        assert set(m[leg]) == {"1", "2", "4", "8"}
+        assert all(m[leg][k]["predicted_ms"] > 0 and m[leg][k]["predicted_speedup"] > 0 for k in m[leg])
+    assert m["msm_2p16_strong"]["8"]["terms_per_rank"] == 1 << 13
 
 
 @pytest.mark.parametrize("ranks", [2, 8])
@@ -55,6 +76,9 @@ def test_bench_ranks_on_one_gpu_gloo(ranks):
     assert "== one multiexp" in out["sharded_fold_check"]
     assert out["create_proof_sharded"]["scaling"] == "strong" and "identical to the single-GPU proof" in out["create_proof_sharded"]["workload"]
     assert out["msm_c5_sharded"]["scaling"] == "strong" and out["msm_c5_sharded"]["value"] > 0
+    # [r6] the line judges itself against the scaling model of DESIGN.md 7: predicted (slowest shard alone + collective) next to measured
+    model = out["msm_c5_sharded"]["model"]
+    assert model["predicted_ms"] > 0 and model["measured_ms"] > 0
     assert "cpu_baseline" not in out          # rank 0 at N = 1 only
     # [r4] the line proves who ran: every rank reported in, here all of them on the one GPU of the box (under RCCL
     # bench.py asserts distinct_devices == world itself)

@@ -41,10 +41,14 @@ def main():
             cp(d + "/p_kernel_stats.csv", d[5:] + "_kernel_stats.csv")
     K = "msm_accumulate_kernel<bh::FpOps, false>"
     f, w = pmc_means(os.path.join(src, "pmc_fetch/p_counter_collection.csv"), K), pmc_means(os.path.join(src, "pmc_write/p_counter_collection.csv"), K)
+    # the plan the profiled command ran, as its own bench line reports it (bh_msm_wait_stats): bench.py refuses this file
+    # for a run whose plan differs
+    plan = json.loads(line)["roofline"]["alu"]["plan"]
     out = {
         "kernel": "msm_accumulate_kernel<FpOps,false>",
-        "workload": "G1 MSM 2^20, signed digits c=16 (W=16, 2^15 buckets per window), K=32 (bench.py default)",
-        "log_n": 20,
+        "workload": "G1 MSM 2^20, signed digits c=%d (%d bucket sets of 2^%d buckets), K=%d (bench.py default plan)" %
+                    (plan["window_bits"], plan["bucket_sets"], plan["window_bits"] - 1, plan["chunk"]),
+        "log_n": 20, "window_bits": plan["window_bits"], "chunk": plan["chunk"],
         "FETCH_SIZE": {"per_launch_kb_mean": f["FETCH_SIZE"][0], "launches": f["FETCH_SIZE"][1]},
         "WRITE_SIZE": {"per_launch_kb_mean": w["WRITE_SIZE"][0], "launches": w["WRITE_SIZE"][1]},
         "algorithmic_bytes_per_launch": 128 << 20,
@@ -59,7 +63,7 @@ def main():
     json.dump(out, open(os.path.join(prof, tag + "_pmc_accumulate.json"), "w"), indent=1)
     v = pmc_means(os.path.join(src, "pmc_valu/p_counter_collection.csv"), K)
     m = {k: x[0] for k, x in v.items()}
-    adds = 16 * (1 << 20) / 64
+    adds = json.loads(line)["roofline"]["alu"]["mixed_additions_per_launch"] / 64   # executed, counted on the device
     json.dump({
         "kernel": "msm_accumulate_kernel<FpOps,false>", "workload": out["workload"], "per_launch_mean": m,
         "derived": {
