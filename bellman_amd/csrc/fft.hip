@@ -810,7 +810,9 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
       for (uint32_t p = 0; p + 1 < pL; p++) s_last += pr[p];
       ok = tile_table(&t1.icoset1, pL - 1, s_last, 2, ginv, one);
     }
-    if (ok) { t = t1; t.one_level = true; }
+    // (the size counts as running on one-level tables only once it HOLDS one: a call that built none - a cached 1/Z, a
+    // single-pass request - must not let later calls skip the budget gate above)
+    if (ok) { t = t1; t.one_level = t.one_level || t1.tw1[0][0] || t1.tw1[1][0] || t1.coset1 || t1.icoset1; }
     else {
       (void)hipStreamSynchronize(st);
       (void)hipGetLastError();
@@ -870,9 +872,9 @@ static int get_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bo
 }
 
 // drops the least recently used sizes other than `keep_log_n` until `need` more bytes fit the budget ((size_t)-1: all of
-// them).  Exclusive: no transform is between its get_tables and its last launch, and the device is drained before a free.
-static void fft_evict(Context &c, uint32_t keep_log_n, size_t need) {
-  std::unique_lock<std::shared_mutex> ex(c.fft_use_mu);
+// them).  The caller holds fft_use_mu EXCLUSIVELY: no transform is between its get_tables and its last launch; the device is
+// drained before a free.
+static void fft_evict_locked(Context &c, uint32_t keep_log_n, size_t need) {
   (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> g(c.fft_mu);
   for (;;) {
@@ -886,19 +888,34 @@ static void fft_evict(Context &c, uint32_t keep_log_n, size_t need) {
     c.fft_tables.erase(victim);
   }
 }
-// get_tables with the cache's eviction round trips; on BH_OK `use` holds fft_use_mu shared - keep it until the last launch
-// that reads the tables has been enqueued
+// What a transform holds on the table cache from get_tables to its last launch: the use lock shared - or, after an eviction,
+// exclusively.
+struct TableUse {
+  std::shared_lock<std::shared_mutex> shared;
+  std::unique_lock<std::shared_mutex> exclusive;
+};
+// get_tables with the cache's eviction; on BH_OK `use` holds fft_use_mu - keep it until the last launch that reads the
+// tables has been enqueued.  [r6, ADVICE r5] The eviction path reaches a guaranteed outcome: it takes the use lock
+// EXCLUSIVELY and keeps it through the rebuild and the caller's launches, so that no other host thread can take the room
+// back between "evicted" and "built" (round 5 retried four times under the shared lock and returned BH_ERR_HIP when two
+// threads whose table sets do not fit the budget together kept evicting each other - a spurious failure that the
+// resident-domain Rust path turns into a panic).  With every other size gone get_tables never asks for an eviction
+// again: it builds the set, completes a set it already runs on, or falls back to two-level tables.
 static int acquire_tables(Context &c, uint32_t log_n, bool inverse, bool need_tw, bool need_coset, bool need_icoset, hipStream_t st,
-                          FftTables *out, const BTw **master, std::shared_lock<std::shared_mutex> &use) {
-  for (int attempt = 0; attempt < 4; attempt++) {
-    use = std::shared_lock<std::shared_mutex>(c.fft_use_mu);
-    size_t need = 0;
-    const int rc = get_tables(c, log_n, inverse, need_tw, need_coset, need_icoset, st, out, master, &need);
-    if (rc != BH_FFT_EVICT) { if (rc != BH_OK) use.unlock(); return rc; }
-    use.unlock();
-    fft_evict(c, log_n, need);
+                          FftTables *out, const BTw **master, TableUse &use) {
+  use.shared = std::shared_lock<std::shared_mutex>(c.fft_use_mu);
+  size_t need = 0;
+  int rc = get_tables(c, log_n, inverse, need_tw, need_coset, need_icoset, st, out, master, &need);
+  if (rc != BH_FFT_EVICT) { if (rc != BH_OK) use.shared.unlock(); return rc; }
+  use.shared.unlock();
+  use.exclusive = std::unique_lock<std::shared_mutex>(c.fft_use_mu);
+  for (int attempt = 0; attempt < 2 && rc == BH_FFT_EVICT; attempt++) {   // (second round: everything else goes)
+    fft_evict_locked(c, log_n, attempt ? (size_t)-1 : need);
+    rc = get_tables(c, log_n, inverse, need_tw, need_coset, need_icoset, st, out, master, &need);
   }
-  return BH_ERR_HIP;
+  if (rc == BH_FFT_EVICT) rc = BH_ERR_HIP;   // (unreachable: nothing is left to evict)
+  if (rc != BH_OK) use.exclusive.unlock();
+  return rc;
 }
 
 // data: device, 2^log_n Montgomery Fr, in place.  scratch: device, same size (ping-pong for the
@@ -916,7 +933,7 @@ static int ntt_run_batch(Context &c, fr_t *data, fr_t *scratch, uint32_t log_n, 
   plan_passes(log_n, r, &L);
   FftTables tab;
   const BTw *master = nullptr;
-  std::shared_lock<std::shared_mutex> use;   // the tables stay cached until this call's launches are enqueued (fft_evict)
+  TableUse use;   // the tables stay cached until this call's launches are enqueued
   int rc = acquire_tables(c, log_n, inverse, L > 1, mode == BH_COSET_FFT, mode == BH_ICOSET_FFT, st, &tab, &master, use);
   if (rc) return rc;
   // one kind of tables per size: the one-level kernel multiplies by whatever its table pointers say, so every table
@@ -976,7 +993,7 @@ int fr_sub_assign(Context &c, fr_t *a, const fr_t *b, u64 n, hipStream_t st) {
 static int cached_zinv(Context &c, uint32_t log_n, hipStream_t st, fr_t *out) {
   FftTables tab;
   const BTw *master = nullptr;
-  std::shared_lock<std::shared_mutex> use;
+  TableUse use;
   int rc = acquire_tables(c, log_n, false, false, false, false, st, &tab, &master, use);
   if (rc) return rc;
   *out = tab.zinv;

@@ -232,7 +232,14 @@ impl MsmJob {
         let mut g2 = [0u64; 24];
         let out = if self.group == ffi::BH_G1 { g1.as_mut_ptr() as *mut c_void } else { g2.as_mut_ptr() as *mut c_void };
         let raw = std::mem::replace(&mut self.raw, ptr::null_mut()); // the library frees the job in bh_msm_wait
-        check(unsafe { ffi::bh_msm_wait(raw, out) })?;
+        let rc = check(unsafe { ffi::bh_msm_wait(raw, out) });
+        // the job no longer reads its scalars: if bellman has dropped the exponent vector meanwhile, its device copy goes now
+        // (not at the start of some later multiexp - after the last one there is none)
+        self._scalars = None;
+        if let Some(ctx) = context() {
+            ctx.trim_scalars();
+        }
+        rc?;
         Ok(if self.group == ffi::BH_G1 { MsmOutput::G1(g1) } else { MsmOutput::G2(g2) })
     }
 }
@@ -245,6 +252,10 @@ impl Drop for MsmJob {
             let mut sink = [0u64; 24];
             let _ = unsafe { ffi::bh_msm_wait(self.raw, sink.as_mut_ptr() as *mut c_void) };
             self.raw = ptr::null_mut();
+            self._scalars = None;
+            if let Some(ctx) = context() {
+                ctx.trim_scalars();
+            }
         }
     }
 }
@@ -401,22 +412,35 @@ impl Context {
         gather: impl FnOnce(&[T]) -> Vec<Scalar>,
     ) -> Result<Arc<Scalars>, HipError> {
         let key = (Arc::as_ptr(v) as usize, v.len());
-        let mut c = self.scalars_cache.lock().unwrap();
-        c.retain(|_, e| e.owner.strong_count() > 0);
-        if let Some(e) = c.get(&key) {
-            if let Some(alive) = e.owner.upgrade() {
-                if let Ok(same) = alive.downcast::<Vec<T>>() {
-                    if Arc::ptr_eq(&same, v) {
-                        return Ok(e.dev.clone());
-                    }
-                }
-            }
+        let lookup = |c: &mut HashMap<(usize, usize), CachedScalars>| -> Option<Arc<Scalars>> {
+            c.retain(|_, e| e.owner.strong_count() > 0);
+            let e = c.get(&key)?;
+            let alive = e.owner.upgrade()?;
+            let same = alive.downcast::<Vec<T>>().ok()?;
+            if Arc::ptr_eq(&same, v) { Some(e.dev.clone()) } else { None }
+        };
+        if let Some(dev) = lookup(&mut self.scalars_cache.lock().unwrap()) {
+            return Ok(dev);
         }
+        // the gather (rayon, tens of milliseconds for 2^20 exponents) and the upload run OUTSIDE the map lock: concurrent
+        // multiexps over different vectors do not serialise on it.  Two threads that miss on the SAME vector both upload;
+        // the second insert finds the first one's entry and keeps it.
         let words = gather(v.as_slice());
         let dev = self.register_scalars(&words)?;
+        let mut c = self.scalars_cache.lock().unwrap();
+        if let Some(first) = lookup(&mut c) {
+            return Ok(first);
+        }
         let owner: Arc<dyn std::any::Any + Send + Sync> = v.clone();
         c.insert(key, CachedScalars { owner: Arc::downgrade(&owner), dev: dev.clone() });
         Ok(dev)
+    }
+
+    /// Drops the device copies of exponent vectors whose `Arc` has died (tens to hundreds of MiB per proof).  Called by
+    /// every `MsmJob::wait` - the last multiexp over a vector is what keeps its copy alive - and available to callers
+    /// that want HBM back at a point of their choosing (next to `bh_ctx_trim`, which cannot see this cache).
+    pub fn trim_scalars(&self) {
+        self.scalars_cache.lock().unwrap().retain(|_, e| e.owner.strong_count() > 0);
     }
 
     /// The h block of `create_proof` (groth16/src/prover.rs:221-240) in one call: a, b, c evaluations in,
@@ -479,7 +503,10 @@ mod tests {
     /// the reference's own property (src/multiexp.rs:334-378): multiexp == naive sum; needs a gfx950 device
     #[test]
     fn msm_matches_naive() {
-        let Some(ctx) = context() else { return };
+        let ctx = match context() {
+            Some(c) => c,
+            None => return,
+        };
         let mut rng = rand_core::OsRng;
         let n = 1 << 10;
         let scalars: Vec<Scalar> = (0..n).map(|_| Scalar::random(&mut rng)).collect();

@@ -233,3 +233,48 @@ def test_fft_table_cache_stays_within_its_budget(worker):
         assert np.array_equal(d.into_coeffs(), cref.fft(data, 3, threads=8))
     finally:
         w.close()
+
+
+def test_fft_cache_eviction_between_two_host_threads_always_completes():
+    """[r6, ADVICE r5] Two host threads transform sizes whose one-level table sets do NOT fit the cache's budget together
+    (2^21: 4 x 64 MiB, 2^22: 4 x 128 MiB under 640 MiB), so each call of one thread may have to evict the other's tables.
+    Round 5 retried that four times under the shared use lock and returned BH_ERR_HIP when the threads kept evicting each
+    other; the eviction path now holds the use lock exclusively through the rebuild.  Every call must succeed, every round
+    trip (ifft . fft, icoset_fft . coset_fft: src/domain.rs:81-125) must give the data back, the budget must hold."""
+    import threading
+
+    import bellman_amd
+    from oracle import cref
+
+    budget = 640 << 20
+    w = bellman_amd.Worker(0)
+    errors, held = [], []
+    try:
+        w.set_limits(fft_table_budget_bytes=budget)
+
+        def run(log_n, rounds):
+            try:
+                data = cref.random_fr(1 << log_n, 4400 + log_n)
+                d = bellman_amd.EvaluationDomain.from_coeffs(w, data)
+                for i in range(rounds):
+                    d.fft()
+                    d.ifft()
+                    d.coset_fft()
+                    d.icoset_fft()
+                    held.append(w.info()["fft_table_bytes"])
+                    if i % 8 == 7 and not np.array_equal(d.as_ref(), data):
+                        errors.append("round trip at 2^%d, round %d" % (log_n, i))
+                if not np.array_equal(d.into_coeffs(), data):
+                    errors.append("final round trip at 2^%d" % log_n)
+            except Exception as e:   # a spurious BH_ERR_HIP surfaces here
+                errors.append("2^%d: %r" % (log_n, e))
+
+        threads = [threading.Thread(target=run, args=(21, 40)), threading.Thread(target=run, args=(22, 40))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:4]
+        assert max(held) <= budget
+    finally:
+        w.close()
