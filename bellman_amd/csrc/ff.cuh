@@ -223,6 +223,9 @@ static_assert(Radix30<FpParams>::NOSPLIT == (0x3ffffffu & ~(0x1fu << 10)), "Fp: 
 // limb i (30 bits) of (x << SH), x given as N 32-bit words
 template <class P, int SH>
 BH_HD u32 fe_limb30(const Fe<P> &x, int i) {
+#ifdef BH_DIAG_NO_SLICE   // TIMING-ONLY diagnostic build (tools/r6/gpu_call12.sh): what if operands were already 30-bit limbs? (wrong results)
+  return x.l[i < P::N ? i : 0] & 0x3fffffffu;
+#endif
   const int bp = 30 * i - SH;
   if (bp < 0) return (x.l[0] << (-bp)) & 0x3fffffffu;   // only limb 0, since SH < 30
   const int w = bp / 32, sh = bp % 32;
@@ -261,6 +264,13 @@ BH_HD void fe_mont_reduce30(Fe<P> &r, const u64 *c) {
     out[k - L] = (u32)t & R::MASK;
     carry = whole ? (t >> 30) : (t >> 30) + (c[k] >> 30);
   }
+#ifdef BH_DIAG_NO_SLICE   // ... and stayed 30-bit limbs (no repack)
+  if (!CANONICAL) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = out[i];
+    return;
+  }
+#endif
   // repack 30-bit limbs into 32-bit words (value < 2m < 2^(32N))
   u32 w[N];
   u64 acc = 0;
@@ -423,8 +433,13 @@ BH_HD void fe_mul2(Fe<P> &r, const Fe<P> &a, const Fe<P> &b, const Fe<P> &c2, co
       A[i] = fe_limb30<P, 0>(c2, i);
       B[i] = fe_limb30<P, R::SHIFT>(d, i);
     }
+#ifdef BH_DIAG_HALF_SECOND_PRODUCT   // TIMING-ONLY diagnostic build (tools/r6/gpu_call13.sh): the unreachable ideal of a Karatsuba
+    constexpr int ROWS = (L + 1) / 2;   // split over a lane pair - 1.5 products + one reduction per lane, exchanges free (wrong results)
+#else
+    constexpr int ROWS = L;
+#endif
 #pragma unroll
-    for (int i = 0; i < L; i++) {
+    for (int i = 0; i < ROWS; i++) {
 #pragma unroll
       for (int j = 0; j < L; j++) c[i + j] += (u64)A[i] * B[j];
     }

@@ -116,6 +116,12 @@ __device__ __forceinline__ constexpr u32 fr_mod2(int i) {   // limb i of 2q
   return (FrParams::mod(i) << 1) | (i ? FrParams::mod(i - 1) >> 31 : 0u);
 }
 __device__ __forceinline__ void frl_add(fr_t &r, const fr_t &a, const fr_t &b) {   // a + b < 4q: bit 256 is the carry
+#ifdef BH_DIAG_CHEAP_ADDSUB   // TIMING-ONLY diagnostic build: carry-free limb-wise additions (wrong results)
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = a.l[i] + b.l[i];
+  r.l[0] += a.l[7] >> 3;   // (a ninth limb's worth)
+  return;
+#endif
   u32 t[8], d[8];
   u32 c = 0, br = 0;
 #pragma unroll
@@ -127,6 +133,12 @@ __device__ __forceinline__ void frl_add(fr_t &r, const fr_t &a, const fr_t &b) {
   for (int i = 0; i < 8; i++) r.l[i] = ge ? d[i] : t[i];
 }
 __device__ __forceinline__ void frl_sub(fr_t &r, const fr_t &a, const fr_t &b) {
+#ifdef BH_DIAG_CHEAP_ADDSUB   // ... and subtractions with a per-limb bias
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = a.l[i] + fr_mod2(i) - b.l[i];
+  r.l[0] += (a.l[7] + fr_mod2(0) - b.l[7]) >> 3;
+  return;
+#endif
   u32 t[8];
   u32 br = 0, c = 0;
 #pragma unroll
