@@ -817,6 +817,34 @@ __device__ __forceinline__ void merge_big_runs(XYZZ<typename WK::Mem> *pts, cons
     }
   }
 }
+// The two parts as launches of their own (one wavefront per workgroup for the medium runs): what the tiny G2 tables run.
+// The fused kernel below needs 256-thread workgroups for its long part, and the lane-triple instantiation then allocates
+// 256 VGPRs + 47 AGPRs where this one fits 256 + 0 - the medium runs of a window table over 2^10 G2 points (128 runs of
+// 32 partials, the whole job) took 351 us fused against ~230 us here (profiles/r6_call14_small_jobs.txt,
+// r6_call15_tail_split_ab.txt).
+template <class WK>
+__global__ __launch_bounds__(64, WK::LANES == 1 && sizeof(typename WK::Pt) > 200 ? 1 : 2) void msm_merge_runs_kernel(
+    XYZZ<typename WK::Mem> *pts, const XYZZ<typename WK::Mem> *head, const XYZZ<typename WK::Mem> *tail, u32 c,
+    u32 chunks_per_window, const LongRun *runs, u32 max_runs, u32 G, const ErrFlags *err) {
+  u32 nruns = err->nlong;
+  if (nruns > max_runs) nruns = max_runs;
+  merge_medium_runs<WK>(pts, head, tail, c, chunks_per_window, runs, nruns, G, blockIdx.x, gridDim.x);
+}
+template <class WK>
+__global__ __launch_bounds__(LONG_THREADS) void msm_merge_long_kernel(XYZZ<typename WK::Mem> *pts,
+                                                                      const XYZZ<typename WK::Mem> *head,
+                                                                      const XYZZ<typename WK::Mem> *tail, u32 c,
+                                                                      u32 chunks_per_window, BigRun *big_runs, u32 max_big,
+                                                                      XYZZ<typename WK::Mem> *piece_out, u32 max_pieces,
+                                                                      const ErrFlags *err) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_part[sizeof(typename WK::Pt) * (LONG_THREADS / 64) * WK::LANES];
+  __shared__ u32 sh_run, sh_last;
+  u32 nbig = err->nbig, total = err->npieces;
+  if (nbig > max_big) nbig = max_big;
+  if (total > max_pieces) total = max_pieces;
+  merge_big_runs<WK>(pts, head, tail, c, chunks_per_window, big_runs, nbig, piece_out, total, blockIdx.x, gridDim.x, lds_part,
+                     &sh_run, &sh_last);
+}
 // ONE launch for both: workgroups [0, run_blocks) fold the medium runs (a wavefront each at a time, worker policy WKR),
 // the rest the pieces of the big runs (policy WKL) - side by side, not one after the other: a window table over 2^16
 // points has 4 096 medium runs AND ~115 big ones (the top row's 8-bit digits), 130 us + 170 us as two launches
@@ -1208,7 +1236,28 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     hipLaunchKernelGGL((msm_merge_tail_kernel<WKR, WKL>), tgrid, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c,              \
                        p.chunks_per_window, long_runs, max_long, run_lanes, run_blocks, big_runs, max_big, piece_out,           \
                        max_pieces, err)
-    if constexpr (PAIRS_POSSIBLE) {
+    // One launch (medium runs and big pieces side by side) - except the 128-bucket window tables of tiny G2 vectors, whose
+    // 128 medium runs are the whole job: two launches there (G2 2^10: 0.74 against 0.85 ms; 2^12 ... 2^16 and every G1 size are
+    // equal or faster fused - G1 2^16 0.79 against 0.88 ms; profiles/r6_call15_tail_split_ab.txt).  BELLMAN_HIP_TAIL_FUSED=0 / 1
+    // forces either for an A/B
+    static const int fused_env = [] { const char *e = getenv("BELLMAN_HIP_TAIL_FUSED"); return e && *e ? (*e == '0' ? 0 : 1) : -1; }();
+    const bool fused = fused_env >= 0 ? fused_env == 1 : (PAIRS_POSSIBLE || p.NB > 128);
+    if (!fused) {
+      const dim3 rg((u32)c.num_cus * 4), lg(long_blocks);
+#define BH_SPLIT(WKR, WKL)                                                                                                  \
+      hipLaunchKernelGGL(msm_merge_runs_kernel<WKR>, rg, dim3(64), 0, st, pts, head, tail, p.c, p.chunks_per_window, long_runs,  \
+                         max_long, run_lanes, err);                                                                         \
+      hipLaunchKernelGGL(msm_merge_long_kernel<WKL>, lg, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c, p.chunks_per_window,   \
+                         big_runs, max_big, piece_out, max_pieces, err)
+      if constexpr (PAIRS_POSSIBLE) {
+        if (runs_on_pairs && long_pairs) { BH_SPLIT(K2Worker, K2Worker); }
+        else if (long_pairs) { BH_SPLIT(XyzzWorker<FR>, K2Worker); }
+        else { BH_SPLIT(XyzzWorker<FR>, XyzzWorker<FR>); }
+      } else {
+        BH_SPLIT(XyzzWorker<FR>, XyzzWorker<FR>);
+      }
+#undef BH_SPLIT
+    } else if constexpr (PAIRS_POSSIBLE) {
       if (runs_on_pairs && long_pairs) BH_TAIL(K2Worker, K2Worker);
       else if (long_pairs) BH_TAIL(XyzzWorker<FR>, K2Worker);
       else BH_TAIL(XyzzWorker<FR>, XyzzWorker<FR>);
