@@ -1091,7 +1091,10 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // per point there too (A/B)
   constexpr bool LONG_ON_PAIRS = PAIRS_POSSIBLE;
   const bool long_pairs = LONG_ON_PAIRS && long_k2;
-  const u32 big_chunks = std::max(32u, 4u * run_lanes);
+  // ... but never a run that is merely TYPICAL: where the average bucket already spans dozens of chunks (32 rows of 8 bits over
+  // 2^11 G2 points: 64 chunks per bucket) "big" starts at twice the average (round 6, first cut: half of that table's runs
+  // went down the long path, 0.81 -> 1.06 ms)
+  const u32 big_chunks = std::max(std::max(32u, 4u * run_lanes), (u32)(2.0 * (double)p.n / (double)p.nb / (double)p.chunk));
   const u32 piece = long_pairs ? long_piece<K2Worker>() : long_piece<XyzzWorker<FR>>();
   const u32 max_big = (u32)(nslots / (big_chunks + 1) + 1);
   // sum of ceil(L_r / piece) over the big runs: consecutive runs share one chunk, so sum L_r <= nslots + max_big

@@ -294,9 +294,16 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // 2^19 points and more are kept at a 128-byte record stride): 16 bits up to 2^20 (wall 2.21 / 3.95 ms against 2.72 / 4.15
   // with 20 bits), 20 bits above (2^21 6.95 vs 7.47 ms with 16 bits; 2^22 12.3 vs 14.2) -
   // profiles/r4_call16_g1_tables_2p19_2p22.txt
-  if (lg <= 11) return g2 ? 8 : 13;
-  if (g2) return lg == 15 ? 8 : 16;
-  return (lg == 15 || lg == 16) ? 13 : lg <= 20 ? 16 : 20;
+  // [r6] re-swept after the merges of the bucket runs moved to lane pairs / one fused launch and "big run" became relative to
+  // the average run (profiles/r6_call20_table_bits_final.txt; the two sweeps before it, r6_call16 / r6_call17, were taken with a
+  // fixed threshold that sent half of a tiny table's runs down the long path).  The cheaper merges favour MORE partials per
+  // bucket: 26 rows of 10 bits for G1 2^11 ... 2^14 (0.44 / 0.46 / 0.50 / 0.57 ms against 0.47 (13 bits) / 0.52 / 0.55 / 0.58
+  // with 16), 13 bits for G1 2^15 ... 2^18 (2^16 0.71 against 0.87, 2^17 0.93 against 1.03, 2^18 1.38 against 1.42 with 16);
+  // G2 keeps its 8-bit rows up to 2^12 (0.80 / 0.97 against 1.02 / 1.07 with 16), takes 10 bits at 2^13 and is back on 16 bits
+  // at 2^15 (1.49 against 1.90 ms with the 8-bit rows round 4 chose for it)
+  if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : 16;
+  if (lg <= 10) return 13;
+  return lg <= 14 ? 10 : lg <= 18 ? 13 : lg <= 20 ? 16 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
