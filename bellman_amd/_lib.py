@@ -43,7 +43,7 @@ EXPORTS = [
 # ... and what include/bellman_hip_test.h declares: test hooks and the built-in demo circuits, in libbellman_hip_test.so
 TEST_EXPORTS = [
     "bh_groth16_prove_demo", "bh_groth16_demo_r1cs", "bh_groth16_prove_demo_r1cs", "bh_groth16_prove_demo_async", "bh_groth16_prove_demo_r1cs_part",
-    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev",
+    "bh_test_fr_mul_dev", "bh_test_fp_mul_dev", "bh_test_point_add_dev", "bh_test_g2_k3_dev", "bh_test_g2_pairs_dev", "bh_test_g2_k6_dev",
     "bh_test_fr_mul_host", "bh_test_fr_mul_bform_host", "bh_test_fp_mul_host", "bh_test_point_add_host", "bh_test_point_mul_host", "bh_test_fr_inv_host", "bh_test_fp_lazy_host", "bh_test_proof_slice", "bh_test_synthesis_ms", "bh_test_fr_from_u512_host", "bh_test_fr_ops_host",
     "bh_test_groth16_prove_via_call_sites", "bh_test_demo_assignment", "bh_test_shard_cuts", "bh_test_pool_size_class", "bh_test_capture_check",
 ]
@@ -244,6 +244,7 @@ def load():
     lib.bh_msm_wait_stats.argtypes = [vp, vp, c.POINTER(c.c_float), c.POINTER(c.c_uint64)]
     lib.bh_test_g2_k3_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
     lib.bh_test_g2_pairs_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+    lib.bh_test_g2_k6_dev.argtypes = [vp, vp, vp, vp, sz]
     for name in ("bh_test_fr_mul_host", "bh_test_fp_mul_host", "bh_test_fr_mul_bform_host"):
         getattr(lib, name).argtypes = [vp, vp, vp, sz]
         getattr(lib, name).restype = None

@@ -669,6 +669,101 @@ __global__ __launch_bounds__(64) void msm_sum_k2_kernel(SumJobs<FK> jobs) {
 }
 
 // ============================================================================================
+// 5''. G2 point additions on lane SEXTETS ("K6") for the latency-bound merges [r6]
+// ============================================================================================
+// The x / y split of K2 on top of the lane triples of K3 (fp2k3.cuh): a G2 point is held by two neighbouring triples -
+// the even triple (X, ZZ), the odd triple (Y, ZZZ), each an Fp2 element in (c0, c1, c0 + c1) form - and the general
+// addition runs as SEVEN product slots of one lane-local Fp product each instead of fourteen (the table of 5' above,
+// with Fp2 products).  A level of a merge tree costs ~20 us instead of the ~37 us of the lane-triple form: what the big
+// bucket runs of boolean-heavy G2 queries and the medium runs of small window tables are made of (a 90 %-boolean G2
+// query of 2^19 points: 14 levels, 0.58 ms in lane triples - profiles/r6_call5_*).  Eight workers per wavefront (48
+// lanes: a power of two for the shuffle trees).  The side exchanges are ds_bpermute moves by +-3 lanes.
+constexpr u32 K6_PER_WAVE = 8;
+__device__ __forceinline__ u32 k6_lane_in_worker() { const u32 l = k3_lane(); return l - 6u * ((l * 43u) >> 8); }   // lane % 6
+__device__ __forceinline__ u32 k6_side() { return k6_lane_in_worker() >= 3u ? 1u : 0u; }   // 0: (X, ZZ)   1: (Y, ZZZ)
+__device__ __forceinline__ fp_t k6_swap(const fp_t &x) {   // the same role's value in the other triple of my sextet
+  const int src = (int)k3_lane() + (k6_side() ? -3 : 3);
+  fp_t r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = (u32)__shfl((int)x.l[i], src);
+  return r;
+}
+// the (triple-uniform) predicate as the `want_side` triple of my sextet sees it
+__device__ __forceinline__ bool k6_flag_from(bool mine, u32 want_side) {
+  const u32 lane = k3_lane();
+  const u64 m = __ballot(mine);
+  return (m >> (lane - k6_lane_in_worker() + 3u * want_side)) & 1;
+}
+__device__ __forceinline__ void k6_load(HalfPt &h, const XYZZ<Fp2Ops> *p) {
+  const bool y = k6_side();
+  Fp2K3Ops::load(h.u, y ? &p->y : &p->x);
+  Fp2K3Ops::load(h.v, y ? &p->zzz : &p->zz);
+}
+__device__ __forceinline__ void k6_store(XYZZ<Fp2Ops> *p, const HalfPt &h) {
+  const bool y = k6_side();
+  Fp2K3Ops::store(y ? &p->y : &p->x, h.u);
+  Fp2K3Ops::store(y ? &p->zzz : &p->zz, h.v);
+}
+__device__ __forceinline__ bool k6_is_identity(const HalfPt &h) { return k6_flag_from(Fp2K3Ops::is_zero(h.v), 0u); }   // ZZ == 0
+// r = a + b; r may alias a.  Every lane of a sextet takes the same branches.
+__device__ __forceinline__ void k6_add(HalfPt &r, const HalfPt &a, const HalfPt &b) {
+  typedef Fp2K3Ops F;
+  const bool y = k6_side();
+  if (k6_is_identity(a)) { r = b; return; }
+  if (k6_is_identity(b)) { r = a; return; }
+  fp_t t1, t2, d;
+  F::mul(t1, a.u, b.v);                     // U1 | S1
+  F::mul(t2, b.u, a.v);                     // U2 | S2
+  F::sub(d, t2, t1);                        // P | R
+  const bool dz = F::is_zero(d);
+  if (k6_flag_from(dz, 0u)) {               // P == 0: the same x coordinate
+    if (k6_flag_from(dz, 1u)) {             // ... and R == 0: the same point - the lane-triple doubling, both triples redundantly
+      XYZZ<F> full, dbl;
+      const fp_t ou = k6_swap(a.u), ov = k6_swap(a.v);
+      full.x = y ? ou : a.u; full.y = y ? a.u : ou;
+      full.zz = y ? ov : a.v; full.zzz = y ? a.v : ov;
+      xyzz_dbl(dbl, full);
+      r.u = y ? dbl.y : dbl.x;
+      r.v = y ? dbl.zzz : dbl.zz;
+    } else {
+      fe_zero(r.u); fe_zero(r.v);           // opposite points
+    }
+    return;
+  }
+  fp_t sq, m4, m5, m6, m7;
+  F::sqr(sq, d);                            // PP | RR
+  const fp_t osq = k6_swap(sq);             // x side: RR    y side: PP
+  const fp_t pp = y ? osq : sq;             // PP on both sides
+  F::mul(m4, k2_sel(y, d, a.v), k2_sel(y, sq, b.v));        // P PP | ZZZ1 ZZZ2
+  const fp_t om4 = k6_swap(m4);
+  const fp_t ppp = y ? om4 : m4;            // PPP on both sides
+  F::mul(m5, t1, k2_sel(y, pp, ppp));       // Q | S1P
+  fp_t x3, dq, y3;
+  F::sub(x3, osq, ppp);                     // x side: RR - PPP (the y side computes garbage it never uses)
+  F::sub(x3, x3, m5);
+  F::sub(x3, x3, m5);                       // X3 = RR - PPP - 2Q
+  F::sub(dq, m5, x3);                       // Q - X3
+  const fp_t odq = k6_swap(dq);             // y side: Q - X3
+  F::mul(m6, k2_sel(y, a.v, m4), k2_sel(y, b.v, ppp));      // T | ZZZ3
+  F::mul(m7, k2_sel(y, m6, d), k2_sel(y, pp, odq));         // ZZ3 | R (Q - X3)
+  F::sub(y3, m7, m5);                       // y side: Y3 = R (Q - X3) - S1P
+  r.u = y ? y3 : x3;
+  r.v = y ? m6 : m7;
+}
+// shuffle tree over groups of G consecutive sextets of one wavefront (G a power of two <= 8)
+__device__ __forceinline__ void k6_group_reduce(HalfPt &acc, u32 G, u32 sub) {
+  for (u32 off = G >> 1; off >= 1; off >>= 1) {
+    HalfPt o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      o.u.l[i] = __shfl_down(acc.u.l[i], off * 6);
+      o.v.l[i] = __shfl_down(acc.v.l[i], off * 6);
+    }
+    if (sub < off) k6_add(acc, acc, o);   // sextets take the branch together
+  }
+}
+
+// ============================================================================================
 // 4''. very long bucket runs: workgroup-sized pieces, the last workgroup to finish folds the piece results
 // ============================================================================================
 // What a run of L partials costs is the DEPTH of its addition tree times the latency of a point addition (~19 us on a
@@ -704,6 +799,22 @@ struct K2Worker {
   __device__ __forceinline__ static void store(XYZZ<FpOps> *m, const Pt &p) { k2_store(m, p); }
   __device__ __forceinline__ static void add(Pt &acc, const Pt &o) { k2_add(acc, acc, o); }
   __device__ __forceinline__ static void tree(Pt &acc, u32 G, u32 sub) { k2_group_reduce(acc, G, sub); }
+};
+struct K6Worker {   // G2 on lane sextets (5'' above)
+  typedef HalfPt Pt;
+  typedef Fp2Ops Mem;
+  static constexpr u32 PER_WAVE = K6_PER_WAVE, LANES = 6;
+  __device__ __forceinline__ static bool index(u32 &in_block) {
+    const u32 t = (k3_lane() * 43u) >> 8;   // sextet inside the wavefront
+    in_block = (threadIdx.x >> 6) * PER_WAVE + t;
+    return t < PER_WAVE;
+  }
+  __device__ __forceinline__ static u32 role() { return k6_lane_in_worker(); }
+  __device__ __forceinline__ static void identity(Pt &p) { fe_zero(p.u); fe_zero(p.v); }
+  __device__ __forceinline__ static void load(Pt &p, const XYZZ<Fp2Ops> *m) { k6_load(p, m); }
+  __device__ __forceinline__ static void store(XYZZ<Fp2Ops> *m, const Pt &p) { k6_store(m, p); }
+  __device__ __forceinline__ static void add(Pt &acc, const Pt &o) { k6_add(acc, acc, o); }
+  __device__ __forceinline__ static void tree(Pt &acc, u32 G, u32 sub) { k6_group_reduce(acc, G, sub); }
 };
 constexpr u32 LONG_THREADS = 256;
 template <class WK>
@@ -1065,7 +1176,11 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // the same model - levels x latency of a level x how far the launch overfills the chip.  BELLMAN_HIP_LONG_K2=0: one lane
   // per point everywhere (A/B)
   static const bool long_k2 = [] { const char *e = getenv("BELLMAN_HIP_LONG_K2"); return !(e && *e == '0'); }();
-  constexpr bool PAIRS_POSSIBLE = std::is_same<FR, FpOps>::value;
+  // [r6] G2 in lane triples: the same on lane SEXTETS (K6Worker)
+  constexpr bool G1_PAIRS = std::is_same<FR, FpOps>::value, G2_SEXTETS = std::is_same<FR, Fp2K3Ops>::value;
+  constexpr bool PAIRS_POSSIBLE = G1_PAIRS || G2_SEXTETS;   // "pairs" below: the half-point worker of the group
+  typedef typename std::conditional<G1_PAIRS, K2Worker, typename std::conditional<G2_SEXTETS, K6Worker, XyzzWorker<FR>>::type>::type HalfWorker;
+  constexpr double LEVEL_US = G2_SEXTETS ? 37.0 : 19.0, HALF_LEVEL_US = G2_SEXTETS ? 20.0 : 10.5;   // a tree level, by worker kind
   u32 run_lanes = 8;
   bool runs_on_pairs = false;
   {
@@ -1079,8 +1194,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
         if (cost < best_cost) { best_cost = cost; run_lanes = g; runs_on_pairs = pairs; }
       }
     };
-    sweep(tree_per_wave<FR>(), 19.0, false);
-    if (PAIRS_POSSIBLE && long_k2) sweep(K2Worker::PER_WAVE, 10.5, true);
+    sweep(tree_per_wave<FR>(), LEVEL_US, false);
+    if (PAIRS_POSSIBLE && long_k2) sweep(HalfWorker::PER_WAVE, HALF_LEVEL_US, true);
     // (the model takes every bucket for a queued run - true of window-table plans; where a typical bucket fits a chunk only
     // the few outliers are queued and the chip has the lanes)
     if (PAIRS_POSSIBLE && long_k2 && avg_chunks <= 1.0) { run_lanes = 8; runs_on_pairs = true; }
@@ -1095,7 +1210,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // 2^11 G2 points: 64 chunks per bucket) "big" starts at twice the average (round 6, first cut: half of that table's runs
   // went down the long path, 0.81 -> 1.06 ms)
   const u32 big_chunks = std::max(std::max(32u, 4u * run_lanes), (u32)(2.0 * (double)p.n / (double)p.nb / (double)p.chunk));
-  const u32 piece = long_pairs ? long_piece<K2Worker>() : long_piece<XyzzWorker<FR>>();
+  const u32 piece = long_pairs ? long_piece<HalfWorker>() : long_piece<XyzzWorker<FR>>();
   const u32 max_big = (u32)(nslots / (big_chunks + 1) + 1);
   // sum of ceil(L_r / piece) over the big runs: consecutive runs share one chunk, so sum L_r <= nslots + max_big
   const u32 max_pieces = (u32)((nslots + max_big) / piece + max_big + 1);
@@ -1253,16 +1368,16 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       hipLaunchKernelGGL(msm_merge_long_kernel<WKL>, lg, dim3(LONG_THREADS), 0, st, pts, head, tail, p.c, p.chunks_per_window,   \
                          big_runs, max_big, piece_out, max_pieces, err)
       if constexpr (PAIRS_POSSIBLE) {
-        if (runs_on_pairs && long_pairs) { BH_SPLIT(K2Worker, K2Worker); }
-        else if (long_pairs) { BH_SPLIT(XyzzWorker<FR>, K2Worker); }
+        if (runs_on_pairs && long_pairs) { BH_SPLIT(HalfWorker, HalfWorker); }
+        else if (long_pairs) { BH_SPLIT(XyzzWorker<FR>, HalfWorker); }
         else { BH_SPLIT(XyzzWorker<FR>, XyzzWorker<FR>); }
       } else {
         BH_SPLIT(XyzzWorker<FR>, XyzzWorker<FR>);
       }
 #undef BH_SPLIT
     } else if constexpr (PAIRS_POSSIBLE) {
-      if (runs_on_pairs && long_pairs) BH_TAIL(K2Worker, K2Worker);
-      else if (long_pairs) BH_TAIL(XyzzWorker<FR>, K2Worker);
+      if (runs_on_pairs && long_pairs) BH_TAIL(HalfWorker, HalfWorker);
+      else if (long_pairs) BH_TAIL(XyzzWorker<FR>, HalfWorker);
       else BH_TAIL(XyzzWorker<FR>, XyzzWorker<FR>);
     } else {
       BH_TAIL(XyzzWorker<FR>, XyzzWorker<FR>);

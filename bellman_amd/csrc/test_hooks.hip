@@ -78,6 +78,51 @@ static int test_g2_lanes(Context &c, void *out_add, void *out_madd, void *out_db
     }
   return BH_OK;
 }
+// the lane-sextet (K6) general addition of the merge kernels on its own: r[i] = a[i] + b[i], one sextet per pair of points
+__global__ __launch_bounds__(64) void k6_add_kernel(XYZZ<Fp2Ops> *r, const Affine<Fp2Ops> *a, const Affine<Fp2Ops> *b, u32 n) {
+  const u32 t = (k3_lane() * 43u) >> 8;
+  const u32 i = blockIdx.x * K6_PER_WAVE + t;
+  if (t >= K6_PER_WAVE || i >= n) return;
+  const bool y = k6_side();
+  auto from_affine = [&](HalfPt &h, const Affine<Fp2Ops> *p) {
+    Fp2K3Ops::load(h.u, y ? &p->y : &p->x);
+    fp_t ox, oy;
+    Fp2K3Ops::load(ox, &p->x);
+    Fp2K3Ops::load(oy, &p->y);
+    if (Fp2K3Ops::is_zero_canonical(ox, oy)) { fe_zero(h.u); fe_zero(h.v); }   // the all-zero record is the identity
+    else Fp2K3Ops::one(h.v);
+  };
+  HalfPt pa, pb;
+  from_affine(pa, a + i);
+  from_affine(pb, b + i);
+  k6_add(pa, pa, pb);
+  k6_store(&r[i], pa);
+}
+static int test_g2_k6(Context &c, void *out_add, const void *a_dev, const void *b_dev, u64 n) {
+  typedef XYZZ<Fp2Ops> Pt;
+  if (!n) return BH_OK;
+  Pt *d = (Pt *)c.pool.acquire(n * sizeof(Pt));
+  if (!d) return BH_ERR_HIP;
+  hipLaunchKernelGGL(k6_add_kernel, dim3((u32)((n + K6_PER_WAVE - 1) / K6_PER_WAVE)), dim3(64), 0, c.stream, d,
+                     (const Affine<Fp2Ops> *)a_dev, (const Affine<Fp2Ops> *)b_dev, (u32)n);
+  int rc = hipGetLastError() == hipSuccess ? BH_OK : BH_ERR_HIP;
+  std::vector<Pt> h(n);
+  if (rc == BH_OK && hipMemcpyAsync(h.data(), d, n * sizeof(Pt), hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = BH_ERR_HIP;
+  if (hipStreamSynchronize(c.stream) != hipSuccess && rc == BH_OK) rc = BH_ERR_HIP;
+  c.pool.release(d);
+  if (rc != BH_OK) return rc;
+  typedef HostFp2Ops H;
+  for (u64 i = 0; i < n; i++) {
+    Pt q = h[i];
+    Fp2Ops::canon(q.x); Fp2Ops::canon(q.y); Fp2Ops::canon(q.zz); Fp2Ops::canon(q.zzz);   // lazily reduced on the device
+    XYZZ<H> hq;
+    memcpy(&hq, &q, sizeof hq);
+    Affine<H> aff;
+    xyzz_to_affine(aff, hq);
+    memcpy((char *)out_add + i * sizeof aff, &aff, sizeof aff);
+  }
+  return BH_OK;
+}
 static int test_g2_k3(Context &c, void *out_add, void *out_madd, void *out_dbl, const void *a_dev, const void *b_dev, u64 n) {
   return test_g2_lanes<Fp2K3Ops>(c, out_add, out_madd, out_dbl, a_dev, b_dev, n);
 }
@@ -117,6 +162,11 @@ int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void
   if (!ctx) return BH_ERR_INVALID_ARG;
   BH_HIP_CHECK(hipSetDevice(ctx->c.device));
   return test_g2_k3(ctx->c, out_add_host, out_madd_host, out_dbl_host, a_dev, b_dev, n);
+}
+int bh_test_g2_k6_dev(bh_ctx *ctx, void *out_add_host, const void *a_dev, const void *b_dev, size_t n) {
+  if (!ctx) return BH_ERR_INVALID_ARG;
+  BH_HIP_CHECK(hipSetDevice(ctx->c.device));
+  return test_g2_k6(ctx->c, out_add_host, a_dev, b_dev, n);
 }
 int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
                          const void *b_dev, size_t n) {

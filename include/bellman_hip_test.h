@@ -50,6 +50,8 @@ int bh_test_point_add_dev(bh_ctx *ctx, int group, void *r_dev, const void *a_dev
  * addition, by the mixed addition (a[i] stays when b[i] is the identity), and 2 a[i]; n affine records each, HOST */
 int bh_test_g2_k3_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
                       const void *b_dev, size_t n);
+/* the general addition in the lane-SEXTET (K6) form of the merge kernels (csrc/msm_ec.cuh 5''): a[i] + b[i], affine out, HOST */
+int bh_test_g2_k6_dev(bh_ctx *ctx, void *out_add_host, const void *a_dev, const void *b_dev, size_t n);
 /* the same in the lane-pair form (csrc/fp2pair.cuh: schoolbook Fp2 products, one reduction per lane) */
 int bh_test_g2_pairs_dev(bh_ctx *ctx, void *out_add_host, void *out_madd_host, void *out_dbl_host, const void *a_dev,
                          const void *b_dev, size_t n);

@@ -119,6 +119,33 @@ def test_g2_k3_group_law(worker):
     assert not outs[0][3].any() and not outs[0][4].any()
 
 
+def test_g2_lane_sextet_addition(worker):
+    """[r6] The lane-sextet (K6) general addition the G2 merge kernels run (csrc/msm_ec.cuh 5'': the x / y split of a point
+    over two lane triples, seven product slots instead of fourteen): a + b for G2 points including P + P (the doubling
+    fallback), P + (-P) and the identity on either side, against the oracle's group law.  70 points: nine wavefronts of 8
+    sextets, a ragged tail."""
+    from bellman_amd import _lib
+
+    lib = _lib.load()
+    n = 70
+    A = cref.gen_bases(2, n, a=19, b=3)
+    B = cref.gen_bases(2, n, a=23, b=29)
+    B[0] = A[0]                                   # doubling
+    B[1] = 0                                      # + identity
+    A[2] = 0                                      # identity +
+    B[3] = cref.point_mul(2, A[3], Q - 1)         # P + (-P)
+    A[4] = 0
+    B[4] = 0
+    B[9] = A[9]                                   # a doubling beside ordinary additions in one wavefront
+    B[n - 1] = A[n - 1]
+    dA, dB = _dev(worker, A), _dev(worker, B)
+    out = np.zeros((n, 24), dtype=np.uint64)
+    assert lib.bh_test_g2_k6_dev(worker.ctx, _p(out), dA, dB, n) == 0
+    want = np.stack([cref.point_add(2, A[i], B[i]) for i in range(n)])
+    assert np.array_equal(out, want)
+    assert not out[3].any() and not out[4].any()
+
+
 def test_g2_lane_pair_group_law(worker):
     """The lane-pair form of Fp2 the large G2 accumulations compute in (csrc/fp2pair.cuh: schoolbook products with one
     reduction per lane, operands exchanged by DPP): the same cases as the lane-triple test above.  70 points: more than
