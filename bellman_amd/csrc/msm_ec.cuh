@@ -763,6 +763,62 @@ __device__ __forceinline__ void k6_group_reduce(HalfPt &acc, u32 G, u32 sub) {
   }
 }
 
+// msm_sum_kernel for G2 with lane-sextet workers: 256 threads = four wavefronts of 8 sextets = 32 workers per block; a
+// group of G <= 8 workers folds inside its wavefront, 16 or 32 through LDS.  For the launches that leave the chip mostly
+// empty (the bucket sets of small window tables: a MiMC-322 proof's G2 job spent 2 x 136 us here in lane triples).
+template <class FK>   // always Fp2K3Ops: a template only so that both translation units may see the definition
+__global__ __launch_bounds__(256) void msm_sum_k6_kernel(SumJobs<FK> jobs) {
+  u32 blk = blockIdx.x;
+  u32 which = 0;
+  if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
+  const SumDesc d = jobs.j[which].d;
+  const XYZZ<Fp2Ops> *in = jobs.j[which].in;
+  XYZZ<Fp2Ops> *out = jobs.j[which].out;
+  constexpr u32 PW = K6_PER_WAVE, WPB = 4 * PW;   // 32 workers per block
+  __shared__ HalfPt wave_part[4][6];
+  const u32 lane = k3_lane(), t_in_wave = (lane * 43u) >> 8, wave = threadIdx.x >> 6, role = k6_lane_in_worker();
+  const bool live = t_in_wave < PW;
+  const u32 t = wave * PW + t_in_wave;      // worker inside the block
+  const u32 G = d.lanes;                    // workers per output (a power of two <= 32)
+  const u32 g = (blk * WPB + t) / G;
+  const u32 sub = t & (G - 1);
+  HalfPt acc;
+  fe_zero(acc.u); fe_zero(acc.v);
+  if (live && g < d.groups) {
+    const u32 outer = g / d.inner, in_idx = g % d.inner;
+    const XYZZ<Fp2Ops> *base = in + ((u64)outer << d.group_shift);
+    if (d.mode == SUM_STRIDED) {
+      for (u32 k = sub; k < d.count; k += G) {
+        HalfPt o;
+        k6_load(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
+        k6_add(acc, acc, o);
+      }
+    } else {  // SUM_BITS: in_idx = bit position
+      for (u32 i = sub; i < d.count; i += G) {
+        if ((i >> in_idx) & 1) {
+          HalfPt o;
+          k6_load(o, base + i);
+          k6_add(acc, acc, o);
+        }
+      }
+    }
+  }
+  if (G <= PW) {
+    k6_group_reduce(acc, G, sub);
+  } else {
+    // the group spans G / 8 wavefronts: tree inside each wavefront, partials through LDS, tree over the partials
+    k6_group_reduce(acc, PW, t_in_wave);
+    if (live && t_in_wave == 0) wave_part[wave][role] = acc;
+    __syncthreads();
+    const u32 wpg = G / PW;                      // wavefronts per group (2 or 4); the group's first wavefront folds
+    if ((wave & (wpg - 1)) == 0) {
+      if (live && t_in_wave < wpg) acc = wave_part[wave + t_in_wave][role]; else { fe_zero(acc.u); fe_zero(acc.v); }
+      k6_group_reduce(acc, wpg, t_in_wave);
+    }
+  }
+  if (live && sub == 0 && g < d.groups) k6_store(&out[g], acc);
+}
+
 // ============================================================================================
 // 4''. very long bucket runs: workgroup-sized pieces, the last workgroup to finish folds the piece results
 // ============================================================================================
@@ -1423,7 +1479,8 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     const u32 total = js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks;
     if (!total) return true;
     if constexpr (std::is_same<FR, FpOps>::value) {
-      if (k2_on && (u64)total * 2 <= (u64)c.num_cus * 4) {   // blocks are single wavefronts
+      static const double k2_fill = [] { const char *e = getenv("BELLMAN_HIP_K2_SUM_FILL"); return e && *e ? atof(e) : 4.0; }();   // wavefronts per SIMD the lane-pair launch may reach
+      if (k2_on && (double)total * 2 <= k2_fill * (double)c.num_cus * 4) {   // blocks are single wavefronts
         for (int q = 0; q < 3; q++) {
           SumJob<FR> &j = js.j[q];
           if (!j.nblocks) continue;
@@ -1432,6 +1489,25 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
         }
         hipLaunchKernelGGL(msm_sum_k2_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64), 0, st, js);
         return hipGetLastError() == hipSuccess;
+      }
+    }
+    if constexpr (std::is_same<FR, Fp2K3Ops>::value) {
+      // G2: the same idea on lane sextets (32 workers per 256-thread block) while the launch stays within one wavefront per SIMD
+      if (k2_on) {
+        SumJobs<FR> k6 = js;
+        u32 blocks6 = 0;
+        for (int q = 0; q < 3; q++) {
+          SumJob<FR> &j = k6.j[q];
+          if (!j.nblocks) continue;
+          if (j.d.lanes > 32) j.d.lanes = 32;
+          j.nblocks = (u32)(((u64)j.d.groups * j.d.lanes + 31) / 32);
+          blocks6 += j.nblocks;
+        }
+        static const double k6_fill = [] { const char *e = getenv("BELLMAN_HIP_K6_SUM_FILL"); return e && *e ? atof(e) : 8.0; }();   // blocks per CU the launch may reach
+        if ((double)blocks6 <= k6_fill * (double)c.num_cus) {
+          hipLaunchKernelGGL(msm_sum_k6_kernel<FR>, dim3(blocks6), dim3(256), 0, st, k6);
+          return hipGetLastError() == hipSuccess;
+        }
       }
     }
     hipLaunchKernelGGL(msm_sum_kernel<FR>, dim3(total), dim3(sum_block_threads<FR>()), 0, st, js);
