@@ -157,7 +157,7 @@ struct bh_bases {
   bh_ctx *ctx = nullptr;
   // [r4] G1 vectors that run the classic plan (>= 2^17 points, owned by the handle): a second copy of the records at a
   // 128-byte stride, which is what the bucket accumulation gathers from - every gather is exactly one cache line (a
-  // 96-byte record at a 96-byte stride straddles two lines half of the time).  profiles/r4_call11_padded_bases.txt:
+  // 96-byte record at a 96-byte stride straddles two lines half of the time).  profiles/archive/r4_call11_padded_bases.txt:
   // FETCH_SIZE of the accumulate launch 2.20 -> 1.58 GB at 2^20; accumulate -1 % at 2^20 (the table sits in the
   // Infinity Cache either way), -3 % at 2^22 (it does not).  Dense `dev` stays what every other path and the API see.
   // BELLMAN_HIP_BASE_PAD=0 switches it off; vectors whose copy would exceed 1/16 of the device memory are not padded.
@@ -207,8 +207,8 @@ static int finish_bases(bh_ctx *ctx, bh_bases *b) {
 // overrides both limits, BELLMAN_HIP_TABLE_MAX_LOG2_G1 the G1 limit alone; 0 = never): a multiexp over a few thousand
 // terms is a chain of latency-bound steps, and with the table the chain loses the 255-step doubling ladder over the
 // windows and all but one of its bucket reductions (the CRS is registered once per circuit).
-// G1 history: 2^16 until round 4; 2^18 after profiles/r4_call13_fft_batched_loads_and_plan_sweeps.txt (2^17 1.04 vs
-// 1.31 ms, 2^18 1.47 vs 1.72).  2^19 ... 2^22 were measured and NOT adopted (profiles/r4_call16_g1_tables_2p19_2p22.txt,
+// G1 history: 2^16 until round 4; 2^18 after profiles/archive/r4_call13_fft_batched_loads_and_plan_sweeps.txt (2^17 1.04 vs
+// 1.31 ms, 2^18 1.47 vs 1.72).  2^19 ... 2^22 were measured and NOT adopted (profiles/archive/r4_call16_g1_tables_2p19_2p22.txt,
 // r4_call17_g1_tables_in_proofs.txt): a multiexp called alone gets faster - the classic plan ends in a HOST tail of 256
 // doublings + 256 additions (16 windows x 16 bit sums, 0.27-0.44 ms by box), the table plan in 19 + 20: wall 2.21 vs
 // 2.67 ms at 2^19, 3.92-3.95 vs 4.09-4.28 at 2^20, 6.95 vs 7.42 at 2^21, 12.3 vs 13.5 at 2^22 - but its bucket
@@ -310,7 +310,7 @@ const char *bh_version(void) { return "bellman_hip 0.4 (gfx950, built " __DATE__
 // A proof keeps 6-7 job streams in flight (one per multiexp + the h block); the HIP runtime multiplexes streams onto
 // GPU_MAX_HW_QUEUES hardware queues, 4 by default, and jobs that share a queue run one after the other (MiMC-322
 // proof 2.99 ms with 4 queues, 2.23 ms with 16; 12 concurrent 2^20 proofs 33.1 -> 36.2 /s:
-// profiles/r2_call12_hw_queues.txt).  The runtime reads the variable when it initialises, so the host program calls
+// profiles/archive/r2_call12_hw_queues.txt).  The runtime reads the variable when it initialises, so the host program calls
 // bh_runtime_configure() before its first HIP call (the Python loader and bench.py set the variable themselves); the
 // library no longer touches the environment behind the caller's back when it is loaded.
 static std::atomic<bool> g_hip_touched{false};      // this library has made a HIP call

@@ -190,7 +190,7 @@ struct Context {
   // The accumulation chain: bucket-accumulation launches that fill the chip run one after the other in issue order
   // (each waits for the previous one's event) instead of sharing the SIMDs - two of them side by side take twice as
   // long each, so every job of a proof would finish late and all the latency-bound merge / reduction tails would pile up
-  // at the end with the chip idle (profiles/r3_call3_proof_timeline.txt).  Chained, job k's tail runs beside job k+1's
+  // at the end with the chip idle (profiles/archive/r3_call3_proof_timeline.txt).  Chained, job k's tail runs beside job k+1's
   // accumulation.  BELLMAN_HIP_ACC_CHAIN=0 switches it off.
   std::mutex acc_mu;
   hipEvent_t last_acc_event = nullptr;

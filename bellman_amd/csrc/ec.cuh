@@ -182,7 +182,7 @@ BH_HD bool xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, PF prefetch) {
   F::sub(t, t, qq);                   // X3 = R^2 - PPP - 2Q
   if constexpr (F::FUSED_Y3_TAIL) {
     // Y3 = R*(Q - X3) - Y1*PPP as two products under ONE reduction (ff.cuh fe_mul2: 169 mads, one out-of-line call and
-    // one subtraction fewer per Fp-level product pair; profiles/r4_call1_fused_y3.txt: G1 accumulate -4.3 %, G2 -6 %)
+    // one subtraction fewer per Fp-level product pair; profiles/archive/r4_call1_fused_y3.txt: G1 accumulate -4.3 %, G2 -6 %)
     F::sub(qq, qq, t);
     acc.x = t;
     order_after(qq);

@@ -18,9 +18,9 @@
 //   * [r5] sizes with one-level tables (2^12 .. 2^24, below) run 512 threads per workgroup: 4 elements per thread,
 //     radix-4 steps (two DIT stages in registers), 128 VGPRs, FOUR wavefronts per SIMD.  The round-4 kernel - 256 threads,
 //     8 elements each, radix-8 steps, two wavefronts per SIMD - had its wavefronts parked 24 % of the time (s_waitcnt /
-//     s_barrier) and stalled at issue another 33 % (profiles/r5_fft_pmc_wait_split.json): with a second wavefront as the
+//     s_barrier) and stalled at issue another 33 % (profiles/archive/r5_fft_pmc_wait_split.json): with a second wavefront as the
 //     only cover, every park left a SIMD on one wavefront's issue rate.  Four wavefronts: -8..15 % by size and mode
-//     (profiles/r5_call1_fft_variants.txt).  The two-level kernel (single-pass sizes, sizes above 2^24, sizes over the
+//     (profiles/archive/r5_call1_fft_variants.txt).  The two-level kernel (single-pass sizes, sizes above 2^24, sizes over the
 //     table budget) keeps the 256-thread radix-8 form: at 128 registers it spills.
 //   * [r5] register steps whose tasks stay inside a wavefront's own block of the tile need no s_barrier between them (a
 //     wavefront's LDS operations execute in order): 4 barriers per tile instead of 7 at r = 11, 2 instead of 5 at r = 8
@@ -157,7 +157,7 @@ __device__ __forceinline__ void frl_canon(fr_t &r) {   // [0, 2q) -> [0, q)
 // ---- the multiplier with a pre-sliced second operand ---------------------------------------------------------
 // x * w for a table entry w in B form.  Out of line: a radix-8 step has 12 of these, inlined they would not fit the
 // instruction cache.  The entry used to be fetched inside - an L2-latency load in front of EVERY product that the
-// two wavefronts of a SIMD could not hide (23 % of the wave time, profiles/r2_call10_pmc_fft.json) - and a load
+// two wavefronts of a SIMD could not hide (23 % of the wave time, profiles/archive/r2_call10_pmc_fft.json) - and a load
 // issued by the caller before the call would be waited for at the callee's first instruction (every non-kernel
 // function starts with s_waitcnt vmcnt(0)).  So the products are chained: a call receives its own entry IN
 // REGISTERS and the address of the NEXT product's entry, issues that load first, multiplies while it is in flight
@@ -175,7 +175,7 @@ __device__ __forceinline__ TwReg tw_load(const BTw *w) {
   return t;
 }
 // entry `idx` of a one-level table: 32 bytes (48 as pre-sliced limbs: a third more to stream per element and pass for 17
-// of a product's 290 instructions - profiles/r5_call1_fft_variants.txt)
+// of a product's 290 instructions - profiles/archive/r5_call1_fft_variants.txt)
 struct MReg { u32x4 a, b; };
 __device__ __forceinline__ MReg tw_load1(const BTw *tab, u64 idx) {
   const BH_GLOBAL_AS u32x4 *q = (const BH_GLOBAL_AS u32x4 *)((const char *)tab + idx * NTT_ONE_STRIDE);
@@ -342,7 +342,7 @@ __device__ __forceinline__ TileGeo tile_geo(const NttPass &a, u64 t) {
 
 // ONE: the instantiation for sizes with one-level tables (tw1 / pre1 / post1).  Their entries stream from HBM (0.2 GB per
 // table and pass), so the chain "multiply while the next entry loads" of the two-level path - whose entries sit in L2 -
-// left a third of the wave cycles waiting (profiles/r4_final_pmc_g2_pairs_and_fft.json: SQ_WAIT_ANY 32 %): all eight
+// left a third of the wave cycles waiting (profiles/archive/r4_final_pmc_g2_pairs_and_fft.json: SQ_WAIT_ANY 32 %): all eight
 // entries of a thread are loaded at once, beside the data, before the first product.
 template <bool ONE>
 __global__ __launch_bounds__(NttCfg<ONE>::TH, NttCfg<ONE>::WAVES_PER_SIMD) void ntt_pass_kernel(NttPass a) {

@@ -35,7 +35,7 @@ namespace bellman {
 // ---- scalar field element (bls12_381::Scalar): 4x64 Montgomery limbs, little-endian -------------
 // The arithmetic a circuit and the linear-combination evaluation use per constraint (+, -, *, comparisons) is defined
 // INLINE here: as calls into the library they were a third of the synthesis time of a 2^20-constraint circuit
-// (profiles/r3_host_synthesis.txt).
+// (profiles/archive/r3_host_synthesis.txt).
 namespace fr_detail {
 typedef unsigned __int128 u128;
 constexpr uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
@@ -280,7 +280,7 @@ class DensityTracker {
 // terms of a constraint's combinations again: it evaluates them and updates the query densities (prover.rs:19-55).  It
 // therefore hands the closures a combination that is bound to an LcSink and does exactly that as each term is added -
 // nothing is stored, the object that travels through `|lc| lc + a + b` is 56 bytes instead of 230, and there is no
-// second pass.  Same values, same densities, same term order (profiles/r3_host_synthesis.txt).
+// second pass.  Same values, same densities, same term order (profiles/archive/r3_host_synthesis.txt).
 struct LcSink {
   // input_assignment / aux_assignment: the VECTORS, read per term - a closure that allocates a variable while it builds
   // its combination (the reference's borrow rules forbid it, C++ does not) may reallocate them

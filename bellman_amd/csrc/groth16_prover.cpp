@@ -47,7 +47,7 @@ static inline Fr eval(const LinearCombination &lc, DensityTracker *input_density
 // ---- recycled assignments ----------------------------------------------------------------------------------------
 // A 2^20-constraint ProvingAssignment is five vectors of 32 MiB.  Grown by push_back from empty and freed after every
 // proof they cost reallocation copies and ~40 000 first-touch page faults per proof - a third of the synthesis time
-// (profiles/r3_host_synthesis.txt).  Finished assignments are cleared (capacity kept) and handed to the next proof.
+// (profiles/archive/r3_host_synthesis.txt).  Finished assignments are cleared (capacity kept) and handed to the next proof.
 namespace {
 template <class T>
 class Recycler {
@@ -142,7 +142,7 @@ struct ProofStream {   // uploads + h block of one proof; independent of other p
   void *st = nullptr;
   // the h block is a short dependent chain on the proof's critical path (the H multiexp waits for it).
   // BELLMAN_HIP_H_PRIORITY=1 puts it on a high-priority stream; measured: no gain for one proof and 8 % less throughput
-  // with twelve proofs in flight (profiles/r3_call3_oversub.txt), so it is off by default
+  // with twelve proofs in flight (profiles/archive/r3_call3_oversub.txt), so it is off by default
   explicit ProofStream(bh_ctx *c) : ctx(c) {
     static const bool high = [] { const char *e = getenv("BELLMAN_HIP_H_PRIORITY"); return e && *e == '1'; }();
     check(bh_stream_create_priority(ctx, high ? 1 : 0, &st));
@@ -291,7 +291,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   DevBuf dscratch(ctx, log_m > 11 ? m * 32 : 32);   // FFT ping-pong vector of the h block
   StreamDrain drain2{ps};                            // (drains before dscratch is released)
   // Optional two-phase issue (BH_MSM_HOLD / bh_msm_start, BELLMAN_HIP_PROOF_HOLD=1): first every job's digit + sort
-  // stage, then the bucket accumulations in chain order.  Measured (profiles/r3_call6_hold_ab.txt): no gain for one proof
+  // stage, then the bucket accumulations in chain order.  Measured (profiles/archive/r3_call6_hold_ab.txt): no gain for one proof
   // - the accumulations are as slow with nothing beside them, 6.35 ms for G2 against 5.46 in a warm back-to-back loop:
   // the chip has just left idle clocks after the host's 51 ms of witness generation - and 12 % less throughput with
   // twelve proofs in flight (the sorts of one proof no longer fill the gaps of another).  Off by default.
@@ -350,7 +350,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
   // GPU is busy while the host stages a/b/c; small proofs (a few launches of latency-bound kernels each) put the h
   // block's dozen kernels at the head of the hardware queues instead of behind ~100 multiexp launches.
   // A small proof is bound by the HOST: every job is ~20 kernel launches, ~0.2 ms of API time, and the H multiexp can
-  // only be issued once the h block has run (profiles/r2_call21_mimc_timeline.txt: five jobs issued one after the other,
+  // only be issued once the h block has run (profiles/archive/r2_call21_mimc_timeline.txt: five jobs issued one after the other,
   // the last at 0.97 ms of a 1.62 ms GPU span).  So the seven assignment multiexps are enqueued by a helper thread while
   // this one enqueues the h block, waits for it and issues H.
   double t1;
@@ -375,7 +375,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     // The H multiexp is ordered after the h block by an event (bh_msm_async_dev_after): the host never waits between
     // them.  With the constraints evaluated on the device the h block is enqueued FIRST - nothing on the host delays it,
     // and started late it queues behind the multiexps' long kernels, the H multiexp then runs alone at the end
-    // (profiles/r3_call2_proof_timeline.txt).  With host evaluations the multiexps go first: the GPU works while the
+    // (profiles/archive/r3_call2_proof_timeline.txt).  With host evaluations the multiexps go first: the GPU works while the
     // host stages a, b, c (96 MiB of pageable memory at 2^20).
     auto issue_h = [&] {
       const Slice sl = slice_of(m - 1, part, parts);   // a.len() - 1, :238-244
@@ -389,7 +389,7 @@ static void msm_sums(const AssignmentSource &src, Parameters &params, size_t par
     if (!src.host) {
       enqueue_h_block();
       // the accumulations wait for the h block (their digit / sort stages run beside it): behind the G2 accumulation's
-      // 5 ms workgroups an FFT pass waits for a free SIMD, and the h block took 17 ms (profiles/r3_call4_proof_timeline.txt)
+      // 5 ms workgroups an FFT pass waits for a free SIMD, and the h block took 17 ms (profiles/archive/r3_call4_proof_timeline.txt)
       check(bh_ctx_accumulations_after(ctx, ps.st));
     }
     issue_seven(true);

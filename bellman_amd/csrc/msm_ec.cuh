@@ -150,7 +150,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
   // ahead and the base point one step ahead are loaded by `prefetch`, which xyzz_madd calls right before its last
   // (inline) product - the only stretch of an iteration without an out-of-line call, i.e. without a forced
   // s_waitcnt vmcnt(0) (ec.cuh).  With one resident wavefront per SIMD the two dependent loads of an iteration were
-  // 21 % of the kernel's time (profiles/r2_call8_pmc_g2_accumulate.json).
+  // 21 % of the kernel's time (profiles/archive/r2_call8_pmc_g2_accumulate.json).
   constexpr bool PIPELINED = F::LANES == 1 && F::WORDS == 24;
   // record `idx` of the vector the accumulation gathers from: every variant reads at the caller's record stride
   auto base_at = [&](u32 idx) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
 // bucket set of a window table, every workgroup recodes ALL scalars into signed digits in its LDS (a few scalars per
 // thread, redundantly per workgroup) and then each worker owns one bucket and scans the digit table for its entries:
 // density prefix, digits, radix sort, zero count, accumulation and the three merge kernels become one launch.
-// (profiles/r3_call7_small_fused.txt)
+// (profiles/archive/r3_call7_small_fused.txt)
 template <class F>
 __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub);   // defined with the merge kernels
 constexpr u32 SMALL_MAX_SCALARS = 2048, SMALL_MAX_ENTRIES = 20480 + 1024, SMALL_MAX_PER_BUCKET = 16, SMALL_LIST_CAP = 24;
@@ -359,7 +359,7 @@ __device__ __forceinline__ u32 run_last_chunk(const u64 *src, u32 n, u32 z, u32 
 // serial chain of point additions (~20 us per link).
 // wavefronts per SIMD the register allocation aims at (hipcc reads the second launch bound that way): two for every
 // bundle whose lane state allows it - the lane-triple instantiation sat at 256 VGPRs + 2 AGPRs, one wavefront per SIMD
-// for two registers (profiles/r4_call8.txt: G2 reduce 1.0 -> 0.91-0.94 ms)
+// for two registers (profiles/archive/r4_call8.txt: G2 reduce 1.0 -> 0.91-0.94 ms)
 template <class F>
 constexpr int merge_waves_per_simd() { return (F::LANES == 1 && F::WORDS == 24) ? 1 : 2; }
 template <class F>
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(LONG_THREADS) void msm_merge_tail_kernel(XYZZ<typen
 
 // Resident wavefronts per SIMD the lane cost model assumes for the reduction kernels: [0] G1, [1] G2 one lane per
 // point, [2] G2 lane triples.  One each: a second resident wavefront does NOT interleave for free in these mad-bound
-// chains (profiles/r2_call8_slots.txt: G1 2^17-2^20 reduce 0.73-0.99 ms with 1, 0.92-1.19 ms with 2; G2 within noise).
+// chains (profiles/archive/r2_call8_slots.txt: G1 2^17-2^20 reduce 0.73-0.99 ms with 1, 0.92-1.19 ms with 2; G2 within noise).
 // BELLMAN_HIP_SUM_SLOTS="a,b,c" overrides for sweeps.
 inline double sum_slot_factor(int kind) {
   static const std::array<double, 3> f = [] {

@@ -15,7 +15,7 @@ int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
   // 0 = lane triples, 1 = lane pairs, 2 = one lane per point
   const bool f_single = opts.flags & BH_MSM_G2_SINGLE_LANE, f_triples = !f_single && (opts.flags & BH_MSM_G2_LANE_TRIPLES);
   const bool f_pairs = opts.flags & BH_MSM_G2_LANE_PAIRS;   // accumulation only; combines with the two above
-  // (profiles/r4_call8.txt: pairs from 2^15 terms - 2^15 1.57 vs 1.73 ms, 2^16 1.67 vs 1.96, 2^17 2.20 vs 2.88; equal at 2^14)
+  // (profiles/archive/r4_call8.txt: pairs from 2^15 terms - 2^15 1.57 vs 1.73 ms, 2^16 1.67 vs 1.96, 2^17 2.20 vs 2.88; equal at 2^14)
   const int acc = f_pairs ? 1 : f_single ? 2 : f_triples ? 0 : (n >= ((u64)1 << 15) ? 1 : 0);
   const bool red_single = f_single ? true : f_triples ? false : (u64)pl.NB > ((u64)1 << 17);
 #define BH_G2_CASE(F, FR) return msm_enqueue<F, FR>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table)

@@ -234,16 +234,16 @@ static u32 ilog2(u64 v) { u32 r = 0; while (v >>= 1) r++; return r; }
 MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
   MsmPlan p;
   p.n = (u32)n;
-  // Window size from the MI355X sweep (profiles/r1_tune_small_sizes.txt, r1_tune_c_K_sweep.txt):
+  // Window size from the MI355X sweep (profiles/archive/r1_tune_small_sizes.txt, r1_tune_c_K_sweep.txt):
   // sizes whose top window is not a sliver (256 = 32*8 = 16*16, 20*13 leaves 9 bits) avoid a
   // few huge buckets; larger c trades bucket-reduction work against accumulation passes.
   const u32 lg = ilog2(n ? n : 1);
-  // re-swept after the field-arithmetic changes (profiles/r1_tune_small_sizes.txt, second table): the
+  // re-swept after the field-arithmetic changes (profiles/archive/r1_tune_small_sizes.txt, second table): the
   // cheaper additions moved every boundary down by 2-3 powers of two
   // G2 keeps c = 13 up to 2^17: its bucket reduction is two G2 additions per bucket and throughput-bound, 16 windows
   // of 2^15 buckets cost ~2 ms whatever n is - more than the 25 % extra accumulation of 20 windows below 2^18
-  // (profiles/r2_call4_*: 2^16 2.4 vs 3.0 ms, 2^17 3.5 vs 3.8, 2^18 5.4 = 5.4).  From 2^24 terms on the accumulation
-  // saved by 13 windows of 20 bits outweighs the 6.8 M-bucket reduction (profiles/r2_call8_c20.txt, 2^24: accumulate
+  // (profiles/archive/r2_call4_*: 2^16 2.4 vs 3.0 ms, 2^17 3.5 vs 3.8, 2^18 5.4 = 5.4).  From 2^24 terms on the accumulation
+  // saved by 13 windows of 20 bits outweighs the 6.8 M-bucket reduction (profiles/archive/r2_call8_c20.txt, 2^24: accumulate
   // 47.6 -> 37.9 ms for +5.2 ms of reduction and a third sort pass; 2^23: 28.6 vs 29.4 ms, no gain).
   int c = g2 ? (lg <= 12 ? 8 : lg <= 17 ? 13 : 16) : (lg <= 11 ? 8 : lg <= 14 ? 13 : lg <= 23 ? 16 : 20);
   if (forced_c) c = (int)std::min(24u, std::max(2u, forced_c));
@@ -264,7 +264,7 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
                               : (lg <= 11 ? 8 : lg <= 17 ? 16 : lg <= 19 ? 32 : 64);   // [r5] 2^20: 64 (below)
   // [r5] G1 at 2^20 terms: K = 64 instead of 32 - 2^18 chunks instead of 2^19, i.e. half the head / tail partials the merge
   // launch folds (merge + reduce 0.86 -> 0.69 ms) for the same accumulation (2.51 vs 2.56 ms): 3.72 -> 3.62 ms of device time,
-  // same process, alternating (profiles/r5_call4_glv_and_chunk_ab.txt); the launch is exactly two wavefronts per SIMD
+  // same process, alternating (profiles/archive/r5_call4_glv_and_chunk_ab.txt); the launch is exactly two wavefronts per SIMD
   // never let a typical bucket span many chunks: the chunk merge is serial per bucket
   // (c = 20: twice the average run - every chunk partial is a 192-byte record written, read and merged, and there
   // are 6.8 M buckets to merge into; 2^24: reduce 8.4 -> 6.1 ms)
@@ -280,20 +280,20 @@ MsmPlan make_plan(u64 n, unsigned forced_c, unsigned forced_chunk, bool g2) {
 // span a few chunks at most), which is 3-4 bits more than the classic plan uses for the same n.
 unsigned table_window_bits(u64 n_bases, bool g2) {
   // only window sizes whose top window is not a sliver (260 = 20 x 13, 256 = 16 x 16): a sliver puts the top digit of
-  // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/r2_call2_sizes_and_table_sweeps.txt:
+  // EVERY scalar into a handful of buckets, i.e. runs of n / 8 entries (profiles/archive/r2_call2_sizes_and_table_sweeps.txt:
   // c = 12 and 14 are 1.5-2x slower than 13 at 2^10-2^14)
   const u32 lg = ilog2(n_bases ? n_bases : 1);
   // 260 = 20 x 13, 256 = 16 x 16, 260 = 13 x 20.  G2 stays at 16 above 2^15: its bucket reduction is the expensive
   // part.  13 again around 2^15-2^16, where the 2^15-bucket set of c = 16 is reduced by a launch that no longer
-  // fills the chip (profiles/r2_call15_table_bits.txt: G1 2^15 0.79 vs 0.90 ms, 2^16 0.96 vs 1.03; G2 2^15 1.64 vs 1.74)
+  // fills the chip (profiles/archive/r2_call15_table_bits.txt: G1 2^15 0.79 vs 0.90 ms, 2^16 0.96 vs 1.03; G2 2^15 1.64 vs 1.74)
   // tiny G2 vectors: 32 rows of 8 bits - 128 buckets instead of 4096 mostly empty ones, a shorter reduction chain
-  // (profiles/r2_call19_table_bits_tiny.txt: 2^9 0.65 vs 0.80 ms, 2^10 0.72 vs 0.81, 2^11 0.85 vs 0.91; G1: no difference)
-  // [r4] re-swept with the lane-pair G2 accumulation and the fused G1 formula (profiles/r4_call13_*): G2 2^15 takes the
+  // (profiles/archive/r2_call19_table_bits_tiny.txt: 2^9 0.65 vs 0.80 ms, 2^10 0.72 vs 0.81, 2^11 0.85 vs 0.91; G1: no difference)
+  // [r4] re-swept with the lane-pair G2 accumulation and the fused G1 formula (profiles/archive/r4_call13_*): G2 2^15 takes the
   // 8-bit table (1.43 vs 1.53-1.54 ms with 13 / 16 bits); G1 tables now reach 2^18 (16 bits: 1.06 / 1.47 ms at 2^17 / 2^18)
   // [r4, call 16] G1 2^19-2^22 (not built automatically - api.hip auto_table_max_log2 - but on request; the tables of
   // 2^19 points and more are kept at a 128-byte record stride): 16 bits up to 2^20 (wall 2.21 / 3.95 ms against 2.72 / 4.15
   // with 20 bits), 20 bits above (2^21 6.95 vs 7.47 ms with 16 bits; 2^22 12.3 vs 14.2) -
-  // profiles/r4_call16_g1_tables_2p19_2p22.txt
+  // profiles/archive/r4_call16_g1_tables_2p19_2p22.txt
   // [r6] re-swept after the merges of the bucket runs moved to lane pairs / one fused launch and "big run" became relative to
   // the average run (profiles/r6_call20_table_bits_final.txt; the two sweeps before it, r6_call16 / r6_call17, were taken with a
   // fixed threshold that sent half of a tiny table's runs down the long path).  The cheaper merges favour MORE partials per
@@ -320,7 +320,7 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   p.hi_bits = (p.c - 1) - p.lo_bits;
   p.num_tiles = (p.n + SORT_TILE - 1) / SORT_TILE;
   // K: at least the average bucket, so that a typical run touches two chunks (one partial to fold) - shorter chunks
-  // turn EVERY bucket into a multi-chunk run and the merge into the dominant cost (profiles/r2_call3_*)
+  // turn EVERY bucket into a multi-chunk run and the merge into the dominant cost (profiles/archive/r2_call3_*)
   const u32 lg = ilog2(p.n ? p.n : 1);
   const u32 base_k = lg <= 20 ? 8 : lg <= 22 ? 16 : g2 ? 64 : 32;
   const u64 avg = (u64)p.n >> (p.c - 1);
@@ -329,8 +329,8 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   // (x BELLMAN_HIP_TABLE_OVERSUB, default 1.  A launch that fills the chip EXACTLY - one wavefront per SIMD for the
   // one-lane-per-point G2 kernel - is the fastest alone, but when other jobs' accumulations hold SIMDs at its start the
   // workgroups that find no slot wait for the first round to END: 10.2 ms instead of 5.5 inside a proof,
-  // profiles/r3_call2_proof_timeline.txt.  Shorter chunks for several rounds bound that tail but multiply the partials
-  // the merge has to fold - reduce 1.0 -> 2.0 -> 3.1 ms for 2 / 4 rounds, profiles/r3_call3_oversub.txt; the
+  // profiles/archive/r3_call2_proof_timeline.txt.  Shorter chunks for several rounds bound that tail but multiply the partials
+  // the merge has to fold - reduce 1.0 -> 2.0 -> 3.1 ms for 2 / 4 rounds, profiles/archive/r3_call3_oversub.txt; the
   // accumulation chain of common.hpp removes the cause instead.)
   static const u64 oversub = [] { const char *e = getenv("BELLMAN_HIP_TABLE_OVERSUB"); long v = e && *e ? strtol(e, nullptr, 10) : 1; return (u64)(v < 1 ? 1 : v > 64 ? 64 : v); }();
   const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2) * oversub;

@@ -419,7 +419,7 @@ def bench_fft(worker, lib, log_n=22, iters=10):
     out = {"workload": "EvaluationDomain fft/ifft/coset_fft/icoset_fft, 2^%d Fr elements resident in HBM "
                        "(BASELINE.json configs[2])" % log_n, "algorithmic_bytes_per_element": 64}
     # The clock is still ramping up when the first transforms of an idle device run: the same pass executes the same wave
-    # cycles in 287 us as the process' first mode and in 262 us as its fourth (profiles/r5_call2_fft_wave_local.txt) -
+    # cycles in 287 us as the process' first mode and in 262 us as its fourth (profiles/archive/r5_call2_fft_wave_local.txt) -
     # 40 untimed transforms (each table built once, ~25 ms of load) come first, so that all four modes are timed alike.
     for i in range(40):
         assert lib.bh_fft_fr_dev(worker.ctx, d, log_n, i & 3, None) == 0
@@ -862,7 +862,7 @@ def main():
     s_dev = torch.from_numpy(s_host.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
-    ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (tools/r5/*.sh, tools/history/)
+    ab_flags = int(os.environ.get("BH_BENCH_FLAGS", "0"), 0)   # bh_msm_opts.flags for A/B runs of a kernel variant (profiles/archive/tools_r5/*.sh, profiles/archive/tools_history/)
 
     job_stats = {}
 
@@ -1065,7 +1065,7 @@ def main():
                                 "v_mul_lo_u32 per addition" % MADS_PER_MIXED_ADD,
                         "peak_provenance": "v_mad_u64_u32 microbenchmark on this chip (tools/microbench_int.hip, "
                                            "profiles/r1_microbench_int.txt) at its sustained clock; under the accumulate kernel the "
-                                           "SQ counters put the clock near 2.0 GHz (profiles/r1_pmc_valu.json), so the fraction is "
+                                           "SQ counters put the clock near 2.0 GHz (profiles/archive/r1_pmc_valu.json), so the fraction is "
                                            "against a peak measured at a higher clock (conservative)"},
             },
         }

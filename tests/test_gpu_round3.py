@@ -578,7 +578,7 @@ def test_bucket_runs_of_every_length_class(worker, group):
     Scalars drawn from a small set of values give every window a few dozen buckets whose runs are 1 ... 60 chunks long,
     so with chunks of 8 / 16 / 32 entries every route and every kernel bundle (one lane, lane pairs, lane triples per G2
     point) sees runs of every length class.  Against the restated multiexp (src/multiexp.rs:210-301).  (Written for the
-    round-4 experiment that folded runs inside the accumulation workgroup - measured slower, profiles/r4_call5_fold_ab.txt,
+    round-4 experiment that folded runs inside the accumulation workgroup - measured slower, profiles/archive/r4_call5_fold_ab.txt,
     and removed - and kept because no other test forces these shapes.)"""
     import random
 

@@ -59,7 +59,7 @@ def test_large_host_scalar_multiexp_error_semantics(worker):
     with a full-size scalar (top window: wins over a later EOF) or a small one (the EOF wins), or under a zero scalar
     (never seen).  (Written for the round-4 experiment that issued such a multiexp as two halves so that the second
     half's upload would overlap the first half's kernels: no gain - each half pays the latency-bound stages and a host
-    tail of its own, profiles/r4_call8.txt - removed; the cases stay.)"""
+    tail of its own, profiles/archive/r4_call8.txt - removed; the cases stay.)"""
     import bellman_amd
     from bellman_amd import UnexpectedEof, UnexpectedIdentity
     from oracle import cref
@@ -124,7 +124,7 @@ def test_g1_window_table_at_128_byte_stride(worker):
     identity base under a full-size / small / zero scalar, running out of bases, and both at once == what the classic plan
     reports for the same inputs (itself == the oracle in test_large_host_scalar_multiexp_error_semantics).  (Such tables
     are built on request - bh_bases_precompute, BELLMAN_HIP_TABLE_MAX_LOG2_G1 - not automatically:
-    profiles/r4_call17_g1_tables_in_proofs.txt.)"""
+    profiles/archive/r4_call17_g1_tables_in_proofs.txt.)"""
     import bellman_amd
     import importlib
     from oracle import cref

@@ -229,7 +229,7 @@ def test_proof_2_24_config_c5(worker):
     (prove_witness_part + sums_add + assemble: what 2 / 8 ranks compute) is the same proof; (c) its largest G2 multiexp -
     b_g2 over 2^23 points, the first size without a window table: the classic 16-window plan with one lane per point in
     accumulation AND reduction - equals the restated multiexp (src/multiexp.rs:210-332) on all host cores.
-    The full comparison with the restated prover is tools/check_proof_large.py 24 (profiles/r3_proof_2p24.txt)."""
+    The full comparison with the restated prover is tools/check_proof_large.py 24 (profiles/archive/r3_proof_2p24.txt)."""
     import bellman_amd
     from bellman_amd import groth16 as pg
     from oracle.pyref import pairing
@@ -307,7 +307,7 @@ def test_fft_above_2_25(worker, log_n):
       * random data: ifft(fft(x)) == x and icoset_fft(coset_fft(x)) == x on every element.
     2^29 ... 2^31 (16 - 64 GiB vectors + as much scratch + a copy): the same method with everything generated and
     compared on the device side, tools/fft_huge.py - test_fft_2_29_device_side below runs 2^29, the output of all three
-    sizes is profiles/r4_fft_2p29_2p31.txt."""
+    sizes is profiles/archive/r4_fft_2p29_2p31.txt."""
     import bellman_amd
 
     n = 1 << log_n
@@ -345,7 +345,7 @@ def test_fft_2_29_device_side():
     """[r4] 2^29 points (16 GiB vector; three passes 10 + 10 + 9) by tools/fft_huge.py: sparse polynomial against Python
     integers at sampled outputs (fft, coset_fft), dense round trips compared on the device - the method of
     test_fft_above_2_25 without host-sized arrays.  2^30 and 2^31 (192 GiB of device memory in total) were run with the
-    same tool: profiles/r4_fft_2p29_2p31.txt (src/domain.rs:57-59 allows exp <= 31)."""
+    same tool: profiles/archive/r4_fft_2p29_2p31.txt (src/domain.rs:57-59 allows exp <= 31)."""
     import subprocess
     import sys
 

@@ -179,7 +179,7 @@ def test_prover_rs_patch_and_shim_are_consistent():
 
 def test_fused_y3_host_check(tmp_path):
     """The fused last line of the mixed addition (R*(Q - X3) - Y1*PPP as two products under one Montgomery reduction,
-    ff.cuh fe_mul2; the default since round 4, profiles/r4_call1_fused_y3.txt): the curve and field code is
+    ff.cuh fe_mul2; the default since round 4, profiles/archive/r4_call1_fused_y3.txt): the curve and field code is
     __host__ __device__, so the formula and the multiplier are also checked on the host (tests/cpp/fused_y3_check.hip) -
     against the separate products and against the general addition, incl. operands with every limb set, the doubling
     and the inverse case (src/multiexp.rs:39)."""
