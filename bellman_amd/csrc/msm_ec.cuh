@@ -120,7 +120,12 @@ __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lan
 
 // LDS_ACC: the running bucket sum lives in the lane's LDS slot instead of 48/96 VGPRs - for G2 this
 // is the difference between spilling at one wave per SIMD and fitting two.
-template <class F, bool LDS_ACC>
+// TOUCH [r6]: one lane per G1 point gathering from a window table that does not fit the Infinity Cache (2 GB for 2^20 points):
+// every record is read exactly once, so each gather is an HBM (and TLB) miss that the other resident wavefront only half
+// covers.  The variant reads ONE word of the next entry's record right before the iteration's last, inline product - the
+// same place the PIPELINED form loads its whole next point, for one live register instead of 24 - so that the line is on
+// its way into the L2 while the product runs and the real load of the next iteration finds it there.
+template <class F, bool LDS_ACC, bool TOUCH = false>
 __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const u32 *zstart,
                                                              const Affine<typename F::Mem> *bases,
                                                              XYZZ<typename F::Mem> *pts, XYZZ<typename F::Mem> *head,
@@ -182,6 +187,36 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
         adds += xyzz_madd(acc, q, prefetch) ? 1u : 0u;
       }
       q = qn;
+      e = e1;
+      e1 = e2;
+    }
+  } else if constexpr (TOUCH) {
+    static_assert(!TOUCH || (F::LANES == 1 && !LDS_ACC), "the touch variant is the one-lane register kernel");
+    u64 e = src[v.begin];
+    u64 e1 = v.begin + 1 < v.end ? src[v.begin + 1] : e;   // (past the chunk's end: an entry that was read already)
+    for (u32 p = v.begin; p < v.end; p++) {
+      const u32 d = (u32)(e >> 32);
+      if (d != cur) {   // bucket `cur` ends inside this chunk
+        store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
+        xyzz_set_identity(acc);
+        cur = d;
+      }
+      Affine<F> q;
+      load_affine<F>(q, base_at((u32)e & 0x7fffffffu));
+      u64 e2 = e1;
+      u32 touched = 0;
+      auto prefetch = [&]() {
+        touched = *reinterpret_cast<const u32 *>(base_at((u32)e1 & 0x7fffffffu));
+        if (p + 2 < v.end) e2 = src[p + 2];
+      };
+      if (aff_is_identity(q)) {
+        saw_identity = true;
+        prefetch();
+      } else {
+        if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
+        adds += xyzz_madd(acc, q, prefetch) ? 1u : 0u;
+      }
+      __asm__ volatile("" : : "v"(touched));   // the word itself is not used: this keeps the load
       e = e1;
       e1 = e2;
     }
@@ -430,6 +465,10 @@ __device__ __forceinline__ void group_reduce_points(XYZZ<F> &acc, u32 G, u32 sub
 // ============================================================================================
 // 5. reductions: G lanes per output point (serial partial sums, then a shuffle tree)
 // ============================================================================================
+// the j-th index with bit k set, j = 0, 1, ...  (SUM_BITS walks exactly the selected half of its vector: striding over ALL
+// indices left the workers whose own index has bit k clear - k < log2 G - with nothing to add and the others with twice the
+// chain; [r6] 13 -> 9 levels for the bit sums of a 2^15-bucket window, 37 -> 21 for a 2^19-bucket set)
+__device__ __forceinline__ u32 nth_with_bit(u32 j, u32 k) { return ((j >> k) << (k + 1)) | (1u << k) | (j & ((1u << k) - 1u)); }
 // out[g] = sum of a set of in[] points chosen by the mode:
 //   SUM_STRIDED: g = (outer, inner): elements in[(outer << group_shift) + inner*istride + t*stride], t < count
 //   SUM_BITS   : g = (outer, k):     elements in[(outer << group_shift) + i], i < count, bit k of i set
@@ -474,23 +513,22 @@ __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void
   XYZZ<F> &acc = LDS_ACC ? lds_acc[threadIdx.x] : reg_acc;
   xyzz_set_identity(acc);
   if (live && g < d.groups) {
-    const u32 outer = g / d.inner, in_idx = g % d.inner;
+    const u32 gg = g / d.splits, len = d.count / d.splits, k0 = (g % d.splits) * len;   // (splits == 1: the whole group)
+    const u32 outer = gg / d.inner, in_idx = gg % d.inner;
     const XYZZ<typename F::Mem> *base = in + ((u64)outer << d.group_shift);
     if (d.mode == SUM_STRIDED) {
-      for (u32 k = sub; k < d.count; k += G) {
+      for (u32 k = k0 + sub; k < k0 + len; k += G) {
         XYZZ<F> o, r;
         load_xyzz<F>(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
         xyzz_add(r, acc, o);
         acc = r;
       }
     } else {  // SUM_BITS: in_idx = bit position
-      for (u32 i = sub; i < d.count; i += G) {
-        if ((i >> in_idx) & 1) {
-          XYZZ<F> o, r;
-          load_xyzz<F>(o, base + i);
-          xyzz_add(r, acc, o);
-          acc = r;
-        }
+      for (u32 j = sub; j < (d.count >> 1); j += G) {
+        XYZZ<F> o, r;
+        load_xyzz<F>(o, base + nth_with_bit(j, in_idx));
+        xyzz_add(r, acc, o);
+        acc = r;
       }
     }
   }
@@ -630,6 +668,25 @@ __device__ __forceinline__ void k2_group_reduce(HalfPt &acc, u32 G, u32 sub) {
     if (sub < off) k2_add(acc, acc, o);   // pairs take the branch together (sub is a property of the pair)
   }
 }
+// worker `sub` of the G that share output g adds up its share of the output's elements
+__device__ __forceinline__ void k2_partial_sum(HalfPt &acc, const SumDesc &d, const XYZZ<FpOps> *in, u32 g, u32 sub, u32 G) {
+  const u32 gg = g / d.splits, len = d.count / d.splits, k0 = (g % d.splits) * len;   // (splits == 1: the whole group)
+  const u32 outer = gg / d.inner, in_idx = gg % d.inner;
+  const XYZZ<FpOps> *base = in + ((u64)outer << d.group_shift);
+  if (d.mode == SUM_STRIDED) {
+    for (u32 k = k0 + sub; k < k0 + len; k += G) {
+      HalfPt o;
+      k2_load(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
+      k2_add(acc, acc, o);
+    }
+  } else {  // SUM_BITS: in_idx = bit position
+    for (u32 j = sub; j < (d.count >> 1); j += G) {
+      HalfPt o;
+      k2_load(o, base + nth_with_bit(j, in_idx));
+      k2_add(acc, acc, o);
+    }
+  }
+}
 // msm_sum_kernel for G1 with lane-pair workers: one wavefront = 32 workers per block
 template <class FK>   // always FpOps: a template only so that both translation units may see the definition
 __global__ __launch_bounds__(64) void msm_sum_k2_kernel(SumJobs<FK> jobs) {
@@ -646,26 +703,37 @@ __global__ __launch_bounds__(64) void msm_sum_k2_kernel(SumJobs<FK> jobs) {
   HalfPt acc;
   k2_set_identity(acc);
   if (g < d.groups) {
-    const u32 outer = g / d.inner, in_idx = g % d.inner;
-    const XYZZ<FpOps> *base = in + ((u64)outer << d.group_shift);
-    if (d.mode == SUM_STRIDED) {
-      for (u32 k = sub; k < d.count; k += G) {
-        HalfPt o;
-        k2_load(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
-        k2_add(acc, acc, o);
-      }
-    } else {  // SUM_BITS: in_idx = bit position
-      for (u32 i = sub; i < d.count; i += G) {
-        if ((i >> in_idx) & 1) {
-          HalfPt o;
-          k2_load(o, base + i);
-          k2_add(acc, acc, o);
-        }
-      }
-    }
+    k2_partial_sum(acc, d, in, g, sub, G);
   }
   k2_group_reduce(acc, G, sub);
   if (sub == 0 && g < d.groups) k2_store(&out[g], acc);
+}
+// The same with ONE output per workgroup of NW = blockDim.x / 64 <= 4 wavefronts (G = 32 NW workers): tree inside each wavefront,
+// the NW partial sums through LDS, tree over them in the first wavefront.  For the handful of long sums a big single bucket
+// set ends in (the 20-bit window table of a 2^20-point G1 query: 10 + 9 bit sums and a total over 512 selected points
+// each were 16 serial additions + 5 levels on one wavefront; 2 + 5 + 3 here).
+template <class FK>
+__global__ __launch_bounds__(256) void msm_sum_k2_wide_kernel(SumJobs<FK> jobs) {
+  u32 blk = blockIdx.x;
+  u32 which = 0;
+  if (blk >= jobs.j[0].nblocks) { blk -= jobs.j[0].nblocks; which = 1; if (blk >= jobs.j[1].nblocks) { blk -= jobs.j[1].nblocks; which = 2; } }
+  const SumDesc d = jobs.j[which].d;
+  const XYZZ<FpOps> *in = jobs.j[which].in;
+  XYZZ<FpOps> *out = jobs.j[which].out;
+  __shared__ HalfPt wave_part[4][2];
+  const u32 NW = blockDim.x >> 6, wave = threadIdx.x >> 6, t_in_wave = (threadIdx.x & 63u) >> 1, role = k2_role();
+  const u32 g = blk;                        // one output per workgroup
+  HalfPt acc;
+  k2_set_identity(acc);
+  if (g < d.groups) k2_partial_sum(acc, d, in, g, wave * 32 + t_in_wave, NW * 32);
+  k2_group_reduce(acc, 32, t_in_wave);
+  if (t_in_wave == 0) wave_part[wave][role] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    if (t_in_wave < NW) acc = wave_part[t_in_wave][role]; else k2_set_identity(acc);
+    k2_group_reduce(acc, NW, t_in_wave);
+    if (t_in_wave == 0 && g < d.groups) k2_store(&out[g], acc);
+  }
 }
 
 // ============================================================================================
@@ -785,21 +853,20 @@ __global__ __launch_bounds__(256) void msm_sum_k6_kernel(SumJobs<FK> jobs) {
   HalfPt acc;
   fe_zero(acc.u); fe_zero(acc.v);
   if (live && g < d.groups) {
-    const u32 outer = g / d.inner, in_idx = g % d.inner;
+    const u32 gg = g / d.splits, len = d.count / d.splits, k0 = (g % d.splits) * len;   // (splits == 1: the whole group)
+    const u32 outer = gg / d.inner, in_idx = gg % d.inner;
     const XYZZ<Fp2Ops> *base = in + ((u64)outer << d.group_shift);
     if (d.mode == SUM_STRIDED) {
-      for (u32 k = sub; k < d.count; k += G) {
+      for (u32 k = k0 + sub; k < k0 + len; k += G) {
         HalfPt o;
         k6_load(o, base + (u64)in_idx * d.istride + (u64)k * d.stride);
         k6_add(acc, acc, o);
       }
     } else {  // SUM_BITS: in_idx = bit position
-      for (u32 i = sub; i < d.count; i += G) {
-        if ((i >> in_idx) & 1) {
-          HalfPt o;
-          k6_load(o, base + i);
-          k6_add(acc, acc, o);
-        }
+      for (u32 j = sub; j < (d.count >> 1); j += G) {
+        HalfPt o;
+        k6_load(o, base + nth_with_bit(j, in_idx));
+        k6_add(acc, acc, o);
       }
     }
   }
@@ -1196,6 +1263,16 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // bundle of the merge and reduction kernels; records in memory are Affine / XYZZ over F::Mem == FR::Mem, so the two
 // can differ: a big G2 job accumulates one lane per point (throughput) and reduces a window table's 2^15 buckets in
 // lane triples (latency).
+// whether the G1 accumulation touches the next entry's record ahead of time (msm_accumulate_kernel<.., TOUCH>): gathers from
+// a window table larger than the Infinity Cache.  BELLMAN_HIP_ACC_TOUCH=0 / 1 forces it off / on for every one-lane G1
+// accumulation (A/B).
+static inline bool touch_next(bool g2, bool use_table, u64 gathered_bytes, u64 /*hbm_total*/) {
+  static const int env = [] { const char *e = getenv("BELLMAN_HIP_ACC_TOUCH"); return e && *e ? (*e == '0' ? 0 : 1) : -1; }();
+  if (g2) return false;
+  if (env >= 0) return env == 1;
+  return use_table && gathered_bytes > ((u64)256 << 20);
+}
+
 template <class F, class FR>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
                        u64 n, int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
@@ -1287,6 +1364,18 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(BigRun));
   const size_t o_pieces = carve((u64)max_pieces * sizeof(Pt));
   const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
+  // [r6] piece sums of the two-stage row / column sums (G1, 2^17 ... 2^21 buckets; below): pieces of `two_len` elements - the
+  // launch of 2 NB / two_len lane pairs is then two wavefronts per SIMD (four with one lane per point and half the length)
+  u32 two_len = 16;
+  if (!G2) {
+    static const int len_env = [] { const char *e = getenv("BELLMAN_HIP_SUM_TWO_LEN"); return e && *e ? atoi(e) : 0; }();
+    const u64 target = (u64)c.num_cus * 4 * 2 * 32;
+    two_len = 4;
+    while (two_len < 64 && 2ull * p.NB / two_len > target) two_len <<= 1;
+    if (len_env >= 2) two_len = (u32)len_env;
+  }
+  const bool want_part = !G2 && p.NB >= (1u << 17) && p.NB <= (1u << 21) && Lw >= 32 && H >= 32;
+  const size_t o_part = want_part ? carve((u64)p.W * ((u64)H * (Lw / std::min(two_len, Lw)) + (u64)Lw * (H / std::min(two_len, H))) * sizeof(Pt)) : 0;
   const size_t o_prefix = density_dev ? carve((nwords + 1) * 4) : 0;
   char *ws = (char *)c.pool.acquire(off);
   if (!ws) return BH_ERR_HIP;
@@ -1301,6 +1390,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   BigRun *big_runs = (BigRun *)(ws + o_big);
   Pt *piece_out = (Pt *)(ws + o_pieces);
   Pt *rowcol = (Pt *)(ws + o_rowcol), *bits = (Pt *)(ws + o_bits);
+  Pt *part = want_part ? (Pt *)(ws + o_part) : nullptr;
   ErrFlags *err = b.err;
   job.err_dev = err;
   job.scalars_dev = scalars_dev; job.density_dev = density_dev; job.word_prefix = b.word_prefix;
@@ -1377,6 +1467,9 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     if constexpr (F::LANES == 1) {
       if (lds_acc)
         hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
+                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
+      else if (touch_next(G2, use_table, (u64)p.Wd * acc_stride * n_bases, c.hbm_total))
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, !G2>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
                            tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
       else
         hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
@@ -1475,12 +1568,32 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   // G1 launches that leave at least half of the SIMDs empty run on lane pairs (K2, above): half the latency per
   // addition for twice the lanes.  BELLMAN_HIP_SUM_K2=0 switches it off.
   static const bool k2_on = [] { const char *e = getenv("BELLMAN_HIP_SUM_K2"); return !(e && *e == '0'); }();
-  auto launch_sums = [&](SumJobs<FR> js) -> bool {
+  // force: 0 = by the rules below, 1 = lane pairs, 2 = one lane per point (the first stage of a two-stage sum chooses)
+  auto launch_sums = [&](SumJobs<FR> js, int force = 0) -> bool {
     const u32 total = js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks;
     if (!total) return true;
     if constexpr (std::is_same<FR, FpOps>::value) {
       static const double k2_fill = [] { const char *e = getenv("BELLMAN_HIP_K2_SUM_FILL"); return e && *e ? atof(e) : 4.0; }();   // wavefronts per SIMD the lane-pair launch may reach
-      if (k2_on && (double)total * 2 <= k2_fill * (double)c.num_cus * 4) {   // blocks are single wavefronts
+      // [r6] a handful of long sums (the bit sums and the total of ONE big bucket set): one workgroup of up to eight
+      // wavefronts per output (msm_sum_k2_wide_kernel).  BELLMAN_HIP_SUM_WIDE=0 switches it off
+      static const bool wide_on = [] { const char *e = getenv("BELLMAN_HIP_SUM_WIDE"); return !(e && *e == '0'); }();
+      u32 groups_all = 0, max_sel = 0;
+      for (int q = 0; q < 3; q++)
+        if (js.j[q].nblocks) {
+          groups_all += js.j[q].d.groups;
+          max_sel = std::max(max_sel, js.j[q].d.mode == SUM_BITS ? js.j[q].d.count / 2 : js.j[q].d.count / js.j[q].d.splits);
+        }
+      if (k2_on && wide_on && force == 0 && max_sel >= 128 && groups_all <= 2u * (u32)c.num_cus) {
+        // (never more than four wavefronts: a CU has four SIMDs, and the wavefronts of a workgroup that share one take turns -
+        // eight were 198 us for 2 + 5 + 3 levels, profiles/r6_call32_timeline.txt)
+        u32 nw = 2;
+        while (nw < 4 && nw * 64 < max_sel) nw <<= 1;
+        for (int q = 0; q < 3; q++)
+          if (js.j[q].nblocks) js.j[q].nblocks = js.j[q].d.groups;
+        hipLaunchKernelGGL(msm_sum_k2_wide_kernel<FR>, dim3(js.j[0].nblocks + js.j[1].nblocks + js.j[2].nblocks), dim3(64 * nw), 0, st, js);
+        return hipGetLastError() == hipSuccess;
+      }
+      if (force != 2 && k2_on && (force == 1 || (double)total * 2 <= k2_fill * (double)c.num_cus * 4)) {   // blocks are single wavefronts
         for (int q = 0; q < 3; q++) {
           SumJob<FR> &j = js.j[q];
           if (!j.nblocks) continue;
@@ -1520,6 +1633,41 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     dc = dr; dc.groups = p.W * Lw; dc.count = H; dc.inner = Lw; dc.stride = Lw; dc.istride = 1;
     SumJobs<FR> js;
     js.j[0] = make_job(pts, rows, dr); js.j[1] = make_job(pts, cols, dc); js.j[2] = js.j[1]; js.j[2].nblocks = 0;
+    // [r6] G1, bucket sets of 2^17 ... 2^21 points (16 windows of 2^15, or the 2^19 buckets of a 20-bit window table): the launch
+    // above gives every output 16-32 lane pairs - 8-16 serial additions, then a 4-5 level tree in which half, a quarter, ...
+    // of the lanes work: 12-13 levels at four wavefronts per SIMD of which 61 % is useful work (0.50 ms for the 2^20 additions
+    // of a 2^20-term multiexp, 0.27 at the multiplier's throughput).  Two stages instead: (1) every output is cut into pieces
+    // of `len` consecutive elements and ONE worker adds up a piece - no tree, every lane busy - sized so that the launch is
+    // two wavefronts per SIMD; (2) the handful of piece sums per output are folded by a small tree launch.
+    // BELLMAN_HIP_SUM_TWO_STAGE=0: off; 1: stage one on lane pairs; 2: stage one with one lane per point
+    static const int two_env = [] { const char *e = getenv("BELLMAN_HIP_SUM_TWO_STAGE"); return e && *e ? atoi(e) : -1; }();
+    bool two_stage = false;
+    if constexpr (std::is_same<FR, FpOps>::value) {
+      two_stage = two_env != 0 && part && p.NB >= (1u << 17) && p.NB <= (1u << 21) && Lw >= 32 && H >= 32;
+    }
+    if (two_stage) {
+      const bool one_lane = two_env == 2;
+      const u32 len_r = std::min(two_len, Lw), len_c = std::min(two_len, H);
+      const u32 Sr = Lw / len_r, Sc = H / len_c;
+      Pt *part_r = part, *part_c = part + (u64)dr.groups * Sr;
+      SumDesc r1 = dr, c1 = dc;
+      r1.splits = Sr; r1.groups = dr.groups * Sr; r1.lanes = 1;
+      c1.splits = Sc; c1.groups = dc.groups * Sc; c1.lanes = 1;
+      SumJobs<FR> s1;
+      s1.j[0].in = pts; s1.j[0].out = Sr > 1 ? part_r : rows; s1.j[0].d = r1; s1.j[0].nblocks = blocks_for(r1.groups, 1);
+      s1.j[1].in = pts; s1.j[1].out = Sc > 1 ? part_c : cols; s1.j[1].d = c1; s1.j[1].nblocks = blocks_for(c1.groups, 1);
+      s1.j[2] = s1.j[1]; s1.j[2].nblocks = 0;
+      if (!launch_sums(s1, one_lane ? 2 : 1)) return BH_ERR_HIP;
+      SumDesc r2, c2;
+      r2.mode = SUM_STRIDED; r2.groups = dr.groups; r2.count = Sr; r2.inner = dr.groups; r2.stride = 1; r2.istride = Sr; r2.group_shift = 0;
+      c2 = r2; c2.groups = dc.groups; c2.count = Sc; c2.inner = dc.groups; c2.istride = Sc;
+      SumJobs<FR> s2;
+      s2.j[0] = make_job(part_r, rows, r2); if (Sr <= 1) s2.j[0].nblocks = 0;
+      s2.j[1] = make_job(part_c, cols, c2); if (Sc <= 1) s2.j[1].nblocks = 0;
+      s2.j[2] = s2.j[1]; s2.j[2].nblocks = 0;
+      if (!launch_sums(s2, 1)) return BH_ERR_HIP;
+      js.j[0].nblocks = js.j[1].nblocks = 0;   // (done)
+    }
     if (G2 && FR::LANES == 1) {
       // single-lane G2 (one resident wavefront per SIMD, so sharing a SIMD doubles every step): the two jobs share
       // one launch, choose their lane counts jointly - the launch lasts as long as its longest chain, stretched by

@@ -301,9 +301,14 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // with 16), 13 bits for G1 2^15 ... 2^18 (2^16 0.71 against 0.87, 2^17 0.93 against 1.03, 2^18 1.38 against 1.42 with 16);
   // G2 keeps its 8-bit rows up to 2^12 (0.80 / 0.97 against 1.02 / 1.07 with 16), takes 10 bits at 2^13 and is back on 16 bits
   // at 2^15 (1.49 against 1.90 ms with the 8-bit rows round 4 chose for it)
+  // [r6, later] 20-bit rows for G1 2^19 ... 2^22 - 13 rows instead of the classic plan's 16 windows, i.e. 19 % fewer additions, into
+  // ONE set of 2^19 buckets - became the default once that set's reduction stopped costing what the rows save (two-stage row /
+  // column sums, bit sums over the selected half, msm_ec.cuh): 2^19 2.01 ms against 2.40 classic and 2.21 with 16-bit rows,
+  // 2^20 3.33 against 3.72-3.81 and 3.88, 2^21 6.12 against 6.90, 2^22 11.3 against 12.9 (profiles/r6_call33_tables_after_sums.txt,
+  // r6_call34_table_bits_mid.txt: 13 bits still win up to 2^18 - 1.37 against 1.38 there)
   if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : 16;
   if (lg <= 10) return 13;
-  return lg <= 14 ? 10 : lg <= 18 ? 13 : lg <= 20 ? 16 : 20;
+  return lg <= 14 ? 10 : lg <= 18 ? 13 : 20;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
@@ -336,6 +341,24 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   const u64 lanes_min = (u64)num_cus * 4 * 64 * (g2 ? 1 : 2) * oversub;
   u64 k = std::max<u64>(base_k, avg);
   k = std::min<u64>(k, std::max<u64>(base_k, (u64)p.n / lanes_min));
+  // [r6] G1 tables with MANY buckets (20-bit rows over 2^19 ... 2^22 points: the average bucket holds 13-104 entries, the chip's
+  // lanes 52-416 each): chunks of a whole number of chip-filling rounds instead of several rounds of average-bucket chunks - the
+  // accumulation takes the same time (2.29 against 2.30-2.33 ms at 2^20) and the chunk merge folds a quarter of the partials
+  // (0.21 -> 0.05 ms; profiles/r6_call29_table20_chunks.txt, r6_call30_*).  BELLMAN_HIP_TABLE_ONE_ROUND=0: the rule above
+  static const bool one_round = [] { const char *e = getenv("BELLMAN_HIP_TABLE_ONE_ROUND"); return !(e && *e == '0'); }();
+  // ... up to 128 entries per lane; beyond, R launches' worth of equal chunks (one round of 208 / 416 entries ran 8 % slower than
+  // four of 52 / 104 at 2^21 / 2^22 - 4.58 against 4.24 ms, 9.33 against 8.59 - for 0.2 ms less merging:
+  // profiles/r6_call33_tables_after_sums.txt).  And never ONE round: a launch that fills the chip exactly is as fast as any
+  // when it runs alone (2^20: 3.31-3.33 ms with one round, 3.29-3.35 with two), but inside a proof the merge and sum kernels of
+  // the job before hold some SIMDs when it starts, and the workgroups that find no slot run as a second round of full-length
+  // chunks - the first G1 accumulation of a 2^20-constraint proof took 3.75 ms against 2.3 stand-alone; with two rounds the
+  // proof's device part is 18.2-18.4 ms against 19.3-19.6 with one and 20.1 without these tables
+  // (profiles/r6_call36_proof_timeline_*.txt, r6_call37_table_rounds.txt).  BELLMAN_HIP_TABLE_ROUNDS=n: at least n rounds
+  static const u64 min_rounds = [] { const char *e = getenv("BELLMAN_HIP_TABLE_ROUNDS"); long v = e && *e ? strtol(e, nullptr, 10) : 2; return (u64)(v < 1 ? 1 : v > 16 ? 16 : v); }();
+  if (one_round && !g2 && (u64)p.n / lanes_min > k) {
+    const u64 per = ((u64)p.n + lanes_min - 1) / lanes_min, rounds = std::max<u64>(min_rounds, (per + 127) / 128);
+    k = std::max<u64>(k, ((u64)p.n + lanes_min * rounds - 1) / (lanes_min * rounds));
+  }
   p.chunk = forced_chunk ? forced_chunk : (u32)k;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;
   p.sort_passes = (p.c + 7) / 8;

@@ -26,6 +26,8 @@ struct SumDesc {
   u32 group_shift; // log2 of the elements spanned by one outer index
   u32 istride;     // STRIDED: element offset between consecutive inner indices
   u32 lanes;       // G: lanes cooperating on one output (power of two <= 64)
+  u32 splits = 1;  // STRIDED: every group is cut into `splits` equal pieces of count / splits consecutive elements, each an
+                   // output of its own (out[group * splits + piece]); `groups` then counts the pieces
 };
 struct LongRun {   // a bucket run that spans more chunks than its owner lane folds itself
   u32 w, lane, d;  // window, first chunk (holds the run's tail partial), digit

@@ -623,10 +623,16 @@ def test_msm_2_20_config_c2(worker):
     bases = cref.gen_bases(1, n, a=1, b=1)
     sc = cref.random_fr(n, 2020)
     hb = bellman_amd.Bases(worker, 1, bases)
+    assert hb.table_info()[:2] == (20, 13)     # [r6] registered with its 13-row window table: the default plan of a 2^20-point query
     got, ms = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, timed=True).wait()
     rc, want = cref.multiexp(1, bases, 0, None, sc, threads=cref.lib().orc_max_threads())
     assert rc == 0 and np.array_equal(got, want)
     print("G1 MSM 2^20 device ms [total, sort, accumulate, reduce]:", ms)
+    # the classic plan (16 windows over the plain vector) on the same inputs
+    from bellman_amd.multiexp import NO_TABLE
+    got, ms = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc, timed=True, flags=NO_TABLE).wait()
+    assert np.array_equal(got, want)
+    print("... classic plan:", ms)
     # linearity: MSM(s, B[:h]) + MSM(s, B[h:]) == MSM(s, B)
     h = n // 2
     lo = bellman_amd.multiexp(worker, hb, bellman_amd.FullDensity(), sc[:h]).wait()

@@ -122,9 +122,9 @@ def test_g1_window_table_at_128_byte_stride(worker):
     LDS-accumulator variant of the kernel (every variant takes the record stride).  Then the error semantics of
     src/multiexp.rs:55-80,295-300 on that path - the error-resolution kernel reads the dense vector, not the table: an
     identity base under a full-size / small / zero scalar, running out of bases, and both at once == what the classic plan
-    reports for the same inputs (itself == the oracle in test_large_host_scalar_multiexp_error_semantics).  (Such tables
-    are built on request - bh_bases_precompute, BELLMAN_HIP_TABLE_MAX_LOG2_G1 - not automatically:
-    profiles/archive/r4_call17_g1_tables_in_proofs.txt.)"""
+    reports for the same inputs (itself == the oracle in test_large_host_scalar_multiexp_error_semantics).  (Until round 6
+    such tables were built on request only - bh_bases_precompute, BELLMAN_HIP_TABLE_MAX_LOG2_G1; a registered vector of up
+    to 2^22 points now gets its 20-bit table automatically.)"""
     import bellman_amd
     import importlib
     from oracle import cref
@@ -179,7 +179,7 @@ def test_g1_window_table_at_128_byte_stride(worker):
     expect = {}
     for tag, bs, count in (("identity", b2, n), ("identity, one base short", b2, n + 1), ("one base short", _host, n + 1)):
         hb = bellman_amd.Bases(worker, 1, bs)
-        assert hb.table_info() == (0, 0, 0)
+        assert hb.table_info()[:2] == (20, 13)     # [r6] the automatic 20-bit table of a 2^19-point vector; NO_TABLE declines it
         for sname, scal in (("full", full), ("small", small), ("zero", zero)):
             expect[tag, sname] = outcome(hb, scal[:count], mx.NO_TABLE)
         hb.precompute(16)

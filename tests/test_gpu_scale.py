@@ -80,8 +80,8 @@ def _device_bases(worker, group, t, table=False):
 def test_msm_c5_scale_matches_oracle(worker, group, log_n, table):
     """multiexp over 2^log_n terms == restated multiexp_inner on all host cores, and == [sum s_i t_i]G.  G2 2^20 runs the
     classic 16-window plan (one lane per point, 2^19 buckets), G2 2^22 the window-table plan a registered CRS query gets;
-    G1 2^19 (16-bit rows) and 2^21 (20-bit rows) the window table kept at a 128-byte record stride (api.hip
-    bh_bases::table_padded) that G1 queries of 2^19 ... 2^22 points get since round 4."""
+    G1 2^19 and 2^21 the 20-bit window table kept at a 128-byte record stride (api.hip bh_bases::table_padded) that G1
+    queries of 2^19 ... 2^22 points get (automatically since round 6)."""
     import bellman_amd
 
     n = 1 << log_n

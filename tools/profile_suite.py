@@ -129,6 +129,7 @@ def run_tsweep(args):
     window table rebuilt for each c (bh_bases_precompute), to re-check the plan boundaries of msm_stages.hip."""
     group, lo, hi = int(args[0]), int(args[1]), int(args[2])
     cs = [int(x) for x in args[3].split(",")]
+    ks = [int(x) for x in args[4].split(",")] if len(args) > 4 else [0]   # chunk lengths K (0 = the plan's)
     from bellman_amd.multiexp import NO_TABLE
     lib = _lib.load()
     w = bellman_amd.Worker(0)
@@ -144,16 +145,17 @@ def run_tsweep(args):
             flags = NO_TABLE if c == 0 else 0
             if c:
                 bases.precompute(c)
-            best, walls = None, []
-            for it in range(7):
-                t0 = time.perf_counter()
-                r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True, flags=flags).wait()
-                walls.append((time.perf_counter() - t0) * 1e3)
-                if it and (best is None or ms[0] < best[0]):
-                    best = ms
-            walls = sorted(walls[1:])
-            print("G%d log_n=%d table c=%2d  wall median %.3f ms  device total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" %
-                  (group, log_n, c, walls[len(walls) // 2], *best), flush=True)
+            for k in ks:
+                best, walls = None, []
+                for it in range(7):
+                    t0 = time.perf_counter()
+                    r, ms = bellman_amd.multiexp(w, bases, bellman_amd.FullDensity(), None, scalars_dev=ds, n=n, timed=True, flags=flags, chunk=k).wait()
+                    walls.append((time.perf_counter() - t0) * 1e3)
+                    if it and (best is None or ms[0] < best[0]):
+                        best = ms
+                walls = sorted(walls[1:])
+                print("G%d log_n=%d table c=%2d%s  wall median %.3f ms  device total %.3f ms  sort %.3f  accumulate %.3f  reduce %.3f" %
+                      (group, log_n, c, " K=%3d" % k if k else "", walls[len(walls) // 2], *best), flush=True)
             bases.release()
 
 
