@@ -498,7 +498,10 @@ __global__ __launch_bounds__(sum_block_threads<F>(), F::LANES == 3 ? 2 : 1) void
   const SumDesc d = jobs.j[which].d;
   const XYZZ<typename F::Mem> *in = jobs.j[which].in;
   XYZZ<typename F::Mem> *out = jobs.j[which].out;
-  constexpr u32 PW = tree_per_wave<F>(), NWAVES = sum_block_threads<F>() / 64, WPB = PW * NWAVES;   // WPB == 64
+  // (lane triples: 16 per wavefront where shuffle trees want a power of two - but all 21 when every worker sums alone, the
+  // first stage of a two-stage sum [r6]: WPB == 84 then, and the host counts its blocks accordingly)
+  constexpr u32 NWAVES = sum_block_threads<F>() / 64;
+  const u32 PW = (F::LANES == 3 && d.lanes == 1) ? default_per_wave<F>() : tree_per_wave<F>(), WPB = PW * NWAVES;   // WPB == 64
   u32 t, gid;
   const bool live = worker_index<F>(PW, t, gid);   // t = worker inside the block
   const u32 G = d.lanes;
@@ -1366,15 +1369,17 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_rowcol = carve((u64)p.W * (H + Lw) * sizeof(Pt));
   // [r6] piece sums of the two-stage row / column sums (G1, 2^17 ... 2^21 buckets; below): pieces of `two_len` elements - the
   // launch of 2 NB / two_len lane pairs is then two wavefronts per SIMD (four with one lane per point and half the length)
+  // [r6] the same for G2 sets reduced on lane triples (the 2^19 buckets of a 20-bit table): 16 workers per wavefront
+  constexpr bool TWO_STAGE_FR = std::is_same<FR, FpOps>::value || std::is_same<FR, Fp2K3Ops>::value;
   u32 two_len = 16;
-  if (!G2) {
+  if (TWO_STAGE_FR) {
     static const int len_env = [] { const char *e = getenv("BELLMAN_HIP_SUM_TWO_LEN"); return e && *e ? atoi(e) : 0; }();
-    const u64 target = (u64)c.num_cus * 4 * 2 * 32;
+    const u64 target = (u64)c.num_cus * 4 * 2 * (G2 ? 16 : 32);
     two_len = 4;
     while (two_len < 64 && 2ull * p.NB / two_len > target) two_len <<= 1;
     if (len_env >= 2) two_len = (u32)len_env;
   }
-  const bool want_part = !G2 && p.NB >= (1u << 17) && p.NB <= (1u << 21) && Lw >= 32 && H >= 32;
+  const bool want_part = TWO_STAGE_FR && p.NB >= (1u << 17) && p.NB <= (1u << 21) && Lw >= 32 && H >= 32;
   const size_t o_part = want_part ? carve((u64)p.W * ((u64)H * (Lw / std::min(two_len, Lw)) + (u64)Lw * (H / std::min(two_len, H))) * sizeof(Pt)) : 0;
   const size_t o_prefix = density_dev ? carve((nwords + 1) * 4) : 0;
   char *ws = (char *)c.pool.acquire(off);
@@ -1606,7 +1611,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     }
     if constexpr (std::is_same<FR, Fp2K3Ops>::value) {
       // G2: the same idea on lane sextets (32 workers per 256-thread block) while the launch stays within one wavefront per SIMD
-      if (k2_on) {
+      if (k2_on && force != 2) {
         SumJobs<FR> k6 = js;
         u32 blocks6 = 0;
         for (int q = 0; q < 3; q++) {
@@ -1642,11 +1647,13 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     // BELLMAN_HIP_SUM_TWO_STAGE=0: off; 1: stage one on lane pairs; 2: stage one with one lane per point
     static const int two_env = [] { const char *e = getenv("BELLMAN_HIP_SUM_TWO_STAGE"); return e && *e ? atoi(e) : -1; }();
     bool two_stage = false;
-    if constexpr (std::is_same<FR, FpOps>::value) {
+    if constexpr (TWO_STAGE_FR) {
       two_stage = two_env != 0 && part && p.NB >= (1u << 17) && p.NB <= (1u << 21) && Lw >= 32 && H >= 32;
     }
     if (two_stage) {
-      const bool one_lane = two_env == 2;
+      // G2 (lane triples): stage one on the lane-triple kernel (16 workers per wavefront; sextets would halve that again)
+      static const bool g2_k6_stage1 = [] { const char *e = getenv("BELLMAN_HIP_SUM_G2_STAGE1_K6"); return e && *e == '1'; }();
+      const bool one_lane = two_env == 2 || (G2 && !g2_k6_stage1);
       const u32 len_r = std::min(two_len, Lw), len_c = std::min(two_len, H);
       const u32 Sr = Lw / len_r, Sc = H / len_c;
       Pt *part_r = part, *part_c = part + (u64)dr.groups * Sr;
@@ -1654,8 +1661,10 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
       r1.splits = Sr; r1.groups = dr.groups * Sr; r1.lanes = 1;
       c1.splits = Sc; c1.groups = dc.groups * Sc; c1.lanes = 1;
       SumJobs<FR> s1;
-      s1.j[0].in = pts; s1.j[0].out = Sr > 1 ? part_r : rows; s1.j[0].d = r1; s1.j[0].nblocks = blocks_for(r1.groups, 1);
-      s1.j[1].in = pts; s1.j[1].out = Sc > 1 ? part_c : cols; s1.j[1].d = c1; s1.j[1].nblocks = blocks_for(c1.groups, 1);
+      // (blocks of the one-lane / lane-triple kernel: 64 workers, 84 for lane triples that each sum alone)
+      const u32 wpb1 = (G2 && one_lane) ? 4 * default_per_wave<FR>() : PW;
+      s1.j[0].in = pts; s1.j[0].out = Sr > 1 ? part_r : rows; s1.j[0].d = r1; s1.j[0].nblocks = (r1.groups + wpb1 - 1) / wpb1;
+      s1.j[1].in = pts; s1.j[1].out = Sc > 1 ? part_c : cols; s1.j[1].d = c1; s1.j[1].nblocks = (c1.groups + wpb1 - 1) / wpb1;
       s1.j[2] = s1.j[1]; s1.j[2].nblocks = 0;
       if (!launch_sums(s1, one_lane ? 2 : 1)) return BH_ERR_HIP;
       SumDesc r2, c2;

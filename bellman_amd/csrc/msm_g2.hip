@@ -17,7 +17,10 @@ int msm_enqueue_g2(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip
   const bool f_pairs = opts.flags & BH_MSM_G2_LANE_PAIRS;   // accumulation only; combines with the two above
   // (profiles/archive/r4_call8.txt: pairs from 2^15 terms - 2^15 1.57 vs 1.73 ms, 2^16 1.67 vs 1.96, 2^17 2.20 vs 2.88; equal at 2^14)
   const int acc = f_pairs ? 1 : f_single ? 2 : f_triples ? 0 : (n >= ((u64)1 << 15) ? 1 : 0);
-  const bool red_single = f_single ? true : f_triples ? false : (u64)pl.NB > ((u64)1 << 17);
+  // [r6] ... but a big TABLE set (the 2^19 buckets of 20-bit rows) stays on lane triples: with the two-stage sums of msm_ec.cuh
+  // its reduction is ~1.5 ms there, 2.8 with one lane per point (profiles/r6_call38_*, r6_call39_*)
+  static const bool big_table_triples = [] { const char *e = getenv("BELLMAN_HIP_G2_BIG_TABLE_TRIPLES"); return !(e && *e == '0'); }();
+  const bool red_single = f_single ? true : f_triples ? false : ((u64)pl.NB > ((u64)1 << 17) && !(with_table && big_table_triples));
 #define BH_G2_CASE(F, FR) return msm_enqueue<F, FR>(job, bases_dev, n_bases, skip, scalars_dev, n, fmt, density_dev, opts, table)
   if (red_single) {
     if (acc == 0) BH_G2_CASE(Fp2K3Ops, Fp2Ops);

@@ -306,7 +306,11 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // column sums, bit sums over the selected half, msm_ec.cuh): 2^19 2.01 ms against 2.40 classic and 2.21 with 16-bit rows,
   // 2^20 3.33 against 3.72-3.81 and 3.88, 2^21 6.12 against 6.90, 2^22 11.3 against 12.9 (profiles/r6_call33_tables_after_sums.txt,
   // r6_call34_table_bits_mid.txt: 13 bits still win up to 2^18 - 1.37 against 1.38 there)
-  if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : 16;
+  // G2: 20-bit rows from 2^20 points (2^20 9.2-9.4 ms against 9.9-10.1 with 16-bit rows, 2^21 16.6 against 19.1; 2^19 5.7-5.9 against
+  // 5.4: its 2^19-bucket reduction is ~1.9 ms on lane triples against 0.6 for 2^15 buckets - profiles/r6_call40_*, r6_call42_*).
+  // BELLMAN_HIP_G2_TABLE20_FROM=<log2> moves the boundary (A/B)
+  static const u32 g2_from = [] { const char *e = getenv("BELLMAN_HIP_G2_TABLE20_FROM"); long v = e && *e ? strtol(e, nullptr, 10) : 20; return (u32)(v < 0 ? 0 : v); }();
+  if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : lg >= g2_from ? 20 : 16;
   if (lg <= 10) return 13;
   return lg <= 14 ? 10 : lg <= 18 ? 13 : 20;
 }
@@ -358,6 +362,14 @@ MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool
   if (one_round && !g2 && (u64)p.n / lanes_min > k) {
     const u64 per = ((u64)p.n + lanes_min - 1) / lanes_min, rounds = std::max<u64>(min_rounds, (per + 127) / 128);
     k = std::max<u64>(k, ((u64)p.n + lanes_min * rounds - 1) / (lanes_min * rounds));
+  }
+  // [r6] G2 tables with many buckets (20-bit rows): the accumulation runs on lane PAIRS, 2 x 32 workers per SIMD; whole rounds
+  // of at most 64 entries (2^20 points: four rounds of 52 - 6.86 ms against 7.51 with the 64 the rule above gives, which is
+  // 3.25 rounds; profiles/r6_call39_g2_table_bits_triples.txt)
+  if (one_round && g2 && p.c >= 18 && !forced_chunk) {
+    const u64 workers = (u64)num_cus * 4 * 2 * 32;
+    const u64 per = ((u64)p.n + workers - 1) / workers, rounds = std::max<u64>(2, (per + 63) / 64);
+    k = std::max<u64>(8, ((u64)p.n + workers * rounds - 1) / (workers * rounds));
   }
   p.chunk = forced_chunk ? forced_chunk : (u32)k;
   p.chunks_per_window = (p.n + p.chunk - 1) / p.chunk;

@@ -83,20 +83,21 @@ G2_GEN_MONT = np.array(  # BLS12-381 G2 generator, Montgomery limbs (x.c0 | x.c1
 )
 
 
-def proof_roofline(log_n, n_aux, a_dense, b_dense, device_ms):
-    """Algorithmic work of ONE create_proof (prover.rs:217-318) against the span of its device part: the five large
-    multiexps (h: m - 1 terms, l: n_aux, a_aux / b_g1 / b_g2: the dense entries of their queries) as 16 windows x terms
-    mixed additions, the 7 FFTs as (m / 2) log m butterflies, bytes per SURVEY.md 8(d)."""
+def proof_roofline(log_n, n_aux, a_dense, b_dense, device_ms, g1_rows=16):
+    """Work of ONE create_proof (prover.rs:217-318) against the span of its device part: the five large multiexps (h: m - 1
+    terms, l: n_aux, a_aux / b_g1 / b_g2: the dense entries of their queries) as digit columns x terms mixed additions -
+    g1_rows columns for the G1 queries (13 since round 6: their 20-bit window tables; 16 before), 16 for the G2 query - the 7
+    FFTs as (m / 2) log m butterflies, bytes per SURVEY.md 8(d)."""
     m = 1 << log_n
     g1_terms = (m - 1) + n_aux + a_dense + b_dense
-    mads = 16 * g1_terms * MADS_PER_MIXED_ADD + 16 * b_dense * MADS_PER_MIXED_ADD_G2 + 7 * (m // 2) * log_n * MADS_PER_FR_BUTTERFLY
+    mads = g1_rows * g1_terms * MADS_PER_MIXED_ADD + 16 * b_dense * MADS_PER_MIXED_ADD_G2 + 7 * (m // 2) * log_n * MADS_PER_FR_BUTTERFLY
     nbytes = g1_terms * BYTES_PER_TERM_G1 + b_dense * BYTES_PER_TERM_G2 + 7 * 64 * m + 128 * m
     t = device_ms * 1e-3
     return {"bound": "alu", "unit": "Tmad/s", "peak": MAD_PEAK_T, "achieved": round(mads / t / 1e12, 2), "frac": round(mads / t / 1e12 / MAD_PEAK_T, 4),
             "device_ms": round(device_ms, 2),
-            "work": "16 windows x (h %d + l %d + a_aux %d + b_g1 %d) G1 mixed additions x %d mads + 16 x %d G2 mixed additions x %d "
+            "work": "%d digit columns x (h %d + l %d + a_aux %d + b_g1 %d) G1 mixed additions x %d mads + 16 x %d G2 mixed additions x %d "
                     "(three Fp products per Fp2 product) + 7 FFTs x (m/2) log m butterflies x %d; the input multiexps, the fused "
-                    "quotient and the constraint evaluation not counted" % (m - 1, n_aux, a_dense, b_dense, MADS_PER_MIXED_ADD, b_dense,
+                    "quotient and the constraint evaluation not counted" % (g1_rows, m - 1, n_aux, a_dense, b_dense, MADS_PER_MIXED_ADD, b_dense,
                                                                             MADS_PER_MIXED_ADD_G2, MADS_PER_FR_BUTTERFLY),
             "hbm": {"algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / t / 1e9, 1), "frac_of_8TBps": round(nbytes / t / 8e12, 5)}}
 
@@ -268,13 +269,14 @@ def bench_create_proof(worker, lib, log_n, proofs=10, cpu_baseline=True):
                       "synthesis excluded (it would add to the CPU side only)" % log_n,
             "seconds": round(tcpu["total_s"], 3),
         }
+    g1_rows = params.bases("h").table_info()[1] or 16   # digit columns of the G1 multiexps: the rows of their window tables
     r1cs.release()
     params.release()
     m = np.median(np.array(tms), axis=0)
     mr = np.median(np.array(tms_r), axis=0)
     pop = lambda words: int(np.unpackbits(words.view(np.uint8)).sum())  # noqa: E731
     n_aux = asg["aux_assignment"].shape[0]
-    roof = proof_roofline(log_n, n_aux, pop(asg["a_aux_density"]), pop(asg["b_aux_density"]), float(mr[4]) - float(mr[0]))
+    roof = proof_roofline(log_n, n_aux, pop(asg["a_aux_density"]), pop(asg["b_aux_density"]), float(mr[4]) - float(mr[0]), g1_rows)
     return {
         "workload": "groth16::create_proof, synthetic multiplicative-chain R1CS, 2^%d constraints, 1 public input "
                     "(BASELINE.json configs[3]): 7 FFTs + fused quotient, 4 large G1 + 1 large G2 multiexp (+3 small)" % log_n,
@@ -855,9 +857,14 @@ def main():
                                    ctypes.c_void_p(t_dev.data_ptr()), n, 0, ctypes.c_void_p(bases_dev.data_ptr()), None)
     assert rc == 0
     worker.synchronize()
-    # registered like a CRS query (bh_bases_copy_dev: the handle owns its device copy - and, for a G1 vector of this
-    # size, the 128-byte-stride copy the accumulation gathers from); no window table at this size
+    # registered like a CRS query (bh_bases_copy_dev: the handle owns its device copy and - a G1 vector of 2^19 ... 2^22
+    # points, since round 6 - its 13-row 20-bit window table at a 128-byte record stride: 1.7 GB for 2^20 points, built once
+    # at registration in ~0.13 s; like the base upload it is outside the timed region, SURVEY.md 8d "excl. one-time base upload")
+    treg0 = time.perf_counter()
     bases = bellman_amd.Bases.copy_device(worker, 1, ctypes.c_void_p(bases_dev.data_ptr()), n)
+    worker.synchronize()
+    register_ms = (time.perf_counter() - treg0) * 1e3
+    table_bits, table_rows, table_bytes = bases.table_info()
     s_host = splitmix_scalars(n, 0x5CA1A25 + rank * 4 * n)
     s_dev = torch.from_numpy(s_host.view(np.int64)).cuda()
     torch.cuda.synchronize()
@@ -933,6 +940,21 @@ def main():
         for _ in range(max(1, min(args.steps, 5))):
             bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), s_host).wait()
         pcie_value = n * max(1, min(args.steps, 5)) / (time.perf_counter() - th0) / 1e6
+
+    # the classic plan on the same handle (16 windows over the plain vector, no table; BH_MSM_NO_TABLE): what `value` was
+    # measured on until round 6.  (A vector registered WITH a table has no 128-byte-stride copy of its points, which the
+    # classic plan's gathers gain 1-3 % from: BELLMAN_HIP_TABLE_MAX_LOG2_G1=18 reproduces the earlier default exactly.)
+    classic_value = classic_ms = None
+    if extras and table_rows:
+        from bellman_amd.multiexp import NO_TABLE
+        cl = []
+        for _ in range(max(3, min(args.steps, 10))):
+            tc0 = time.perf_counter()
+            bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=ctypes.c_void_p(s_dev.data_ptr()),
+                                 n=n, flags=ab_flags | NO_TABLE).wait()
+            cl.append((time.perf_counter() - tc0) * 1e3)
+        classic_ms = float(np.median(cl[1:]))
+        classic_value = n / classic_ms / 1e3
 
     sharded_check = None
     if distributed:
@@ -1025,6 +1047,12 @@ def main():
             "config": {
                 "workload": "G1 Pippenger MSM, 2^%d (base,scalar) terms per GPU, FullDensity, inputs resident in HBM "
                             "(BASELINE.json configs[1])" % args.log_n,
+                "plan": ("bases registered once with their %d-row %d-bit window table (%.2f GB in HBM at a 128-byte record stride; "
+                         "registration incl. the table build %.0f ms, outside the timed region like the base upload): every digit of a "
+                         "scalar goes to ONE set of 2^%d buckets" % (table_rows, table_bits, table_bytes / 1e9, register_ms, table_bits - 1))
+                        if table_rows else "classic plan: 16 windows of 2^15 buckets over the plain base vector",
+                "value_classic_plan_no_table_per_gpu": round(classic_value, 3) if classic_value else None,
+                "ms_per_step_classic_plan_no_table": round(classic_ms, 4) if classic_ms else None,
                 "sharding": "bases split across ranks, one 96-B all-gather per step" if distributed else "single GPU",
                 "collective": ("%s%s world_size=%d" % (backend, " (RCCL)" if backend == "nccl" else "", world)) if collective else None,
                 "device_ms": {"pipeline": round(float(stage[0]), 4), "digits_sort": round(float(stage[1]), 4),

@@ -142,7 +142,7 @@ def run_tsweep(args):
         n = 1 << log_n
         for c in cs:
             bases = bellman_amd.Bases.copy_device(w, group, dout, n)
-            flags = NO_TABLE if c == 0 else 0
+            flags = (NO_TABLE if c == 0 else 0) | SUITE_FLAGS
             if c:
                 bases.precompute(c)
             for k in ks:
