@@ -231,8 +231,10 @@ static unsigned auto_table_max_log2(int group) {
     return (int)(x < 0 ? 0 : x > 24 ? 24 : x);
   }();
   if (group == BH_G1 && v1 >= 0) return (unsigned)v1;
-  // [r6] G1: up to 2^22 points (it was 2^18): a 13-row table at a 128-byte stride is 1.7 GB per 2^20 points, built in 0.13 s
-  return v >= 0 ? (unsigned)v : 22u;
+  // [r6] G1: up to 2^24 points (it was 2^18): a 13-row table at a 128-byte stride is 1.7 GB per 2^20 points, built in 0.13 s;
+  // 2^23 24.6 -> 21.4 ms, 2^24 44.6 -> 40.5 (profiles/r6_call44_g1_tables_2p23_2p24.txt).  Always within the context's table
+  // budget (a quarter of the memory by default): two of the 28 GB tables of 2^24-point queries fit, the next query stays classic
+  return v >= 0 ? (unsigned)v : (group == BH_G1 ? 24u : 22u);
 }
 // G1 tables of 2^19 points and more are stored at a 128-byte record stride (bh_bases::table_padded);
 // BELLMAN_HIP_TABLE_PAD=0 keeps them dense

@@ -197,8 +197,8 @@ int msm_debug_stages(Context &c, const void *scalars_host, u64 n, int fmt, unsig
   void *sc = alloc(n * 32);
   b.pairs_a = (u64 *)alloc(npairs * 8);
   b.pairs_b = (u64 *)alloc(npairs * 8);
-  b.counts = (u32 *)alloc(ncounts * 4);
-  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts) * 4);
+  b.counts = (u32 *)alloc((ncounts + 1) * 4);
+  b.scan_tmp = (u32 *)alloc(scan_tmp_elems(ncounts + 1) * 4);
   b.zstart = (u32 *)alloc((u64)p.W * 4);
   b.err = (ErrFlags *)alloc(sizeof(ErrFlags));
   b.word_prefix = nullptr;

@@ -113,7 +113,8 @@ __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lan
   v.end = (u32)min((u64)n, b + K);
   v.d_first = (u32)(src[v.begin] >> 32);
   v.d_last = (u32)(src[v.end - 1] >> 32);
-  v.head_partial = v.begin > 0 && (u32)(src[v.begin - 1] >> 32) == v.d_first;
+  // (never look below z: with one bucket set the sort drops the zero digits and what lies there is not an entry)
+  v.head_partial = v.begin > z && (u32)(src[v.begin - 1] >> 32) == v.d_first;
   v.tail_partial = v.end < n && (u32)(src[v.end] >> 32) == v.d_last;
   return true;
 }
@@ -1362,7 +1363,7 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const size_t o_pts = carve((u64)p.NB * sizeof(Pt));
   const size_t zero_bytes = off;
   const size_t o_pairs_a = carve(npairs * 8), o_pairs_b = carve(npairs * 8);
-  const size_t o_counts = carve(ncounts * 4), o_scan = carve(scan_tmp_elems(ncounts) * 4), o_zstart = carve((u64)p.W * 4);
+  const size_t o_counts = carve((ncounts + 1) * 4), o_scan = carve(scan_tmp_elems(ncounts + 1) * 4), o_zstart = carve((u64)p.W * 4);
   const size_t o_head = carve(nslots * sizeof(Pt)), o_tail = carve(nslots * sizeof(Pt));
   const size_t o_long = carve((u64)max_long * sizeof(LongRun)), o_big = carve((u64)max_big * sizeof(BigRun));
   const size_t o_pieces = carve((u64)max_pieces * sizeof(Pt));

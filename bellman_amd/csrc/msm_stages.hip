@@ -148,25 +148,39 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ROUNDS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
 
+// [r6] Plans with ONE bucket set (window tables) drop the zero digits in the first pass instead of sorting them to the front:
+// `drop_zeros` - the pass neither counts nor moves entries whose digit is 0; `live_from` (later passes) - only the
+// n - *live_from entries the first pass kept exist; the last pass writes them to the END of the array (`out_shift`), so that
+// what follows sees exactly what it saw before: *zstart entries to skip, then the sorted non-zero digits.  Boolean-heavy
+// scalars are mostly zero digits (12 of the 13 of a 0 / 1 scalar): a 90 %-boolean 2^20-term multiexp sorted 13.6 M entries to
+// accumulate 1.8 M of them.
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u64 *pairs, u32 *counts, u32 n,
-                                                                u32 shift, u32 num_tiles) {
+                                                                u32 shift, u32 num_tiles, u32 drop_zeros, const u32 *live_from) {
   __shared__ u32 hist[256];
   const u32 tid = threadIdx.x, tile = blockIdx.x, w = blockIdx.y;
   hist[tid] = 0;
   __syncthreads();
   const u64 *src = pairs + (u64)w * n;
+  const u32 nn = live_from ? n - *live_from : n;
 #pragma unroll 4
   for (int r = 0; r < SORT_ROUNDS; r++) {
     u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
-    if (idx < n) atomicAdd(&hist[(u32)(src[idx] >> shift) & 0xff], 1u);
+    if (idx < nn) {
+      const u64 key = src[idx];
+      if (!(drop_zeros && (u32)(key >> 32) == 0)) atomicAdd(&hist[(u32)(key >> shift) & 0xff], 1u);
+    }
   }
   __syncthreads();
   counts[((u64)w * 256 + tid) * num_tiles + tile] = hist[tid];
+  if (drop_zeros && tile == 0 && w == 0 && tid == 0) counts[(u64)gridDim.y * 256 * num_tiles] = 0;   // the scan's total slot
 }
+// after the first pass's scan (one bucket set): the entries it keeps, as the count of those it drops
+__global__ void sort_live_kernel(const u32 *scanned_total, u32 *zstart, u32 n) { zstart[0] = n - *scanned_total; }
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *pairs_in, u64 *pairs_out,
                                                                    const u32 *offsets, u32 n, u32 shift,
-                                                                   u32 num_tiles) {
+                                                                   u32 num_tiles, u32 drop_zeros, const u32 *live_from,
+                                                                   const u32 *out_shift) {
   __shared__ u32 base[256];
   __shared__ u32 wcnt[SORT_THREADS / 64][256];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x, w = blockIdx.y;
@@ -175,6 +189,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
   for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][tid] = 0;
   __syncthreads();
   const u64 *src = pairs_in + (u64)w * n;
+  const u32 nn = live_from ? n - *live_from : n;
+  if (out_shift) pairs_out += *out_shift;
   const u64 lt_mask = ((u64)1 << lane) - 1;
   // all of the thread's keys are loaded before the ranking rounds: one exposed memory latency per tile instead of one
   // per round (the rounds themselves are ballots, LDS and barriers)
@@ -182,13 +198,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; r++) {
     const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
-    keys[r] = idx < n ? src[idx] : 0;
+    keys[r] = idx < nn ? src[idx] : 0;
   }
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; r++) {
     const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
-    const bool valid = idx < n;
     const u64 key = keys[r];
+    const bool valid = idx < nn && !(drop_zeros && (u32)(key >> 32) == 0);
     const u32 bin = (u32)(key >> shift) & 0xff;
     // wavefront match-any over the 8-bit bin: lanes with equal bins
     u64 mask = __ballot(valid);
@@ -301,7 +317,7 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // with 16), 13 bits for G1 2^15 ... 2^18 (2^16 0.71 against 0.87, 2^17 0.93 against 1.03, 2^18 1.38 against 1.42 with 16);
   // G2 keeps its 8-bit rows up to 2^12 (0.80 / 0.97 against 1.02 / 1.07 with 16), takes 10 bits at 2^13 and is back on 16 bits
   // at 2^15 (1.49 against 1.90 ms with the 8-bit rows round 4 chose for it)
-  // [r6, later] 20-bit rows for G1 2^19 ... 2^22 - 13 rows instead of the classic plan's 16 windows, i.e. 19 % fewer additions, into
+  // [r6, later] 20-bit rows for G1 2^19 ... 2^24 - 13 rows instead of the classic plan's 16 windows, i.e. 19 % fewer additions, into
   // ONE set of 2^19 buckets - became the default once that set's reduction stopped costing what the rows save (two-stage row /
   // column sums, bit sums over the selected half, msm_ec.cuh): 2^19 2.01 ms against 2.40 classic and 2.21 with 16-bit rows,
   // 2^20 3.33 against 3.72-3.81 and 3.88, 2^21 6.12 against 6.90, 2^22 11.3 against 12.9 (profiles/r6_call33_tables_after_sums.txt,
@@ -394,24 +410,35 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
   hipLaunchKernelGGL(msm_digits_kernel, dim3((p.nd + 255) / 256), dim3(256), 0, st, scalars_dev, fmt, p.nd,
                      density_dev, b.word_prefix, skip, n_bases, p.c, p.Wd, p.base_stride, b.pairs_a, b.err);
   BH_HIP_CHECK(hipGetLastError());
-  // 2. sort by digit, 8 bits per pass
+  // 2. sort by digit, 8 bits per pass; one bucket set: zero digits dropped by the first pass (BELLMAN_HIP_SORT_DROP_ZEROS=0:
+  // sorted to the front like the classic plan's)
+  static const bool drop_on = [] { const char *e = getenv("BELLMAN_HIP_SORT_DROP_ZEROS"); return !(e && *e == '0'); }();
+  const bool drop = drop_on && p.W == 1;
   u64 *src = b.pairs_a, *dst = b.pairs_b;
   for (u32 pass = 0; pass < p.sort_passes; pass++) {
     const u32 shift = 32 + 8 * pass;
+    const bool first = pass == 0, last = pass + 1 == p.sort_passes;
+    const u32 *live_from = (drop && !first) ? b.zstart : nullptr;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, b.counts, p.n,
-                       shift, p.num_tiles);
+                       shift, p.num_tiles, (drop && first) ? 1u : 0u, live_from);
     BH_HIP_CHECK(hipGetLastError());
-    int rc = exclusive_scan_u32(b.counts, ncounts, b.scan_tmp, st);
+    int rc = exclusive_scan_u32(b.counts, ncounts + ((drop && first) ? 1 : 0), b.scan_tmp, st);
     if (rc) return rc;
+    if (drop && first) {
+      hipLaunchKernelGGL(sort_live_kernel, dim3(1), dim3(1), 0, st, b.counts + ncounts, b.zstart, p.n);
+      BH_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
-                       p.n, shift, p.num_tiles);
+                       p.n, shift, p.num_tiles, (drop && first) ? 1u : 0u, live_from, (drop && last) ? b.zstart : nullptr);
     BH_HIP_CHECK(hipGetLastError());
     std::swap(src, dst);
   }
   *sorted_out = src;
   // 3. where the non-zero digits start in every window
-  hipLaunchKernelGGL(window_zero_count_kernel, dim3((p.W + 63) / 64), dim3(64), 0, st, src, b.zstart, p.n, p.W);
-  BH_HIP_CHECK(hipGetLastError());
+  if (!drop) {
+    hipLaunchKernelGGL(window_zero_count_kernel, dim3((p.W + 63) / 64), dim3(64), 0, st, src, b.zstart, p.n, p.W);
+    BH_HIP_CHECK(hipGetLastError());
+  }
   return BH_OK;
 }
 
