@@ -322,10 +322,12 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // column sums, bit sums over the selected half, msm_ec.cuh): 2^19 2.01 ms against 2.40 classic and 2.21 with 16-bit rows,
   // 2^20 3.33 against 3.72-3.81 and 3.88, 2^21 6.12 against 6.90, 2^22 11.3 against 12.9 (profiles/r6_call33_tables_after_sums.txt,
   // r6_call34_table_bits_mid.txt: 13 bits still win up to 2^18 - 1.37 against 1.38 there)
-  // G2: 20-bit rows from 2^20 points (2^20 9.2-9.4 ms against 9.9-10.1 with 16-bit rows, 2^21 16.6 against 19.1; 2^19 5.7-5.9 against
-  // 5.4: its 2^19-bucket reduction is ~1.9 ms on lane triples against 0.6 for 2^15 buckets - profiles/r6_call40_*, r6_call42_*).
-  // BELLMAN_HIP_G2_TABLE20_FROM=<log2> moves the boundary (A/B)
-  static const u32 g2_from = [] { const char *e = getenv("BELLMAN_HIP_G2_TABLE20_FROM"); long v = e && *e ? strtol(e, nullptr, 10) : 20; return (u32)(v < 0 ? 0 : v); }();
+  // G2 keeps its 16-bit rows.  20-bit rows (bh_bases_precompute(.., 20), or BELLMAN_HIP_G2_TABLE20_FROM=<log2 of the first size that
+  // takes them>) win on UNIFORM scalars from 2^20 points - 2^20 9.2-9.4 ms against 9.9-10.1, 2^21 16.6 against 19.1 (2^19: 5.7-5.9
+  // against 5.4) - but the reduction of their 2^19-bucket set is ~2 ms on lane triples against 0.6 for 2^15 buckets whatever the
+  // scalars are, and the b_g2 query of a real proof meets a boolean-heavy witness: 90 % booleans at 2^20 points 3.9 ms against 2.5
+  // (profiles/r6_call40_*, r6_call42_*, r6_call45_drop_zeros.txt against r6_final_boolean_mix.txt).  Not the default.
+  static const u32 g2_from = [] { const char *e = getenv("BELLMAN_HIP_G2_TABLE20_FROM"); long v = e && *e ? strtol(e, nullptr, 10) : 99; return (u32)(v < 0 ? 0 : v); }();
   if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : lg >= g2_from ? 20 : 16;
   if (lg <= 10) return 13;
   return lg <= 14 ? 10 : lg <= 18 ? 13 : 20;

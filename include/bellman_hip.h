@@ -196,9 +196,10 @@ int bh_bases_write_uncompressed(bh_ctx *ctx, const bh_bases *bases, size_t first
  * The result of a multiexp is the same group element either way.  window_bits = 0 picks the tuned
  * value for the vector length.  Registration (bh_bases_register / _uncompressed / bh_bases_copy_dev) builds this
  * table by itself for G1 vectors of up to 2^24 points and G2 vectors of up to 2^22 while the context's table
- * budget lasts (bh_ctx_set_limits): G1 from 2^19 points and G2 from 2^20 take 20-bit rows - 13 rows, so a
- * multiexp performs 13 n additions instead of the 16 n of the classic 16-window plan - at 13 x 128 bytes per G1
- * point (1.7 GB per 2^20 points; built in ~0.13 s) and 13 x 192 bytes per G2 point.  BH_ERR_HIP when the table does not fit in HBM (the handle stays usable
+ * budget lasts (bh_ctx_set_limits): G1 vectors from 2^19 points take 20-bit rows - 13 rows, so a multiexp
+ * performs 13 n additions instead of the 16 n of the classic 16-window plan - at 13 x 128 bytes per point (1.7 GB
+ * per 2^20 points; built in ~0.13 s); G2 vectors keep 16-bit rows (20-bit ones on request: faster on uniform
+ * scalars from 2^20 points, slower on boolean-heavy ones - their 2^19 buckets cost ~2 ms to reduce).  BH_ERR_HIP when the table does not fit in HBM (the handle stays usable
  * without it); BH_ERR_INVALID_ARG when W x n >= 2^31. */
 int bh_bases_precompute(bh_ctx *ctx, bh_bases *b, unsigned window_bits);
 int bh_bases_table_info(const bh_bases *b, unsigned *window_bits, unsigned *rows, size_t *bytes);
