@@ -121,12 +121,10 @@ __device__ __forceinline__ bool chunk_view(const u64 *src, u32 n, u32 z, u32 lan
 
 // LDS_ACC: the running bucket sum lives in the lane's LDS slot instead of 48/96 VGPRs - for G2 this
 // is the difference between spilling at one wave per SIMD and fitting two.
-// TOUCH [r6]: one lane per G1 point gathering from a window table that does not fit the Infinity Cache (2 GB for 2^20 points):
-// every record is read exactly once, so each gather is an HBM (and TLB) miss that the other resident wavefront only half
-// covers.  The variant reads ONE word of the next entry's record right before the iteration's last, inline product - the
-// same place the PIPELINED form loads its whole next point, for one live register instead of 24 - so that the line is on
-// its way into the L2 while the product runs and the real load of the next iteration finds it there.
-template <class F, bool LDS_ACC, bool TOUCH = false>
+// (measured and removed in round 6: a variant that reads one word of the NEXT entry's record right before the iteration's
+// last, inline product, so that a window table too big for the Infinity Cache is gathered through the L2 - no difference, 2.88
+// against 2.90 ms over a 2 GB table: profiles/r6_call28_touch.txt)
+template <class F, bool LDS_ACC>
 __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, const u32 *zstart,
                                                              const Affine<typename F::Mem> *bases,
                                                              XYZZ<typename F::Mem> *pts, XYZZ<typename F::Mem> *head,
@@ -188,36 +186,6 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const u64 *pairs, c
         adds += xyzz_madd(acc, q, prefetch) ? 1u : 0u;
       }
       q = qn;
-      e = e1;
-      e1 = e2;
-    }
-  } else if constexpr (TOUCH) {
-    static_assert(!TOUCH || (F::LANES == 1 && !LDS_ACC), "the touch variant is the one-lane register kernel");
-    u64 e = src[v.begin];
-    u64 e1 = v.begin + 1 < v.end ? src[v.begin + 1] : e;   // (past the chunk's end: an entry that was read already)
-    for (u32 p = v.begin; p < v.end; p++) {
-      const u32 d = (u32)(e >> 32);
-      if (d != cur) {   // bucket `cur` ends inside this chunk
-        store_xyzz<F>((cur == v.d_first && v.head_partial) ? &head[slot] : &bucket[cur], acc);
-        xyzz_set_identity(acc);
-        cur = d;
-      }
-      Affine<F> q;
-      load_affine<F>(q, base_at((u32)e & 0x7fffffffu));
-      u64 e2 = e1;
-      u32 touched = 0;
-      auto prefetch = [&]() {
-        touched = *reinterpret_cast<const u32 *>(base_at((u32)e1 & 0x7fffffffu));
-        if (p + 2 < v.end) e2 = src[p + 2];
-      };
-      if (aff_is_identity(q)) {
-        saw_identity = true;
-        prefetch();
-      } else {
-        if ((u32)e >> 31) F::neg(q.y, q.y);   // negative digit: add -P
-        adds += xyzz_madd(acc, q, prefetch) ? 1u : 0u;
-      }
-      __asm__ volatile("" : : "v"(touched));   // the word itself is not used: this keeps the load
       e = e1;
       e1 = e2;
     }
@@ -1267,16 +1235,6 @@ static int points_check_t(const void *pts_dev, u64 n, u32 *status_dev, hipStream
 // bundle of the merge and reduction kernels; records in memory are Affine / XYZZ over F::Mem == FR::Mem, so the two
 // can differ: a big G2 job accumulates one lane per point (throughput) and reduces a window table's 2^15 buckets in
 // lane triples (latency).
-// whether the G1 accumulation touches the next entry's record ahead of time (msm_accumulate_kernel<.., TOUCH>): gathers from
-// a window table larger than the Infinity Cache.  BELLMAN_HIP_ACC_TOUCH=0 / 1 forces it off / on for every one-lane G1
-// accumulation (A/B).
-static inline bool touch_next(bool g2, bool use_table, u64 gathered_bytes, u64 /*hbm_total*/) {
-  static const int env = [] { const char *e = getenv("BELLMAN_HIP_ACC_TOUCH"); return e && *e ? (*e == '0' ? 0 : 1) : -1; }();
-  if (g2) return false;
-  if (env >= 0) return env == 1;
-  return use_table && gathered_bytes > ((u64)256 << 20);
-}
-
 template <class F, class FR>
 static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 skip, const void *scalars_dev,
                        u64 n, int fmt, const u64 *density_dev, const MsmOpts &opts, const WindowTable *table) {
@@ -1473,9 +1431,6 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
     if constexpr (F::LANES == 1) {
       if (lds_acc)
         hipLaunchKernelGGL((msm_accumulate_kernel<F, true>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
-                           tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
-      else if (touch_next(G2, use_table, (u64)p.Wd * acc_stride * n_bases, c.hbm_total))
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, false, !G2>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,
                            tail, p.n, p.c, p.chunk, p.chunks_per_window, err, acc_stride);
       else
         hipLaunchKernelGGL((msm_accumulate_kernel<F, false>), grid, dim3(128), 0, st, sorted, b.zstart, acc_bases, pts, head,

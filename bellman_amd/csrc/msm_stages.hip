@@ -162,6 +162,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u64 *pair
   __syncthreads();
   const u64 *src = pairs + (u64)w * n;
   const u32 nn = live_from ? n - *live_from : n;
+  if (tile * SORT_TILE >= nn) {   // nothing left for this tile (later passes of a vector that was mostly zero digits)
+    counts[((u64)w * 256 + tid) * num_tiles + tile] = 0;
+    return;
+  }
 #pragma unroll 4
   for (int r = 0; r < SORT_ROUNDS; r++) {
     u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
   __shared__ u32 base[256];
   __shared__ u32 wcnt[SORT_THREADS / 64][256];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x, w = blockIdx.y;
+  if (live_from && tile * SORT_TILE >= n - *live_from) return;   // (uniform over the workgroup: before any barrier)
   base[tid] = offsets[((u64)w * 256 + tid) * num_tiles + tile];   // global position (all windows)
 #pragma unroll
   for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][tid] = 0;
@@ -329,8 +334,10 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // (profiles/r6_call40_*, r6_call42_*, r6_call45_drop_zeros.txt against r6_final_boolean_mix.txt).  Not the default.
   static const u32 g2_from = [] { const char *e = getenv("BELLMAN_HIP_G2_TABLE20_FROM"); long v = e && *e ? strtol(e, nullptr, 10) : 99; return (u32)(v < 0 ? 0 : v); }();
   if (g2) return lg <= 12 ? 8 : lg == 13 ? 10 : lg >= g2_from ? 20 : 16;
+  // (2^25 points and more - never automatic, 94 GB for 2^26 points - take 24-bit rows: 11 of them into 2^23 buckets; 2^25 75.1 ms
+  // against 83.5 classic and 82.5 / 77.5 with 20- / 22-bit rows, 2^26 145.1 against 162.0: profiles/r6_call46_g1_tables_2p25_2p26.txt)
   if (lg <= 10) return 13;
-  return lg <= 14 ? 10 : lg <= 18 ? 13 : 20;
+  return lg <= 14 ? 10 : lg <= 18 ? 13 : lg <= 24 ? 20 : 24;
 }
 
 MsmPlan make_table_plan(u64 n, const WindowTable &t, unsigned forced_chunk, bool g2, int num_cus) {
