@@ -32,7 +32,7 @@ for wl in "fft 22 5" "msm 2 19 5" "msm 1 16 10" "msm 2 16 10" "mimc 10"; do
   tag=$(echo $wl | tr ' ' '_')
   $P --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o p -- python tools/profile_suite.py $wl > $OUT/prof_$tag.log 2>&1
 done
-for cfg in "bool50,1,20,0" "bool90,1,20,0" "bool50,2,19,1"; do
+for cfg in "bool50,1,20,1" "bool90,1,20,1" "bool50,2,19,1"; do
   IFS=, read mix g ln tb <<< "$cfg"
   tag=${mix}_g${g}_${ln}
   (cd /tmp && MIX=$mix $P --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o p -- python $GRAFT_REPO_ROOT/tools/r6/boolean_mix.py $g $ln $tb 0 5 > $OUT/prof_$tag.log 2>&1)
@@ -41,7 +41,8 @@ stamp "kernel profiles"
 timeout 60 python tools/profile_suite.py sizes 1 8 20 > $OUT/sizes_g1.txt 2>&1
 timeout 60 python tools/profile_suite.py sizes 2 8 20 > $OUT/sizes_g2.txt 2>&1
 timeout 100 python tools/profile_suite.py sizes 1 22 26 > $OUT/sizes_g1_large.txt 2>&1
-(for a in "1 20 0 0" "1 20 0 1" "1 22 0 0" "1 18 1 0" "1 16 1 0" "2 20 1 0" "2 19 1 1"; do timeout 200 python tools/r6/boolean_mix.py $a 9; done) > $OUT/boolean_mix.txt 2>&1
+# (table = 1: a registered vector with its automatic window table - the default plan; "1 20 0 0": the classic plan beside it)
+(for a in "1 20 1 0" "1 20 1 1" "1 22 1 0" "1 20 0 0" "1 18 1 0" "1 16 1 0" "2 20 1 0" "2 19 1 1"; do timeout 200 python tools/r6/boolean_mix.py $a 9; done) > $OUT/boolean_mix.txt 2>&1
 (timeout 40 python tools/profile_suite.py fft 20 10; timeout 40 python tools/profile_suite.py fft 22 10; timeout 40 python tools/profile_suite.py fft 24 5) > $OUT/fft.txt 2>&1
 timeout 40 python tools/profile_suite.py mimc 30 > $OUT/mimc.txt 2>&1
 for i in 1 2; do timeout 60 python tools/profile_suite.py proof 20 7 12 2>&1 | grep create_proof >> $OUT/proof.txt; done

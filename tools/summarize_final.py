@@ -32,6 +32,8 @@ def main():
     cp("mimc.txt", "mimc.txt")
     cp("pmc_extra.json", "pmc_g2_pairs_and_fft.json")
     cp("proof.txt", "proof_2p20.txt")
+    cp("boolean_mix.txt", "boolean_mix.txt")
+    cp("proof_timeline.txt", "proof_timeline.txt")
     with open(os.path.join(prof, tag + "_sizes.txt"), "w") as f:
         for name in ("sizes_g1.txt", "sizes_g1_large.txt", "sizes_g2.txt"):
             if os.path.exists(os.path.join(src, name)):
