@@ -221,3 +221,53 @@ def test_repeated_and_opposite_bases_at_scale(worker, group, log_n):
         plain.release()
         table.release()
         worker.free(dev)
+
+
+@pytest.mark.parametrize("seed", range(10 + int(os.environ.get("BH_FUZZ_EXTRA", "0"))))   # BH_FUZZ_EXTRA=n: n more seeds
+def test_table_plans_fuzz_mid_sizes(worker, seed):
+    """[r6] Randomised sweep of what round 6's second half touched - one bucket set of 2^12 ... 2^19 buckets reduced by two-stage /
+    multi-wavefront sums, zero digits dropped by the first sort pass, chunks in whole rounds: a vector of 2^14 ... 2^20 + a few
+    points with a window table of 13, 16, 18, 19 or 20 bits (G2: 16 or 20 at up to 2^17 points), a forced chunk length or the
+    plan's, a scalar mix, full density or a density map + skip.  Checked against [sum s_i t_i]G (the bases are [t_i]G for known
+    t_i - no oracle multiexp needed at these sizes) and against the classic plan on the same inputs."""
+    import bellman_amd
+    from bellman_amd import _lib
+    from bellman_amd.multiexp import NO_TABLE
+
+    lib = _lib.load()
+    rnd = np.random.default_rng(0x7AB1E + seed)
+    group = 2 if seed % 5 == 4 else 1
+    log_n = int(rnd.integers(14, 18 if group == 2 else 21))
+    n = (1 << log_n) + int(rnd.integers(-300, 300)) if log_n < 20 else (1 << 20) - int(rnd.integers(0, 5000))
+    c = int(rnd.choice([16, 20])) if group == 2 else int(rnd.choice([13, 16, 18, 19, 20]))
+    K = int(rnd.choice([0, 0, 7, 26, 52, 300]))
+    mix = str(rnd.choice(["uniform", "bool50", "bool90", "ones", "small90"]))
+    words = 12 if group == 1 else 24
+    gen = cref.g1_generator() if group == 1 else cref.g2_generator()
+    t = scalar_mixes.scalars("uniform", n, 0xF00 + seed)
+    dt, dout = worker.alloc(n * 32), worker.alloc(n * 8 * words)
+    worker.upload(dt, t)
+    assert lib.bh_fixed_base_mul_dev(worker.ctx, group, gen.ctypes.data_as(ctypes.c_void_p), dt, n, 0, dout, None) == 0
+    worker.synchronize()
+    worker.free(dt)
+    bases = bellman_amd.Bases.copy_device(worker, group, dout, n)
+    bases.precompute(c)
+    assert bases.table_info()[0] == c
+    skip = int(rnd.integers(0, 9))
+    m = n - skip - int(rnd.integers(0, 50))
+    sc = scalar_mixes.scalars(mix, m, 0x5CA + seed)
+    if rnd.random() < 0.5:
+        bits = rnd.random(m) < float(rnd.choice([0.1, 0.5, 0.9]))
+        dmap = bellman_amd.DensityTracker()
+        dmap.bv = bits
+        k = cref.fr_dot(sc[bits], t[skip:skip + int(bits.sum())])
+    else:
+        dmap = bellman_amd.FullDensity()
+        k = cref.fr_dot(sc, t[skip:skip + m])
+    want = cref.point_mul(group, gen, k)
+    got = bellman_amd.multiexp(worker, bases, dmap, sc, skip=skip, chunk=K).wait()
+    assert np.array_equal(got, want), (group, n, c, K, mix, "table")
+    got = bellman_amd.multiexp(worker, bases, dmap, sc, skip=skip, flags=NO_TABLE).wait()
+    assert np.array_equal(got, want), (group, n, c, K, mix, "classic")
+    bases.release()
+    worker.free(dout)
