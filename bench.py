@@ -739,19 +739,23 @@ def bench_scaling_model(worker, lib, log_n_total=26, proof_log_n=24, reps=3):
     base_ms = None
     for ranks in (1, 2, 4, 8):
         n = nmax // ranks
-        bases = bellman_amd.Bases.wrap_device(worker, 1, dout, n)
+        # registered like a rank registers its shard of the CRS query: up to 2^24 points with the 20-bit window table
+        bases = bellman_amd.Bases.copy_device(worker, 1, dout, n)
+        worker.synchronize()
         walls = []
         for it in range(reps + 1):
             t0 = time.perf_counter()
             bellman_amd.multiexp(worker, bases, bellman_amd.FullDensity(), None, scalars_dev=dt, n=n).wait()
             if it:
                 walls.append((time.perf_counter() - t0) * 1e3)
+        bases_rows = bases.table_info()[1]
         bases.release()
         ms = float(np.median(walls)) + (0.1 if ranks > 1 else 0.0)
         base_ms = ms if ranks == 1 else base_ms
         out["msm_2p%d_strong" % log_n_total][str(ranks)] = {"terms_per_rank": n, "predicted_ms": round(ms, 2),
                                                                "predicted_speedup": round(base_ms / ms, 2),
-                                                               "predicted_Mscalar_mul_per_s": round(nmax / ms / 1e3, 1)}
+                                                               "predicted_Mscalar_mul_per_s": round(nmax / ms / 1e3, 1),
+                                                               "window_table_rows": int(bases_rows)}
     worker.free(dt)
     worker.free(dout)
     worker.trim()
@@ -972,7 +976,8 @@ def main():
         assert lib.bh_fixed_base_mul_dev(worker.ctx, 1, G1_GEN_MONT.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(t5.data_ptr()),
                                          n5, 0, ctypes.c_void_p(b5.data_ptr()), None) == 0
         worker.synchronize()
-        bases5 = bellman_amd.Bases.wrap_device(worker, 1, ctypes.c_void_p(b5.data_ptr()), n5)
+        # registered like a CRS query: a shard of up to 2^24 points gets its 20-bit window table (round 6) - 8 ranks: 2^23 each
+        bases5 = bellman_amd.Bases.copy_device(worker, 1, ctypes.c_void_p(b5.data_ptr()), n5)
         s5 = torch.from_numpy(splitmix_scalars(n5, 0x5CA1A25 + rank * 8 * n5).view(np.int64)).cuda()
 
         def step5():
