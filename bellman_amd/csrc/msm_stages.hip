@@ -181,15 +181,24 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const u64 *pair
 // after the first pass's scan (one bucket set): the entries it keeps, as the count of those it drops
 __global__ void sort_live_kernel(const u32 *scanned_total, u32 *zstart, u32 n) { zstart[0] = n - *scanned_total; }
 
+// STAGED [r6]: the tile is first sorted into LDS (same stable ballot ranking, positions relative to the tile) and then copied
+// out, so that neighbouring lanes write neighbouring entries of a bin's run instead of one 8-byte store per bin and round: a
+// timing-only build with coalesced writes put the scattered stores at 25-40 % of the whole sort (0.44 -> 0.33 ms at 2^20,
+// 1.80 -> 1.09 at 2^22: profiles/r6_call52_scatter_writes_upper_bound.txt).
+template <bool STAGED>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *pairs_in, u64 *pairs_out,
                                                                    const u32 *offsets, u32 n, u32 shift,
                                                                    u32 num_tiles, u32 drop_zeros, const u32 *live_from,
                                                                    const u32 *out_shift) {
-  __shared__ u32 base[256];
+  __shared__ u32 base[256];                              // next position of every bin: global, or (STAGED) inside the tile
   __shared__ u32 wcnt[SORT_THREADS / 64][256];
+  __shared__ u32 gbase[STAGED ? 256 : 1];                // STAGED: global position of a bin's run minus its position in the tile
+  __shared__ u32 wsum[STAGED ? SORT_THREADS / 64 : 1];
+  __shared__ u64 stage[STAGED ? SORT_TILE : 1];          // STAGED: the tile, sorted (32 KB)
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x, w = blockIdx.y;
   if (live_from && tile * SORT_TILE >= n - *live_from) return;   // (uniform over the workgroup: before any barrier)
-  base[tid] = offsets[((u64)w * 256 + tid) * num_tiles + tile];   // global position (all windows)
+  const u32 goff = offsets[((u64)w * 256 + tid) * num_tiles + tile];   // global position (all windows)
+  base[tid] = STAGED ? 0u : goff;
 #pragma unroll
   for (int v = 0; v < SORT_THREADS / 64; v++) wcnt[v][tid] = 0;
   __syncthreads();
@@ -204,6 +213,36 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
   for (int r = 0; r < SORT_ROUNDS; r++) {
     const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
     keys[r] = idx < nn ? src[idx] : 0;
+  }
+  u32 tile_total = 0;
+  if constexpr (STAGED) {
+    // the tile's histogram, then its exclusive prefix: where every bin's run starts inside the sorted tile
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+      const u32 idx = tile * SORT_TILE + r * SORT_THREADS + tid;
+      const u64 key = keys[r];
+      if (idx < nn && !(drop_zeros && (u32)(key >> 32) == 0)) atomicAdd(&base[(u32)(key >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    const u32 cnt = base[tid];
+    u32 x = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 y = __shfl_up(x, off);
+      if (lane >= (u32)off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u32 woff = 0;
+#pragma unroll
+    for (int v = 0; v < SORT_THREADS / 64; v++) {
+      if ((u32)v < wave) woff += wsum[v];
+      tile_total += wsum[v];
+    }
+    const u32 lstart = woff + x - cnt;
+    base[tid] = lstart;
+    gbase[tid] = goff - lstart;
+    __syncthreads();
   }
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; r++) {
@@ -224,7 +263,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
     if (valid) {
       u32 off = base[bin] + rank;
       for (u32 v = 0; v < wave; v++) off += wcnt[v][bin];
-      pairs_out[off] = key;
+      if constexpr (STAGED) stage[off] = key; else pairs_out[off] = key;
     }
     __syncthreads();
     u32 tot = 0;
@@ -232,6 +271,12 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const u64 *p
     for (int v = 0; v < SORT_THREADS / 64; v++) { tot += wcnt[v][tid]; wcnt[v][tid] = 0; }
     base[tid] += tot;
     __syncthreads();
+  }
+  if constexpr (STAGED) {
+    for (u32 j = tid; j < tile_total; j += SORT_THREADS) {
+      const u64 key = stage[j];
+      pairs_out[gbase[(u32)(key >> shift) & 0xff] + j] = key;
+    }
   }
 }
 
@@ -423,6 +468,8 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
   // sorted to the front like the classic plan's)
   static const bool drop_on = [] { const char *e = getenv("BELLMAN_HIP_SORT_DROP_ZEROS"); return !(e && *e == '0'); }();
   const bool drop = drop_on && p.W == 1;
+  // tiles sorted in LDS and copied out (sort_scatter_kernel<true>).  BELLMAN_HIP_SORT_STAGED=0: one store per entry and round
+  static const bool staged_on = [] { const char *e = getenv("BELLMAN_HIP_SORT_STAGED"); return !(e && *e == '0'); }();
   u64 *src = b.pairs_a, *dst = b.pairs_b;
   for (u32 pass = 0; pass < p.sort_passes; pass++) {
     const u32 shift = 32 + 8 * pass;
@@ -437,8 +484,12 @@ int msm_run_stages(const MsmPlan &p, const MsmBuffers &b, const void *scalars_de
       hipLaunchKernelGGL(sort_live_kernel, dim3(1), dim3(1), 0, st, b.counts + ncounts, b.zstart, p.n);
       BH_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
-                       p.n, shift, p.num_tiles, (drop && first) ? 1u : 0u, live_from, (drop && last) ? b.zstart : nullptr);
+    if (staged_on)
+      hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
+                         p.n, shift, p.num_tiles, (drop && first) ? 1u : 0u, live_from, (drop && last) ? b.zstart : nullptr);
+    else
+      hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(p.num_tiles, p.W), dim3(SORT_THREADS), 0, st, src, dst, b.counts,
+                         p.n, shift, p.num_tiles, (drop && first) ? 1u : 0u, live_from, (drop && last) ? b.zstart : nullptr);
     BH_HIP_CHECK(hipGetLastError());
     std::swap(src, dst);
   }
