@@ -11,7 +11,9 @@
 //                  W = ceil(256/c) SIGNED c-bit digits (carry between windows) and written as
 //                  (|digit| << 32 | sign << 31 | base) pairs, window-major.       msm_stages.hip
 //   2. sort        stable LSD radix sort of every window's pairs by |digit|, 8 bits per pass;
-//                  ranking inside a tile uses wavefront ballots (match-any) + popcounts.
+//                  ranking inside a tile uses wavefront ballots (match-any) + popcounts; the tile is sorted
+//                  into LDS and copied out in runs.  One bucket set (window tables): the first pass drops
+//                  the zero digits.
 //   3. chunks      the sorted stream of every window (zero digits skipped) is cut into equal
 //                  chunks of K entries: every lane performs exactly K mixed additions whatever
 //                  the bucket-size distribution.
