@@ -1372,9 +1372,15 @@ static int msm_enqueue(MsmJobImpl &job, const void *bases_dev, u64 n_bases, u64 
   const u64 *sorted = nullptr;
   // small multiexps over a window table: one launch for everything up to the filled buckets (msm_small_fill_kernel)
   static const bool small_on = [] { const char *e = getenv("BELLMAN_HIP_SMALL_FUSED"); return !(e && *e == '0'); }();
+  // ... and only when no bucket is EXPECTED to outgrow its list: rows whose top one is a sliver of t = 255 - (Wd - 1) c bits (10-bit
+  // rows: t = 5, 11 bits: 2, 12 bits: 3) send the top digit of every scalar to 2^t buckets, nd / 2^t entries each - such buckets fall
+  // back to a scan of the whole digit table per worker (an explicit 11-bit table over 2^9 points took 8.9 ms in this kernel against
+  // 0.7 through the sort: profiles/r6_call54_tiny_g2_bits.txt); the default 13-bit tables have t = 8
+  const u32 top_bits = 255u - (p.Wd - 1) * p.c;
+  const u64 sliver_load = top_bits >= 31 ? 0 : ((u64)p.nd >> top_bits);
   const bool small_fused = small_on && use_table && !opts.padded_table && p.W == 1 && p.nd <= SMALL_MAX_SCALARS && p.n <= SMALL_MAX_ENTRIES &&
                            (u64)p.n <= (u64)SMALL_MAX_PER_BUCKET * p.nb && p.c <= 15 && small_fill_lds_bytes(p.nd, p.n) <= 64 * 1024 &&
-                           !(opts.flags & BH_MSM_NO_SMALL_PATH);
+                           sliver_load + (u64)p.n / p.nb <= SMALL_LIST_CAP / 2 && !(opts.flags & BH_MSM_NO_SMALL_PATH);
   if (small_fused) {
     const u32 bpb = workers_per_block<F>(SMALL_THREADS, tree_per_wave<F>()) / SMALL_LANES_PER_BUCKET;   // buckets per workgroup
     const size_t lds = small_fill_lds_bytes(p.nd, p.n);

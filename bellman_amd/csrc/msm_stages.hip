@@ -383,8 +383,9 @@ unsigned table_window_bits(u64 n_bases, bool g2) {
   // [r6] tiny G2 vectors (up to 2^10 points): 13-bit rows like G1 - 20 n entries over 4096 buckets qualify for the one-launch path
   // (msm_small_fill_kernel: at most 16 entries per bucket on average), which the 8-bit rows' 128 buckets never did: 2^8 0.45 against
   // 0.60 ms, 2^9 0.45 against 0.51, 2^10 0.48 against 0.54 - the b_g2 multiexp was the critical path of a MiMC-322 proof; 2^12: 10 bits
-  // (0.70 against 0.78).  (Explicit 10- to 12-bit tables over 2^8 ... 2^9 points take that path too and are pathologically slow in
-  // it - 2-9 ms, bucket lists that overflow: profiles/r6_call54_tiny_g2_bits.txt.  No default plan goes there.)
+  // (0.70 against 0.78).  (Explicit 10- to 12-bit tables over 2^8 ... 2^9 points used to take that path too and were pathologically slow
+  // in it - 2-9 ms, bucket lists overflowing under a sliver top row: profiles/r6_call54_tiny_g2_bits.txt; msm_enqueue now declines
+  // the path for such plans, r6_call56_small_path_guard.txt.)
   if (g2) return lg <= 10 ? 13 : lg == 11 ? 8 : lg <= 13 ? 10 : lg >= g2_from ? 20 : 16;
   // (2^25 points and more - never automatic, 94 GB for 2^26 points - take 24-bit rows: 11 of them into 2^23 buckets; 2^25 75.1 ms
   // against 83.5 classic and 82.5 / 77.5 with 20- / 22-bit rows, 2^26 145.1 against 162.0: profiles/r6_call46_g1_tables_2p25_2p26.txt)
