@@ -19,20 +19,33 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def fold_partials(partial, group, device=None, process_group=None):
-    """all-gather every rank's partial affine record and add them up (same result on all ranks)."""
+def _all_gather_records(record, device=None, process_group=None):
+    """every rank's record (a small uint64 array) as the rows of one host array [world, len]: ONE collective into one
+    tensor and ONE copy back to the host - a list of `world` tensors brought back one by one was `world` synchronising
+    copies per step (8 x ~20 us at 8 ranks, next to a 3.3 ms multiexp)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(process_group)
-    mine = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
+    mine = torch.from_numpy(np.ascontiguousarray(record, dtype=np.uint64).view(np.int64).copy())
     if device is not None:
         mine = mine.to(device)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=process_group)
-    total = parts[0].cpu().numpy().view(np.uint64)
+    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    try:
+        dist.all_gather_into_tensor(out, mine, group=process_group)
+    except (RuntimeError, NotImplementedError, AttributeError):   # a backend without the tensor form
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=process_group)
+        out = torch.stack(parts)
+    return out.cpu().numpy().view(np.uint64)
+
+
+def fold_partials(partial, group, device=None, process_group=None):
+    """all-gather every rank's partial affine record and add them up (same result on all ranks)."""
+    parts = _all_gather_records(partial, device=device, process_group=process_group)
+    total = parts[0]
     for p in parts[1:]:
-        total = point_add(group, total, p.cpu().numpy().view(np.uint64))
+        total = point_add(group, total, p)
     return total
 
 
@@ -48,20 +61,12 @@ def sharded_multiexp(worker, bases_shard, density_map, scalars_shard, group, dev
 
 def fold_sums(sums, process_group=None, device=None):
     """all-gather every rank's multiexp-result record (960 B) and add them slot-wise."""
-    import torch
-    import torch.distributed as dist
-
     from .groth16 import sums_add
 
-    world = dist.get_world_size(process_group)
-    mine = torch.from_numpy(np.ascontiguousarray(sums, dtype=np.uint64).view(np.int64).copy())
-    if device is not None:
-        mine = mine.to(device)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=process_group)
-    total = parts[0].cpu().numpy().view(np.uint64)
+    parts = _all_gather_records(sums, device=device, process_group=process_group)
+    total = parts[0]
     for p in parts[1:]:
-        total = sums_add(total, p.cpu().numpy().view(np.uint64))
+        total = sums_add(total, p)
     return total
 
 
