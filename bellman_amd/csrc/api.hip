@@ -266,19 +266,6 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
   static const bool pad_on = [] { const char *e = getenv("BELLMAN_HIP_BASE_PAD"); return !(e && *e == '0'); }();
   const unsigned lg_table = auto_table_max_log2(group);
   const bool table_size = lg_table && n > TINY_MSM_MAX && n <= (size_t(1) << lg_table);   // (takes a window table instead)
-  if (pad_on && group == BH_G1 && !table_size && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
-      (ctx->c.hbm_total == 0 || n * 128 <= ctx->c.hbm_total / 16)) {
-    if (hipMalloc(&b->padded, n * 128) == hipSuccess) {
-      if (hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
-        (void)hipFree(b->padded);
-        b->padded = nullptr;
-      }
-    } else {
-      (void)hipGetLastError();
-      b->padded = nullptr;
-    }
-  }
   if (table_size) {
     const size_t need = table_bytes_for(b, table_window_bits(n, group == BH_G2));
     bool fits;
@@ -298,6 +285,21 @@ static int new_bases(bh_ctx *ctx, int group, void *dev, size_t n, bool owned, bh
         std::lock_guard<std::mutex> g(ctx->c.job_mu);
         ctx->c.table_bytes -= need;
       }
+    }
+  }
+  // (a vector that got its window table gathers from the table; one that did not - too large, or over the table budget - gets the
+  // 128-byte-stride copy of its points for the classic plan's gathers)
+  if (pad_on && group == BH_G1 && !b->table && n >= ((size_t)1 << 17) && n < ((size_t)1 << 31) &&
+      (ctx->c.hbm_total == 0 || n * 128 <= ctx->c.hbm_total / 16)) {
+    if (hipMalloc(&b->padded, n * 128) == hipSuccess) {
+      if (hipMemcpy2DAsync(b->padded, 128, dev, 96, 96, n, hipMemcpyDeviceToDevice, ctx->c.stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->c.stream) != hipSuccess) {
+        (void)hipFree(b->padded);
+        b->padded = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      b->padded = nullptr;
     }
   }
   *out = b;
